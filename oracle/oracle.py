@@ -1,0 +1,240 @@
+"""ctypes front-end of the CPU parity oracle (oracle/swd_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Allowed importers: tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+
+The classes mirror the reference's Cython classes (constructor kwargs, ``decode``,
+properties) so that parity tests read like calls into the reference:
+  osd_window          /root/reference/src/osd_window.pyx
+  bpgdg_decoder etc.  /root/reference/src/bp_guessing_decoder.pyx
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libswd_oracle.so")
+    src = os.path.join(_HERE, "swd_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libswd_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class _Result(C.Structure):
+    _fields_ = [("converge", C.c_int32), ("bp_iteration", C.c_int32), ("exit_class", C.c_int32),
+                ("reserved", C.c_int32), ("min_pm", C.c_double)]
+
+
+RESULT_DTYPE = np.dtype([("converge", "<i4"), ("bp_iteration", "<i4"), ("exit_class", "<i4"),
+                         ("reserved", "<i4"), ("min_pm", "<f8")])
+
+
+class _OsdwParams(C.Structure):
+    _fields_ = [("pre_max_iter", C.c_int32), ("post_max_iter", C.c_int32),
+                ("ms_scaling_factor", C.c_double), ("new_n", C.c_int32),
+                ("osd_method", C.c_int32), ("osd_order", C.c_int32)]
+
+
+class _GdgParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("ms_scaling_factor", C.c_double),
+                ("max_iter_per_step", C.c_int32), ("max_step", C.c_int32),
+                ("max_tree_depth", C.c_int32), ("max_side_depth", C.c_int32),
+                ("max_tree_branch_step", C.c_int32), ("max_side_branch_step", C.c_int32),
+                ("gdg_factor", C.c_double), ("new_n", C.c_int32), ("low_error_mode", C.c_int32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.swo_graph_create.restype = C.c_void_p
+        L.swo_graph_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.swo_graph_free.argtypes = [C.c_void_p]
+        L.swo_graph_rank.argtypes = [C.c_void_p]
+        L.swo_osdw_create.restype = C.c_void_p
+        L.swo_osdw_create.argtypes = [C.c_void_p, C.POINTER(_OsdwParams)]
+        L.swo_osdw_free.argtypes = [C.c_void_p]
+        L.swo_osdw_clear_history.argtypes = [C.c_void_p]
+        L.swo_osdw_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Result)]
+        L.swo_osdw_decode_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        for f in ("swo_osdw_history", "swo_osdw_osd0", "swo_osdw_bp", "swo_gdg_history"):
+            getattr(L, f).restype = C.c_void_p
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.swo_gdg_create.restype = C.c_void_p
+        L.swo_gdg_create.argtypes = [C.c_void_p, C.POINTER(_GdgParams)]
+        L.swo_gdg_free.argtypes = [C.c_void_p]
+        L.swo_gdg_clear_history.argtypes = [C.c_void_p]
+        L.swo_gdg_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_Result)]
+        _LIB = L
+    return _LIB
+
+
+_OSD_METHODS = {  # osd_window.pyx:69-79
+    0: ["osd_0", "0", "osd0"],
+    1: ["osd_e", "1", "osde", "exhaustive", "e"],
+    2: ["osd_cs", "2", "osdcs", "combination_sweep", "cs"],
+}
+
+
+def parse_osd_method(osd_method, osd_order):
+    s = str(osd_method).lower()
+    for k, names in _OSD_METHODS.items():
+        if s in names:
+            return k, (0 if k == 0 else int(osd_order))
+    raise ValueError(f"ERROR: OSD method '{osd_method}' invalid. Please choose from the following "
+                     "methods: 'OSD_0', 'OSD_E' or 'OSD_CS'.")
+
+
+class _Graph:
+    def __init__(self, pcm, channel_probs):
+        if not (isinstance(pcm, np.ndarray) or sp.issparse(pcm)):
+            raise TypeError("The input matrix is of an invalid type. Please input a np.ndarray or "
+                            f"scipy.sparse.spmatrix object, not {type(pcm)}")
+        a = sp.csr_matrix(pcm)
+        a.eliminate_zeros()
+        a.sort_indices()
+        self.m, self.n = a.shape
+        probs = np.ascontiguousarray(channel_probs, dtype=np.float64)
+        if len(probs) != self.n:
+            raise ValueError("The length of the channel probability vector must be eqaul to the "
+                             f"block length n={self.n}.")
+        self.row_ptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+        self.col_idx = np.ascontiguousarray(a.indices, dtype=np.int32)
+        self.probs = probs
+        self.h = lib().swo_graph_create(self.m, self.n, self.row_ptr.ctypes.data,
+                                        self.col_idx.ctypes.data, probs.ctypes.data)
+        self.rank = lib().swo_graph_rank(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().swo_graph_free(self.h)
+            self.h = None
+
+
+def _synd_u8(s, m):
+    s = np.asarray(s)
+    if s.shape[0] != m:
+        raise ValueError(f"The input to the ldpc.bp_decoder.decode must be a syndrome (of length={m}). "
+                         f"The inputted vector has length={s.shape[0]}.")
+    return np.ascontiguousarray(s.astype(np.int64).astype(np.uint8))
+
+
+class osd_window:
+    def __init__(self, parity_check_matrix, **kw):
+        self._g = _Graph(parity_check_matrix, kw.get("channel_probs"))
+        self.m, self.n = self._g.m, self._g.n
+        method, order = parse_osd_method(kw.get("osd_method", "osd_0"), kw.get("osd_order", 0))
+        new_n = kw.get("new_n", None)
+        p = _OsdwParams(int(kw.get("pre_max_iter", 8)), int(kw.get("post_max_iter", 100)),
+                        float(kw.get("ms_scaling_factor", 1.0)), int(new_n) if new_n else 0,
+                        method, order)
+        self.new_n = min(self.n, 2 * self.m) if not new_n else min(int(new_n), self.n)
+        self.rank = self._g.rank
+        self._h = lib().swo_osdw_create(self._g.h, C.byref(p))
+        if not self._h:
+            raise ValueError("For this code, the OSD order should be set in the range "
+                             f"0<=osd_oder<={self.new_n - self.rank}.")
+        self._res = _Result()
+        self._out = np.zeros(self.n, dtype=np.uint8)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().swo_osdw_free(self._h)
+            self._h = None
+
+    def clear_history(self):
+        lib().swo_osdw_clear_history(self._h)
+
+    def decode(self, syndrome):
+        s = _synd_u8(syndrome, self.m)
+        lib().swo_osdw_decode(self._h, s.ctypes.data, self._out.ctypes.data, C.byref(self._res))
+        return self._out.astype(np.int64)
+
+    def decode_batch(self, syndromes):
+        s = np.ascontiguousarray(np.asarray(syndromes).astype(np.uint8))
+        B = s.shape[0]
+        out = np.zeros((B, self.n), dtype=np.uint8)
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        lib().swo_osdw_decode_batch(self._h, B, s.ctypes.data, out.ctypes.data, res.ctypes.data)
+        return out, res
+
+    bp_iteration = property(lambda self: self._res.bp_iteration)
+    converge = property(lambda self: self._res.converge)
+    min_pm = property(lambda self: self._res.min_pm)
+    exit_class = property(lambda self: self._res.exit_class)
+
+    def _vec(self, fn):
+        p = getattr(lib(), fn)(self._h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (self.n,)).astype(np.int64)
+
+    bp_decoding = property(lambda self: self._vec("swo_osdw_bp"))
+    osd0_decoding = property(lambda self: self._vec("swo_osdw_osd0"))
+
+    @property
+    def osdw_decoding(self):
+        return self._out.astype(np.int64)
+
+    @property
+    def log_prob_ratios(self):
+        p = lib().swo_osdw_history(self._h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (self.n, 4)).copy()
+
+
+class _GdgBase:
+    _mode = 2
+
+    def __init__(self, parity_check_matrix, **kw):
+        self._g = _Graph(parity_check_matrix, kw.get("channel_probs"))
+        self.m, self.n = self._g.m, self._g.n
+        new_n = kw.get("new_n", None)
+        p = _GdgParams(int(kw.get("max_iter", 50)), float(kw.get("ms_scaling_factor", 1.0)),
+                       int(kw.get("max_iter_per_step", 6)), int(kw.get("max_step", 25)),
+                       int(kw.get("max_tree_depth", 3)), int(kw.get("max_side_depth", 10)),
+                       int(kw.get("max_tree_branch_step", 10)), int(kw.get("max_side_branch_step", 10)),
+                       float(kw.get("gdg_factor", kw.get("gd_factor", 1.0))),
+                       int(new_n) if new_n else 0, int(bool(kw.get("low_error_mode", False))))
+        self._h = lib().swo_gdg_create(self._g.h, C.byref(p))
+        self._res = _Result()
+        self._out = np.zeros(self.n, dtype=np.uint8)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().swo_gdg_free(self._h)
+            self._h = None
+
+    def clear_history(self):
+        lib().swo_gdg_clear_history(self._h)
+
+    def decode(self, syndrome):
+        s = _synd_u8(syndrome, self.m)
+        lib().swo_gdg_decode(self._h, self._mode, s.ctypes.data, self._out.ctypes.data, C.byref(self._res))
+        return self._out.astype(np.int64)
+
+    converge = property(lambda self: self._res.converge)
+    min_pm = property(lambda self: self._res.min_pm)
+
+    @property
+    def log_prob_ratios(self):
+        p = lib().swo_gdg_history(self._h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (self.n, 4)).copy()
+
+
+class bp_history_decoder(_GdgBase):
+    _mode = 2
+
+
+class bpgdg_decoder(_GdgBase):
+    _mode = 0
+
+
+class bpgd_decoder(_GdgBase):
+    _mode = 1

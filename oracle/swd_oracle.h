@@ -1,0 +1,105 @@
+/*
+ * swd_oracle.h -- CPU restatement of the reference decoders (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for the MI355X sliding-window decoder.  It restates, in plain
+ * C over CSR/CSC index arrays, the algorithms of gongaa/SlidingWindowDecoder:
+ *   osd_window            /root/reference/src/osd_window.pyx
+ *   bp_history_decoder    /root/reference/src/bp_guessing_decoder.pyx:5-158
+ *   bpgdg_decoder (gdg)   /root/reference/src/bp_guessing_decoder.pyx:160-442 + src/include/bpgd.cpp
+ *   bpgd_decoder  (gd)    /root/reference/src/bp_guessing_decoder.pyx:473-571 + src/include/bpgd.cpp:258-286
+ *   LU / OSD helpers      /root/reference/src/include/mod2sparse_extra.cpp:78-376
+ *
+ * It is pinned against golden vectors produced by the reference's own compiled Cython
+ * extension (tests/golden/, generator script tests/golden/make_golden.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (slidingwindowdecoder_amd) never links, imports or calls it.
+ */
+#ifndef SWD_ORACLE_H
+#define SWD_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct swo_graph swo_graph;
+
+/* CSR of an m x n GF(2) matrix (column indices ascending inside each row) + per-column
+ * fault probabilities; llr = log((1-p)/p) as osd_window.pyx:113. */
+swo_graph *swo_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *col_idx,
+                            const double *channel_probs);
+void swo_graph_free(swo_graph *g);
+int swo_graph_rank(const swo_graph *g); /* mod2sparse_extra.cpp:32-76 (value only) */
+
+/* exit classes */
+enum {
+    SWO_EXIT_PRE = 0,      /* pre-processing BP converged   (osd_window.pyx:166-170) */
+    SWO_EXIT_POST = 1,     /* post-processing BP converged  (osd_window.pyx:188-192) */
+    SWO_EXIT_OSD = 2,      /* OSD ran                        (osd_window.pyx:193-195) */
+    SWO_EXIT_FAIL_SET = 3, /* "setting vn failed"            (osd_window.pyx:179-181) */
+    SWO_EXIT_FAIL_PEEL = 4,/* "peeling failed"               (osd_window.pyx:184-186) */
+    SWO_EXIT_NO_OSD = 5    /* post BP failed and osd_order == -1 (osd_window.pyx:199) */
+};
+
+typedef struct {
+    int32_t pre_max_iter;
+    int32_t post_max_iter;
+    double ms_scaling_factor;
+    int32_t new_n;      /* <=0 : min(n, 2m) */
+    int32_t osd_method; /* 0 osd_0, 1 osd_e, 2 osd_cs */
+    int32_t osd_order;
+} swo_osdw_params;
+
+typedef struct {
+    int32_t converge;
+    int32_t bp_iteration;
+    int32_t exit_class;
+    int32_t reserved;
+    double min_pm;
+} swo_result;
+
+/* One osd_window object: holds the persistent LLR history exactly like the reference
+ * object does (osd_window.pyx:53-56; slots are never cleared between decodes). */
+typedef struct swo_osdw swo_osdw;
+swo_osdw *swo_osdw_create(const swo_graph *g, const swo_osdw_params *p);
+void swo_osdw_free(swo_osdw *d);
+void swo_osdw_clear_history(swo_osdw *d);
+/* decode one syndrome; out[n] receives the returned vector (bp/osdw decoding). */
+int swo_osdw_decode(swo_osdw *d, const uint8_t *synd, uint8_t *out, swo_result *res);
+const double *swo_osdw_history(const swo_osdw *d);  /* n x 4 */
+const uint8_t *swo_osdw_osd0(const swo_osdw *d);    /* n */
+const uint8_t *swo_osdw_bp(const swo_osdw *d);      /* n */
+/* batch helper for the CPU baseline: B syndromes, fresh history for every shot */
+int swo_osdw_decode_batch(swo_osdw *d, int B, const uint8_t *synd, uint8_t *out,
+                          swo_result *res);
+
+/* ---- GDG / BPGD (bp_guessing_decoder.pyx) ---- */
+typedef struct {
+    int32_t max_iter;
+    double ms_scaling_factor;
+    int32_t max_iter_per_step;
+    int32_t max_step;
+    int32_t max_tree_depth;
+    int32_t max_side_depth;
+    int32_t max_tree_branch_step;
+    int32_t max_side_branch_step;
+    double gdg_factor;
+    int32_t new_n; /* <=0 : min(n, 2m) */
+    int32_t low_error_mode;
+} swo_gdg_params;
+
+typedef struct swo_gdg swo_gdg;
+swo_gdg *swo_gdg_create(const swo_graph *g, const swo_gdg_params *p);
+void swo_gdg_free(swo_gdg *d);
+void swo_gdg_clear_history(swo_gdg *d);
+/* mode 0: bpgdg_decoder.decode (single thread gdg); mode 1: bpgd_decoder.decode (gd);
+ * mode 2: bp_history_decoder (plain BP only) */
+int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_result *res);
+const double *swo_gdg_history(const swo_gdg *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
