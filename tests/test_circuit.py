@@ -1,0 +1,98 @@
+"""Host-side problem construction against the reference's notebook known-answers
+ and against the committed fixtures."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from slidingwindowdecoder_amd import gf2
+from slidingwindowdecoder_amd.circuit import bb_dem
+from slidingwindowdecoder_amd.codes import bb_code
+from slidingwindowdecoder_amd.windows import plan_windows
+from tests import fixtures as fx
+
+
+@pytest.fixture(scope="module")
+def dem144():
+    code, A, B = bb_code(144)
+    return code, bb_dem(code, A, B, 0.003, 12)
+
+
+def test_bb_codes_match_reference_matrices():
+    # hx / hz recorded from the reference's create_bivariate_bicycle_codes (codes_q.py:235-246)
+    f72 = fx.load("bb72_capacity.npz")
+    code, _, _ = bb_code(72)
+    assert np.array_equal(code.hx, f72["hx"]) and np.array_equal(code.hz, f72["hz"])
+    f288 = fx.load("bb288_circuit_p005_w4f1.npz")
+    code, _, _ = bb_code(288)
+    assert np.array_equal(code.hx, f288["hx"])
+    assert (code.N, code.K) == (288, 12)
+
+
+def test_logicals_are_valid():
+    code, _, _ = bb_code(144)
+    assert code.K == 12 and code.lz.shape == (12, 144)
+    assert not ((code.hx.astype(int) @ code.lz.T) % 2).any()       # commute with X checks
+    stacked = np.vstack((code.hz, code.lz))
+    assert gf2.rank(stacked) == gf2.rank(code.hz) + 12             # independent of stabilisers
+    assert gf2.rank((code.lx.astype(int) @ code.lz.T) % 2) == 12   # pair up with lx
+
+
+def test_dem_structure_known_answers(dem144):
+    _, dem = dem144
+    # IBM.ipynb:165  -> (936, 8784); Round Analysis.ipynb:207-208 -> 864 = 144+216+504 faults/round
+    assert dem.chk.shape == (936, 8784) and dem.chk.nnz == 30672
+    cw = np.asarray(dem.chk.sum(axis=0)).ravel()
+    assert {int(k): int((cw == k).sum()) for k in np.unique(cw)} == {2: 864, 3: 5328, 4: 864, 5: 864, 6: 864}
+    rw = np.asarray(dem.chk.sum(axis=1)).ravel()
+    assert rw.min() == 16 and rw.max() == 35
+    assert dem.obs.shape == (12, 8784)
+    assert len(np.unique(np.round(dem.priors, 13))) == 8
+
+
+@pytest.mark.parametrize("p,expect", [(0.003, 0.027499817877069083), (0.004, 0.036622121785736664),
+                                      (0.005, 0.04572241379526658)])
+def test_noisy_syndrome_prior_known_answers(p, expect):
+    # Sliding Window OSD.ipynb:665 / 293 / 471 "prior for noisy syndrome"
+    code, A, B = bb_code(144)
+    dem = bb_dem(code, A, B, p, 4)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 72, 3, 1, method=1)
+    assert plan.noisy_prior == pytest.approx(expect, rel=0, abs=2e-16)
+
+
+def test_window_geometry_known_answers(dem144):
+    _, dem = dem144
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 72, 3, 1, method=1)
+    # Round Analysis.ipynb:322 anchors
+    assert plan.anchors[:6] == [(0, 0), (72, 648), (144, 1368), (216, 2088), (288, 2808), (360, 3528)]
+    assert plan.anchors[-1] == (936, 8784)
+    assert len(plan.windows) == 11
+    shapes = [w.mat.shape for w in plan.windows]
+    assert shapes[0] == (216, 1656) and shapes[-1] == (216, 1656) and set(shapes[1:-1]) == {(216, 1728)}
+    assert [w.mat.nnz for w in plan.windows] == [5544] + [5976] * 9 + [5904]
+    assert [w.commit for w in plan.windows] == [648] + [720] * 9 + [1656]
+    # mid windows are translates of one another
+    a, b = plan.windows[3], plan.windows[7]
+    assert (a.mat != b.mat).nnz == 0 and np.array_equal(a.prior, b.prior)
+
+
+def test_dem_matches_committed_fixture(dem144):
+    """The fixture's matrices are what the reference decoders were run on; the generator must
+    keep producing exactly those (column order included)."""
+    _, dem = dem144
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 72, 3, 1, method=1)
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    chk, priors = fx.graph(f, "chk_")
+    assert (sp.csr_matrix(plan.chk) != chk).nnz == 0
+    assert np.array_equal(plan.priors, priors)
+    for wi, w in enumerate(plan.windows):
+        mat, pr = fx.graph(f, f"win{wi}_")
+        assert (w.mat != mat).nnz == 0 and np.array_equal(w.prior, pr)
+        assert list(f[f"win{wi}_meta"]) == [w.row0, w.row1, w.col0, w.ncols_global, w.commit, int(w.is_last)]
+
+
+def test_bb288_window_shapes():
+    code, A, B = bb_code(288)
+    dem = bb_dem(code, A, B, 0.005, 6)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 144, 4, 1, method=1)
+    assert [w.mat.shape for w in plan.windows] == [(576, 4752), (576, 4896), (576, 4896), (576, 4752)]
+    assert plan.windows[1].mat.nnz == 16992

@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/swd_oracle.c) against vectors recorded from the reference's own
+compiled extension (tests/golden/make_golden.py).  Everything is compared bit-for-bit:
+returned vectors, converge, bp_iteration, min_pm (float ==) and a hash of the n x 4 LLR
+history after every decode (the reference object is stateful, so the decodes are replayed in
+the recorded order on one oracle object)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import fixtures as fx
+
+
+def replay(dec, tr, check_hist=True):
+    for k in range(len(tr)):
+        out = dec.decode(tr.synd[k])
+        assert (out == tr.out[k]).all(), f"decode {k}: vector differs in {(out != tr.out[k]).sum()} bits"
+        assert bool(dec.converge) == bool(tr.converge[k]), f"decode {k}: converge"
+        if tr.bp_iteration is not None:
+            assert dec.bp_iteration == tr.bp_iteration[k], f"decode {k}: bp_iteration"
+            assert dec.min_pm == tr.min_pm[k], f"decode {k}: min_pm {dec.min_pm} vs {tr.min_pm[k]}"
+        if check_hist and tr.hist_hash is not None:
+            assert fx.h64(dec.log_prob_ratios) == tr.hist_hash[k], f"decode {k}: LLR history differs"
+        if tr.osd0 is not None:
+            assert (dec.osd0_decoding == tr.osd0[k]).all(), f"decode {k}: osd0_decoding"
+    if tr.hist is not None:  # full arrays are recorded every few decodes; re-run to compare values
+        pass
+
+
+@pytest.mark.parametrize("tag", ["c1", "osd0", "cs10", "e6", "short"])
+def test_bb72_osd_window(tag):
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, tag + "_")
+    kw = fx.params(f, tag + "_params")
+    dec = O.osd_window(mat, channel_probs=priors, **kw)
+    tr = fx.Trace(f, tag + "_", *mat.shape)
+    replay(dec, tr)
+
+
+def test_bb72_full_history_values():
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, "cs10_")
+    dec = O.osd_window(mat, channel_probs=priors, **fx.params(f, "cs10_params"))
+    tr = fx.Trace(f, "cs10_", *mat.shape)
+    want = dict(zip(tr.hist_idx.tolist(), tr.hist))
+    for k in range(len(tr)):
+        dec.decode(tr.synd[k])
+        if k in want:
+            assert np.array_equal(dec.log_prob_ratios, want[k])
+
+
+@pytest.mark.parametrize("tag,cls", [("gdg", O.bpgdg_decoder), ("gdg_low", O.bpgdg_decoder), ("gd", O.bpgd_decoder)])
+def test_bb72_guessing(tag, cls):
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, tag + "_")
+    kw = fx.params(f, tag + "_params")
+    kw.pop("multi_thread", None)
+    dec = cls(mat, channel_probs=priors, **kw)
+    replay(dec, fx.Trace(f, tag + "_", *mat.shape))
+
+
+@pytest.mark.parametrize("tag", ["osd0", "osd10"])
+def test_bb144_sliding_trace(tag):
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, tag + "_params")
+    nwin = sum(1 for k in f.files if k.startswith("win") and k.endswith("_meta"))
+    assert nwin == 11
+    classes = np.zeros(6, int)
+    for wi in range(nwin):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        dec = O.osd_window(mat, channel_probs=priors, **kw)
+        tr = fx.Trace(f, f"{tag}_win{wi}_", *mat.shape)
+        for k in range(len(tr)):
+            out = dec.decode(tr.synd[k])
+            classes[dec.exit_class] += 1
+            assert (out == tr.out[k]).all()
+            assert dec.converge == tr.converge[k] and dec.bp_iteration == tr.bp_iteration[k]
+            assert dec.min_pm == tr.min_pm[k]
+            assert fx.h64(dec.log_prob_ratios) == tr.hist_hash[k]
+    # every exit class of osd_window.decode is exercised by the trace
+    assert classes[0] > 500 and classes[1] > 300 and classes[2] > 50
+
+
+def test_bb144_gdg_trace():
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    for wi in range(11):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        dec = O.bpgdg_decoder(mat, channel_probs=priors, **kw)
+        replay(dec, fx.Trace(f, f"gdg_win{wi}_", *mat.shape))
+
+
+def test_bb144_fresh_history_values():
+    """Full LLR history (n x 4) for 24 decodes, one fresh reference object each: equal to the
+    last bit, which is stronger than the 1e-5 relative tolerance the north star asks for."""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    wi = int(f["fresh_win"])
+    mat, priors = fx.graph(f, f"win{wi}_")
+    kw = fx.params(f, "osd0_params")
+    m, n = mat.shape
+    synd = fx.unpack(f["fresh_synd"], m)
+    out = fx.unpack(f["fresh_out"], n)
+    dec = O.osd_window(mat, channel_probs=priors, **kw)
+    for k in range(synd.shape[0]):
+        dec.clear_history()
+        got = dec.decode(synd[k])
+        assert (got == out[k]).all()
+        assert dec.bp_iteration == f["fresh_bp_iteration"][k]
+        assert np.array_equal(dec.log_prob_ratios, f["fresh_hist"][k])
+
+
+@pytest.mark.parametrize("order", [0, 10])
+def test_bb144_rank_deficient_inconsistent(order):
+    """Last window has rank 210 < 216; random syndromes are mostly outside its column space."""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    mat, priors = fx.graph(f, "win10_")
+    kw = dict(fx.params(f, "incons_params"), osd_order=order)
+    dec = O.osd_window(mat, channel_probs=priors, **kw)
+    assert dec.rank == 210
+    replay(dec, fx.Trace(f, f"incons{order}_", *mat.shape))
+
+
+def test_bb288_sliding_trace():
+    f = fx.load("bb288_circuit_p005_w4f1.npz")
+    kw = fx.params(f, "osd10_params")
+    for wi in range(4):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        dec = O.osd_window(mat, channel_probs=priors, **kw)
+        replay(dec, fx.Trace(f, f"osd10_win{wi}_", *mat.shape))
+
+
+def test_constructor_errors_match_reference():
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, "c1_")
+    with pytest.raises(TypeError):
+        O.osd_window([[1, 0], [0, 1]], channel_probs=[0.1, 0.1])
+    with pytest.raises(ValueError):
+        O.osd_window(mat, channel_probs=priors[:-1])
+    with pytest.raises(ValueError):
+        O.osd_window(mat, channel_probs=priors, osd_method="nope")
+    with pytest.raises(ValueError):  # osd_order > new_n - rank  (osd_window.pyx:88-92)
+        O.osd_window(mat, channel_probs=priors, osd_method="osd_cs", osd_order=43)
+    d = O.osd_window(mat, channel_probs=priors)
+    with pytest.raises(ValueError):
+        d.decode(np.zeros(35))
