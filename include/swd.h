@@ -1,0 +1,99 @@
+/*
+ * swd.h -- C ABI of the MI355X sliding-window QLDPC decoder (libswd_hip.so).
+ *
+ * The reference has no FFI layer: its boundary is the Cython extension-type surface
+ * re-exported by /root/reference/src/__init__.py:2-4 and called one syndrome at a time from
+ * Python loops (/root/reference/osd.py:152-167, guessing.py:160-197).  Each entry point below
+ * names the reference interface it replaces.  Plain pointers and sizes only; integer return
+ * codes (0 = ok, <0 = error, text via swd_last_error()); no exceptions, no exit().
+ *
+ * Conventions
+ *   - check matrices are passed as CSR over GF(2): row_ptr[m+1], col_idx[nnz] (columns need
+ *     not be sorted; duplicates are not allowed);
+ *   - syndromes / error vectors are one byte per bit (0/1), row-major [shot][bit];
+ *   - "_dev" entry points take DEVICE pointers (e.g. torch tensors' data_ptr()) and a
+ *     hipStream_t passed as void*; the others take HOST pointers and copy.
+ */
+#ifndef SWD_H
+#define SWD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWD_ABI_VERSION 1
+
+/* exit class of one window decode, low byte of status[]; bit 8 = converge flag */
+enum {
+    SWD_EXIT_PRE = 0,       /* pre-processing BP converged    osd_window.pyx:166-170 */
+    SWD_EXIT_POST = 1,      /* post-processing BP converged   osd_window.pyx:188-192 */
+    SWD_EXIT_OSD = 2,       /* OSD produced the answer        osd_window.pyx:193-195 */
+    SWD_EXIT_FAIL_SET = 3,  /* "setting vn failed"            osd_window.pyx:179-181 */
+    SWD_EXIT_FAIL_PEEL = 4, /* "peeling failed"               osd_window.pyx:184-186 */
+    SWD_EXIT_NO_OSD = 5     /* BP failed and osd_order == -1  osd_window.pyx:199     */
+};
+#define SWD_STATUS_CONVERGE 0x100
+
+typedef struct swd_graph_desc {
+    int32_t m, n, nnz;
+    const int32_t *row_ptr;      /* m+1 */
+    const int32_t *col_idx;      /* nnz */
+    const double *channel_probs; /* n; llr = log((1-p)/p) as osd_window.pyx:113 */
+} swd_graph_desc;
+
+/* kwargs of osd_window.__cinit__ (osd_window.pyx:10-16) */
+typedef struct swd_osdw_params {
+    int32_t pre_max_iter;  /* default 8   */
+    int32_t post_max_iter; /* default 100 */
+    double ms_scaling_factor;
+    int32_t new_n;      /* <=0: min(n, 2m) (osd_window.pyx:60-63) */
+    int32_t osd_method; /* 0 osd_0, 1 osd_e, 2 osd_cs (osd_window.pyx:69-79) */
+    int32_t osd_order;  /* -1 disables OSD */
+} swd_osdw_params;
+
+typedef struct swd_osdw swd_osdw;
+
+const char *swd_last_error(void);
+int swd_abi_version(void);
+int swd_device_count(void);
+
+/* replaces osd_window(pcm, **kwargs)  (osd_window.pyx:8-126).  device = HIP ordinal. */
+swd_osdw *swd_osdw_create(const swd_graph_desc *g, const swd_osdw_params *p, int device);
+void swd_osdw_destroy(swd_osdw *d);
+/* properties fixed at construction: rank (osd_window.pyx:87), new_n, m, n */
+int swd_osdw_info(const swd_osdw *d, int32_t *m, int32_t *n, int32_t *new_n, int32_t *rank);
+
+/* replaces the per-shot loop around osd_window.decode (osd.py:166-167): B independent
+ * syndromes in one launch.  Host pointers.
+ *   synd   [B*m]   in
+ *   out    [B*n]   returned vector of decode() (bp_decoding or osdw_decoding)
+ *   status [B]     exit class | SWD_STATUS_CONVERGE        (property `converge`)
+ *   iters  [B]     property `bp_iteration`
+ *   min_pm [B]     property `min_pm`
+ *   hist   [B*4*n] nullable; LLR history, layout [shot][slot][vn]  (property log_prob_ratios is
+ *                  its transpose).  If hist_is_state != 0 the buffer is read as the initial
+ *                  history too (the reference object keeps it between decodes); otherwise
+ *                  every shot starts from a zero history like a freshly built object.
+ *   osd0   [B*n]   nullable; property osd0_decoding (only written for SWD_EXIT_OSD shots)   */
+int swd_osdw_decode_batch(swd_osdw *d, int32_t B, const uint8_t *synd, uint8_t *out,
+                          int32_t *status, int32_t *iters, double *min_pm, double *hist,
+                          int32_t hist_is_state, uint8_t *osd0);
+
+/* same, device-resident buffers, asynchronous on `stream` (hipStream_t).  hist may be NULL: the
+ * decoder then uses its own scratch, grown to B shots on first use. */
+int swd_osdw_decode_batch_dev(swd_osdw *d, int32_t B, const uint8_t *synd, int64_t synd_stride,
+                              uint8_t *out, int64_t out_stride, int32_t *status, int32_t *iters,
+                              double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0,
+                              void *stream);
+
+/* average duration (ms) of the decode kernel launches since the last call, measured with HIP
+ * events on the launch stream when timing was enabled with swd_osdw_set_timing(d, 1) */
+int swd_osdw_set_timing(swd_osdw *d, int32_t on);
+int swd_osdw_get_timing(swd_osdw *d, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+"""ctypes binding of libswd_hip.so (C ABI: include/swd.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible, construction of
+any decoder raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from this package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswd_hip.so")
+_lib = None
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("nnz", C.c_int32),
+                ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("channel_probs", C.c_void_p)]
+
+
+class OsdwParams(C.Structure):
+    _fields_ = [("pre_max_iter", C.c_int32), ("post_max_iter", C.c_int32),
+                ("ms_scaling_factor", C.c_double), ("new_n", C.c_int32),
+                ("osd_method", C.c_int32), ("osd_order", C.c_int32)]
+
+
+# every symbol include/swd.h declares: (name, restype, argtypes)
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+SYMBOLS = [
+    ("swd_last_error", C.c_char_p, []),
+    ("swd_abi_version", C.c_int, []),
+    ("swd_device_count", C.c_int, []),
+    ("swd_osdw_create", _vp, [C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
+    ("swd_osdw_destroy", None, [_vp]),
+    ("swd_osdw_info", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    ("swd_osdw_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    ("swd_osdw_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    ("swd_osdw_set_timing", C.c_int, [_vp, _i32]),
+    ("swd_osdw_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+]
+
+
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in
+    one process do not share a device context (the second one to initialise sees 0 devices), so
+    when torch is installed its copy is loaded first with RTLD_GLOBAL and libswd_hip.so binds to
+    it by SONAME; torch tensors' data_ptr()s and streams are then valid in our launches."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+def lib():
+    """Load libswd_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C slidingwindowdecoder_amd/csrc). "
+                "This package has no CPU fallback.")
+        _preload_torch_hip_runtime()
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().swd_last_error() or b"").decode()

@@ -1,0 +1,63 @@
+// Host-side helpers shared by the C-ABI translation units: error reporting, device buffers,
+// and the CSR -> device-graph builder.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "swd.h"
+#include "swd_graph.h"
+
+namespace swd {
+
+void set_error(const char *fmt, ...);
+
+#define SWD_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            swd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                           __LINE__);                                                         \
+            return -1;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        SWD_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// Host copy of the device graph arrays + the device allocation holding them.
+struct Graph {
+    int m = 0, n = 0, E = 0, K = 0, D = 0, rank = 0, wm = 0;
+    std::vector<uint16_t> jptr, row_col, perm, iperm, vn_row;
+    std::vector<uint8_t> row_deg, col_deg;
+    std::vector<uint32_t> vn_edge;
+    std::vector<double> llr;
+    // original CSR/CSC kept for host-side use (rank, OSD-CS setup)
+    std::vector<int32_t> row_ptr, col_idx, col_ptr, row_idx;
+    DevBuf dev;
+    SwdGraphDev d{};
+
+    int build(const swd_graph_desc *g);   // validates, fills host arrays, computes rank
+    int upload();                          // hipMalloc + copy, fills d
+};
+
+int gf2_rank(int m, int n, const std::vector<int32_t> &row_ptr, const std::vector<int32_t> &col_idx);
+
+} // namespace swd

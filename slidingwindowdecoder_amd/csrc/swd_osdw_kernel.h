@@ -1,0 +1,563 @@
+// One-workgroup-per-shot decode of a window: the whole of osd_window.decode
+// (/root/reference/src/osd_window.pyx:158-199) for one syndrome --
+//   pre-processing min-sum BP  -> LLR-history sort -> shortening (decimate + peel)
+//   -> post-processing masked BP -> OSD on the ordered matrix --
+// with the messages of the shot living in LDS for its whole lifetime.
+//
+// Numerics: fp64, no FMA contraction (build with -ffp-contract=off), every sum in the
+// reference's order, so hard decisions, iteration counts and min_pm are bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "swd.h"
+#include "swd_graph.h"
+
+#define SWD_DMAX 8 // unrolled variable-node degree bound of this build (col degree <= 8)
+
+struct SwdLdsLayout {
+    int32_t off_livemask, off_par, off_lv, off_jptr, off_cnval, off_cndeg, off_vnval, off_hard,
+        off_misc, total;
+    int32_t npad;      // power of two >= n (bitonic sort size)
+    int32_t off_idx;   // inside scratch: u16 idx[npad] after u64 key[npad]
+    int32_t off_aux;   // inside scratch: first byte after the sort arrays
+};
+
+struct SwdOsdwArgs {
+    SwdGraphDev g;
+    SwdLdsLayout L;
+    int32_t pre_iter, post_iter, osd_method, osd_order;
+    double alpha;
+    int32_t B;
+    int32_t hist_is_state;
+    const uint8_t *synd;
+    int64_t synd_stride;
+    uint8_t *out;
+    int64_t out_stride;
+    int32_t *status;
+    int32_t *iters;
+    double *min_pm;
+    double *hist; // [B][4][n]
+    uint8_t *osd0; // nullable [B][n]
+};
+
+namespace swd {
+
+struct Lds {
+    double *msg;        // scratch region start
+    char *scratch;
+    uint64_t *livemask; // [m]
+    uint32_t *par;      // [m]
+    uint16_t *lv;       // [new_n]
+    uint16_t *jptr;     // [K+1]
+    int8_t *cn_val;     // [m]  residual check value, -1 = cleared
+    uint8_t *cn_deg;    // [m]
+    int8_t *vn_val;     // [n]  -1 live / decided value
+    uint8_t *hard;      // [n]  bp_decoding
+    int *flags;         // [32]
+    int *scal;          // [32]
+    int fpar;
+};
+
+template <int NT>
+__device__ __forceinline__ bool block_any(bool p, Lds &s) {
+    constexpr int NW = NT / 64;
+    const int par = (s.fpar++) & 1;
+    unsigned long long b = __ballot(p);
+    if ((threadIdx.x & 63) == 0) s.flags[par * 16 + (threadIdx.x >> 6)] = (b != 0ull);
+    __syncthreads();
+    bool r = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r |= (s.flags[par * 16 + w] != 0);
+    return r;
+}
+
+// exclusive prefix sum over the block; `total` = sum of all. Two barriers.
+template <int NT>
+__device__ __forceinline__ int block_exscan(int x, Lds &s, int &total) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+    }
+    int *wsum = s.scal + 8; // [NW]
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        int c = wsum[w];
+        if (w < wave) off += c;
+        tot += c;
+    }
+    total = tot;
+    return off + incl - x;
+}
+
+__device__ __forceinline__ uint64_t f2key(double x) {
+    x = x + 0.0; // -0.0 -> +0.0 so that equal doubles get equal keys
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------
+// Masked flooding min-sum (osd_window.pyx:381-485; unmasked special case =
+// bp_guessing_decoder.pyx:48-139).  Per iteration:
+//   CN pass  lane per check: reads the b2c of its live edges, overwrites them in place with
+//            c2b = (min over the other edges) * (+-alpha)          (osd_window.pyx:393-439)
+//   VN pass  thread per live VN: posterior / hard decision / new b2c = prefix + suffix in
+//            row order (osd_window.pyx:442-471); hard decisions are folded into the
+//            per-check parity words with LDS atomics, which is the convergence test
+//            H*e == s of osd_window.pyx:474-483 restricted to live checks.
+// The parity words of iteration i are inspected at the start of the CN pass of iteration
+// i+1, so an iteration costs two barriers.
+// ------------------------------------------------------------------------------------------
+template <int NT, bool FULL>
+__device__ int bp_run(const SwdOsdwArgs &a, Lds &s, int max_iter, int nlive, double *hist_b,
+                      int &iters_done) {
+    const SwdGraphDev &g = a.g;
+    const int tid = threadIdx.x, m = g.m, n = g.n;
+    const double alpha = a.alpha, nalpha = -a.alpha;
+    iters_done = 0;
+    if (max_iter <= 0) return 0;
+    for (int it = 0; it < max_iter; ++it) {
+        bool unsat = false;
+        for (int l = tid; l < m; l += NT) {
+            const int cv = s.cn_val[l];
+            if (cv < 0) continue;
+            if (it > 0 && s.par[l] != 0u) unsat = true;
+            s.par[l] = (uint32_t)cv;
+            const uint64_t mk = s.livemask[l];
+            double min1 = 1e308, min2 = 1e308;
+            int arg = -1, sg = cv;
+            uint64_t negm = 0, t = mk;
+            while (t) {
+                const int j = __ffsll((long long)t) - 1;
+                t &= t - 1;
+                double x = s.msg[s.jptr[j] + l];
+                if (x > 50.0) x = 50.0;
+                else if (x < -50.0) x = -50.0;
+                const double ax = fabs(x);
+                if (ax < min1) { min2 = min1; min1 = ax; arg = j; }
+                else if (ax < min2) min2 = ax;
+                if (x <= 0) { negm |= 1ull << j; sg ^= 1; }
+            }
+            t = mk;
+            while (t) {
+                const int j = __ffsll((long long)t) - 1;
+                t &= t - 1;
+                const double mag = (j == arg) ? min2 : min1;
+                const int sgn = sg ^ (int)((negm >> j) & 1ull);
+                s.msg[s.jptr[j] + l] = mag * (sgn ? nalpha : alpha);
+            }
+        }
+        const bool any = block_any<NT>(unsat, s);
+        if (it > 0 && !any) { iters_done = it; return 1; }
+
+        const int cnt = FULL ? n : nlive;
+        const int slot_h = it & 3;
+        for (int i = tid; i < cnt; i += NT) {
+            const int v = FULL ? i : (int)s.lv[i];
+            const int deg = g.col_deg[v];
+            uint32_t ed[SWD_DMAX];
+            double c[SWD_DMAX], pre[SWD_DMAX];
+            bool live[SWD_DMAX];
+#pragma unroll
+            for (int k = 0; k < SWD_DMAX; ++k) {
+                live[k] = false;
+                if (k < deg) {
+                    ed[k] = g.vn_edge[k * n + v];
+                    live[k] = FULL ? true : (s.cn_val[swd_edge_lane(ed[k])] >= 0);
+                    if (live[k]) c[k] = s.msg[swd_edge_slot(ed[k])];
+                }
+            }
+            double temp = g.llr[v];
+#pragma unroll
+            for (int k = 0; k < SWD_DMAX; ++k)
+                if (live[k]) { pre[k] = temp; temp += c[k]; }
+            hist_b[slot_h * n + v] = temp;
+            const bool hd = (temp <= 0);
+            s.hard[v] = hd ? 1 : 0;
+            double suf = 0.0;
+#pragma unroll
+            for (int k = SWD_DMAX - 1; k >= 0; --k)
+                if (live[k]) { s.msg[swd_edge_slot(ed[k])] = pre[k] + suf; suf += c[k]; }
+            if (hd) {
+#pragma unroll
+                for (int k = 0; k < SWD_DMAX; ++k)
+                    if (live[k]) atomicXor(&s.par[swd_edge_lane(ed[k])], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    bool unsat = false;
+    for (int l = tid; l < m; l += NT)
+        if (s.cn_val[l] >= 0 && s.par[l] != 0u) unsat = true;
+    const bool any = block_any<NT>(unsat, s);
+    iters_done = max_iter;
+    return any ? 0 : 1;
+}
+
+// bp_init (osd_window.pyx:370-379): b2c <- prior on every edge of every live VN
+template <int NT, bool FULL>
+__device__ void bp_init(const SwdOsdwArgs &a, Lds &s, int nlive) {
+    const SwdGraphDev &g = a.g;
+    const int cnt = FULL ? g.n : nlive;
+    for (int i = threadIdx.x; i < cnt; i += NT) {
+        const int v = FULL ? i : (int)s.lv[i];
+        const int deg = g.col_deg[v];
+        const double l = g.llr[v];
+        for (int k = 0; k < deg; ++k) s.msg[swd_edge_slot(g.vn_edge[k * g.n + v])] = l;
+    }
+}
+
+// Bitonic sort of (key, idx) pairs, ascending lexicographic == the reference's stable
+// ascending argsort (index_sort, src/include/bpgd.cpp:384-389).
+template <int NT>
+__device__ void sort_pairs(uint64_t *key, uint16_t *idx, int npad) {
+    const int half = npad >> 1;
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < half; i += NT) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo + j;
+                const bool up = ((lo & k) == 0);
+                const uint64_t ka = key[lo], kb = key[hi];
+                const uint16_t ia = idx[lo], ib = idx[hi];
+                const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                if (gt == up) { key[lo] = kb; key[hi] = ka; idx[lo] = ib; idx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// sum of llr[v] over hard[v]==1 in ascending v (min_pm, osd_window.pyx:168-169 / 233-235).
+// `list` must hold n u16.  Result valid on every thread.
+template <int NT>
+__device__ double ordered_pm(const SwdOsdwArgs &a, Lds &s, uint16_t *list) {
+    const int n = a.g.n;
+    const int ch = (n + NT - 1) / NT;
+    const int v0 = threadIdx.x * ch, v1 = min(n, v0 + ch);
+    int cnt = 0;
+    for (int v = v0; v < v1; ++v) cnt += s.hard[v] ? 1 : 0;
+    int total;
+    int pos = block_exscan<NT>(cnt, s, total);
+    for (int v = v0; v < v1; ++v)
+        if (s.hard[v]) list[pos++] = (uint16_t)v;
+    __syncthreads();
+    double *dres = (double *)(s.scal + 28);
+    if (threadIdx.x == 0) {
+        double pm = 0.0;
+        for (int i = 0; i < total; ++i) pm += a.g.llr[list[i]];
+        *dres = pm;
+    }
+    __syncthreads();
+    return *dres;
+}
+
+// vn_set_value (osd_window.pyx:340-368) executed by wave 0: lane k takes the k-th neighbour
+// check of vn (distinct checks, so the updates are independent).  Returns true on
+// contradiction.
+__device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, int vn, int value) {
+    const int lane = threadIdx.x & 63;
+    const int deg = g.col_deg[vn];
+    if (lane == 0) { s.vn_val[vn] = (int8_t)value; s.hard[vn] = (uint8_t)value; }
+    bool bad = false;
+    if (lane < deg) {
+        const uint32_t e = g.vn_edge[lane * g.n + vn];
+        const int l = swd_edge_lane(e), j = swd_edge_j(e);
+        int cv = s.cn_val[l];
+        if (cv >= 0) {
+            const int d = (int)s.cn_deg[l] - 1;
+            if (value) cv ^= 1;
+            s.livemask[l] &= ~(1ull << j);
+            if (d == 0) {
+                if (cv != 0) bad = true;
+                cv = -1;
+            }
+            s.cn_val[l] = (int8_t)cv;
+            s.cn_deg[l] = (uint8_t)d;
+        }
+    }
+    wave_fence();
+    return __ballot(bad) != 0ull;
+}
+
+// peel (osd_window.pyx:306-338) on wave 0, reproducing the reference's sweep order: the next
+// check handled is the lowest original index >= sweep pointer with live degree 1, wrapping to
+// a new sweep when the current one is exhausted.  Returns true on contradiction.
+__device__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
+    const int lane = threadIdx.x & 63;
+    int ptr = 0;
+    for (;;) {
+        int best_ge = 0x7fffffff, best_all = 0x7fffffff;
+        for (int l = lane; l < g.m; l += 64) {
+            if (s.cn_val[l] >= 0 && s.cn_deg[l] == 1) {
+                const int c = g.perm[l];
+                best_all = min(best_all, c);
+                if (c >= ptr) best_ge = min(best_ge, c);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            best_ge = min(best_ge, __shfl_xor(best_ge, d, 64));
+            best_all = min(best_all, __shfl_xor(best_all, d, 64));
+        }
+        if (best_all == 0x7fffffff) return false;
+        const int c = (best_ge != 0x7fffffff) ? best_ge : best_all;
+        const int l = g.iperm[c];
+        const uint64_t mk = s.livemask[l];
+        const int j = __ffsll((long long)mk) - 1;
+        const int vn = g.row_col[s.jptr[j] + l];
+        const int val = s.cn_val[l];
+        if (vn_set_value_wave(g, s, vn, val)) return true;
+        ptr = c + 1;
+    }
+}
+
+// OSD-0 on wave 0 (osd_window.pyx:201-240).  GF(2) elimination in "transform" form: T starts
+// as the m x m identity and accumulates the row operations; a sorted column (<= D ones) is
+// reduced by XOR-ing the <= D columns of T it selects, so the work per scanned column does
+// not depend on n.  Pivot rule = mod2sparse_decomp_osd (mod2sparse_extra.cpp:186-195): first
+// column in priority order with a 1 in a not-yet-pivoted row, lowest such row.  Row
+// operations are applied to all rows (Gauss-Jordan) which gives the same solution as the
+// reference's LU + forward/backward substitution (mod2sparse_extra.cpp:78-106) because both
+// solve the same invertible pivot-row x pivot-column system with zeros elsewhere.
+// T is stored column-major: Tc[j*wm + w] = word w of column j (bit r = T[r][j]).
+__device__ void osd0_wave(const SwdOsdwArgs &a, Lds &s, const uint16_t *order, uint64_t *Tc,
+                          uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b) {
+    const SwdGraphDev &g = a.g;
+    const int lane = threadIdx.x & 63;
+    const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
+    // this lane's words of the pivoted-row mask: w = lane, lane + 64, ... (wm <= 16 -> one word)
+    uint64_t P = 0;
+    int npiv = 0;
+    for (int p = 0; p < n && npiv < rank; ++p) {
+        const int v = order[p];
+        const int deg = g.col_deg[v];
+        uint64_t red = 0;
+        if (lane < wm)
+            for (int k = 0; k < deg; ++k) red ^= Tc[(int)g.vn_row[k * n + v] * wm + lane];
+        const uint64_t cand = red & ~P;
+        const unsigned long long bal = __ballot(lane < wm && cand != 0ull);
+        if (bal == 0ull) continue;
+        const int ws = __ffsll((long long)bal) - 1;
+        const uint64_t cw = __shfl(cand, ws, 64);
+        const int bit = __ffsll((long long)cw) - 1;
+        const int r = ws * 64 + bit;
+        if (lane == ws) { P |= 1ull << bit; red &= ~(1ull << bit); }
+        if (lane == 0) { piv_col[npiv] = (uint16_t)v; piv_row[npiv] = (uint16_t)r; }
+        ++npiv;
+        if (lane < wm) Sbuf[lane] = red;
+        wave_fence();
+        const int rw = r >> 6;
+        const uint64_t rb = 1ull << (r & 63);
+        for (int j = lane; j < m; j += 64) {
+            if (Tc[j * wm + rw] & rb)
+                for (int w = 0; w < wm; ++w) Tc[j * wm + w] ^= Sbuf[w];
+        }
+        wave_fence();
+    }
+    // y = T * s  (s in original row order)
+    uint64_t y = 0; // lane w < wm holds word w
+    for (int j = 0; j < m; ++j)
+        if (synd_b[j] && lane < wm) y ^= Tc[j * wm + lane];
+    if (lane < wm) Sbuf[lane] = y;
+    wave_fence();
+    for (int i = lane; i < npiv; i += 64) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+    }
+    wave_fence();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) osdw_kernel(const SwdOsdwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SwdGraphDev &g = a.g;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int m = g.m, n = g.n;
+    Lds s;
+    s.scratch = smem;
+    s.msg = (double *)smem;
+    s.livemask = (uint64_t *)(smem + a.L.off_livemask);
+    s.par = (uint32_t *)(smem + a.L.off_par);
+    s.lv = (uint16_t *)(smem + a.L.off_lv);
+    s.jptr = (uint16_t *)(smem + a.L.off_jptr);
+    s.cn_val = (int8_t *)(smem + a.L.off_cnval);
+    s.cn_deg = (uint8_t *)(smem + a.L.off_cndeg);
+    s.vn_val = (int8_t *)(smem + a.L.off_vnval);
+    s.hard = (uint8_t *)(smem + a.L.off_hard);
+    s.flags = (int *)(smem + a.L.off_misc);
+    s.scal = s.flags + 32;
+    s.fpar = 0;
+
+    const uint8_t *synd_b = a.synd + (int64_t)b * a.synd_stride;
+    uint8_t *out_b = a.out + (int64_t)b * a.out_stride;
+    double *hist_b = a.hist + (int64_t)b * 4 * n;
+
+    // reset (osd_window.pyx:288-303)
+    for (int l = tid; l < m; l += NT) {
+        const int d = g.row_deg[l];
+        s.cn_val[l] = (int8_t)(synd_b[g.perm[l]] ? 1 : 0);
+        s.cn_deg[l] = (uint8_t)d;
+        s.livemask[l] = (d >= 64) ? ~0ull : ((1ull << d) - 1ull);
+    }
+    for (int v = tid; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
+    for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
+    if (!a.hist_is_state)
+        for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
+    bp_init<NT, true>(a, s, n);
+    __syncthreads();
+
+    int exit_class, conv = 0, total_it = 0, it = 0;
+    double pm = 0.0;
+    uint16_t *list0 = (uint16_t *)s.scratch;
+
+    conv = bp_run<NT, true>(a, s, a.pre_iter, n, hist_b, it);
+    total_it = it;
+    if (conv) {
+        exit_class = SWD_EXIT_PRE;
+        pm = ordered_pm<NT>(a, s, list0);
+    } else {
+        // ---- order columns by summed LLR history (osd_window.pyx:172-176)
+        uint64_t *key = (uint64_t *)s.scratch;
+        uint16_t *idx = (uint16_t *)(s.scratch + a.L.off_idx);
+        __syncthreads(); // history stores of the last VN pass are visible block-wide
+        for (int v = tid; v < a.L.npad; v += NT) {
+            if (v < n) {
+                const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+                key[v] = f2key(sum);
+                idx[v] = (uint16_t)v;
+            } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+        }
+        __syncthreads();
+        sort_pairs<NT>(key, idx, a.L.npad);
+        // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
+        for (int i = g.new_n + tid; i < n; i += NT) s.vn_val[idx[i]] = 0;
+        __syncthreads();
+        bool contra = false;
+        for (int l = tid; l < m; l += NT) {
+            const int d = g.row_deg[l];
+            uint64_t mk = 0;
+            int cntl = 0;
+            for (int j = 0; j < d; ++j) {
+                const int v = g.row_col[s.jptr[j] + l];
+                if (s.vn_val[v] < 0) { mk |= 1ull << j; ++cntl; }
+            }
+            s.livemask[l] = mk;
+            s.cn_deg[l] = (uint8_t)cntl;
+            if (cntl == 0) {
+                if (s.cn_val[l] != 0) contra = true;
+                else s.cn_val[l] = -1;
+            }
+        }
+        const bool any_contra = block_any<NT>(contra, s);
+        if (any_contra) {
+            // "setting vn failed" (osd_window.pyx:179-181): the reference stops at the first
+            // decimation that empties an unsatisfied check; only VNs up to that sorted position
+            // have been zeroed in bp_decoding.
+            uint16_t *pos = (uint16_t *)(s.scratch + a.L.off_aux);
+            for (int i = tid; i < n; i += NT) pos[idx[i]] = (uint16_t)i;
+            if (tid == 0) s.scal[0] = 0x7fffffff;
+            __syncthreads();
+            for (int l = tid; l < m; l += NT) {
+                if (s.cn_deg[l] == 0 && s.cn_val[l] > 0) {
+                    int mx = 0;
+                    const int d = g.row_deg[l];
+                    for (int j = 0; j < d; ++j) mx = max(mx, (int)pos[g.row_col[s.jptr[j] + l]]);
+                    atomicMin(&s.scal[0], mx);
+                }
+            }
+            __syncthreads();
+            const int kstop = s.scal[0];
+            for (int i = g.new_n + tid; i <= kstop && i < n; i += NT) s.hard[idx[i]] = 0;
+            __syncthreads();
+            exit_class = SWD_EXIT_FAIL_SET;
+        } else {
+            for (int i = g.new_n + tid; i < n; i += NT) s.hard[idx[i]] = 0;
+            __syncthreads();
+            // ---- peel (osd_window.pyx:184-186)
+            if (tid < 64) {
+                const bool bad = peel_wave(g, s);
+                if (tid == 0) s.scal[1] = bad ? 1 : 0;
+            }
+            __syncthreads();
+            if (s.scal[1]) {
+                exit_class = SWD_EXIT_FAIL_PEEL;
+            } else {
+                // ---- compact the live VNs, re-initialise their messages (osd_window.pyx:187)
+                const int ch = (n + NT - 1) / NT;
+                const int v0 = tid * ch, v1 = min(n, v0 + ch);
+                int cnt = 0;
+                for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] < 0) ? 1 : 0;
+                int nlive;
+                int pos = block_exscan<NT>(cnt, s, nlive);
+                for (int v = v0; v < v1; ++v)
+                    if (s.vn_val[v] < 0) s.lv[pos++] = (uint16_t)v;
+                __syncthreads();
+                bp_init<NT, false>(a, s, nlive);
+                __syncthreads();
+                conv = bp_run<NT, false>(a, s, a.post_iter, nlive, hist_b, it);
+                total_it += it;
+                if (conv) {
+                    exit_class = SWD_EXIT_POST;
+                    pm = ordered_pm<NT>(a, s, list0);
+                } else if (a.osd_order < 0) {
+                    exit_class = SWD_EXIT_NO_OSD;
+                } else {
+                    // ---- OSD (osd_window.pyx:201-284): keys -1000 / +1000 / history sum
+                    __syncthreads();
+                    for (int v = tid; v < a.L.npad; v += NT) {
+                        if (v < n) {
+                            double sum;
+                            const int vv = s.vn_val[v];
+                            if (vv == 1) sum = -1000.0;
+                            else if (vv == 0) sum = 1000.0;
+                            else sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+                            key[v] = f2key(sum);
+                            idx[v] = (uint16_t)v;
+                        } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+                    }
+                    __syncthreads();
+                    sort_pairs<NT>(key, idx, a.L.npad);
+                    uint64_t *Tc = (uint64_t *)(s.scratch + a.L.off_aux);
+                    uint64_t *Sbuf = Tc + m * g.wm;
+                    uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
+                    uint16_t *piv_row = piv_col + g.rank;
+                    uint16_t *list1 = piv_row + g.rank;
+                    for (int i = tid; i < m * g.wm; i += NT) {
+                        const int j = i / g.wm, w = i - j * g.wm;
+                        Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
+                    }
+                    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+                    __syncthreads();
+                    if (tid < 64) osd0_wave(a, s, idx, Tc, Sbuf, piv_col, piv_row, synd_b);
+                    __syncthreads();
+                    if (a.osd0)
+                        for (int v = tid; v < n; v += NT) a.osd0[(int64_t)b * n + v] = s.hard[v];
+                    pm = ordered_pm<NT>(a, s, list1);
+                    exit_class = SWD_EXIT_OSD;
+                }
+            }
+        }
+    }
+    for (int v = tid; v < n; v += NT) out_b[v] = s.hard[v];
+    if (tid == 0) {
+        a.status[b] = exit_class | (conv ? 0x100 : 0);
+        a.iters[b] = total_it;
+        a.min_pm[b] = pm;
+    }
+}
+
+} // namespace swd

@@ -1,0 +1,218 @@
+"""Python class surface of the reference, backed by the HIP library.
+
+``osd_window`` keeps the constructor kwargs, ``decode`` and the properties of the reference's
+Cython class (/root/reference/src/osd_window.pyx:8-126, 158-199, 487-517) so that the
+notebook / script loops (/root/reference/osd.py:152-167) run unchanged, and adds
+``decode_batch`` (shape modelled on the batched decoders the reference's notebooks compare
+against) which is the path that actually uses the GPU well: one launch, one workgroup per
+syndrome.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+EXIT_PRE, EXIT_POST, EXIT_OSD, EXIT_FAIL_SET, EXIT_FAIL_PEEL, EXIT_NO_OSD = range(6)
+STATUS_CONVERGE = 0x100
+
+_OSD_METHODS = {  # aliases of osd_window.pyx:69-79
+    0: ["osd_0", "0", "osd0"],
+    1: ["osd_e", "1", "osde", "exhaustive", "e"],
+    2: ["osd_cs", "2", "osdcs", "combination_sweep", "cs"],
+}
+
+
+def _parse_osd_method(osd_method, osd_order):
+    s = str(osd_method).lower()
+    for k, names in _OSD_METHODS.items():
+        if s in names:
+            return k, (0 if k == 0 else int(osd_order))
+    raise ValueError(f"ERROR: OSD method '{osd_method}' invalid. Please choose from the following "
+                     "methods: 'OSD_0', 'OSD_E' or 'OSD_CS'.")
+
+
+class _Csr:
+    """Validated CSR + priors kept alive for the C call."""
+
+    def __init__(self, pcm, channel_probs):
+        if not (isinstance(pcm, np.ndarray) or sp.issparse(pcm)):
+            raise TypeError("The input matrix is of an invalid type. Please input a np.ndarray or "
+                            f"scipy.sparse.spmatrix object, not {type(pcm)}")
+        a = sp.csr_matrix(pcm)
+        a.data = (np.asarray(a.data) != 0).astype(np.uint8)
+        a.eliminate_zeros()
+        a.sort_indices()
+        self.m, self.n = a.shape
+        if channel_probs is None:
+            raise ValueError("channel_probs is required")
+        probs = np.ascontiguousarray(channel_probs, dtype=np.float64)
+        if len(probs) != self.n:
+            raise ValueError("The length of the channel probability vector must be eqaul to the "
+                             f"block length n={self.n}.")
+        self.row_ptr = np.ascontiguousarray(a.indptr, dtype=np.int32)
+        self.col_idx = np.ascontiguousarray(a.indices, dtype=np.int32)
+        self.probs = probs
+        self.desc = _lib.GraphDesc(self.m, self.n, int(self.row_ptr[-1]), self.row_ptr.ctypes.data,
+                                   self.col_idx.ctypes.data, probs.ctypes.data)
+
+
+def _as_synd(x, m):
+    x = np.asarray(x)
+    if x.ndim != 1 or x.shape[0] != m:
+        n_in = x.shape[0] if x.ndim >= 1 else 0
+        raise ValueError(f"The input to the ldpc.bp_decoder.decode must be a syndrome (of length={m}). "
+                         f"The inputted vector has length={n_in}. Valid formats are `np.ndarray` or "
+                         "`scipy.sparse.spmatrix`.")
+    return np.ascontiguousarray((x.astype(np.int64) & 0xFF).astype(np.uint8))  # C (char) cast, c_util.pyx:6-9
+
+
+class osd_window:
+    """BP + OSD on a shortened window matrix (reference: src/osd_window.pyx)."""
+
+    def __init__(self, parity_check_matrix, **kwargs):
+        L = _lib.lib()
+        self._csr = _Csr(parity_check_matrix, kwargs.get("channel_probs"))
+        self.m, self.n = self._csr.m, self._csr.n
+        method, order = _parse_osd_method(kwargs.get("osd_method", "osd_0"), kwargs.get("osd_order", 0))
+        new_n = kwargs.get("new_n", None)
+        self.pre_max_iter = int(kwargs.get("pre_max_iter", 8))
+        self.post_max_iter = int(kwargs.get("post_max_iter", 100))
+        self.ms_scaling_factor = float(kwargs.get("ms_scaling_factor", 1.0))
+        self.osd_method, self.osd_order = method, order
+        self.device = int(kwargs.get("device", 0))
+        p = _lib.OsdwParams(self.pre_max_iter, self.post_max_iter, self.ms_scaling_factor,
+                            int(new_n) if new_n else 0, method, order)
+        self._h = L.swd_osdw_create(C.byref(self._csr.desc), C.byref(p), self.device)
+        if not self._h:
+            msg = _lib.last_error()
+            if "OSD order" in msg or "invalid" in msg:
+                raise ValueError(msg)
+            raise RuntimeError(f"swd_osdw_create failed: {msg}")
+        i = [C.c_int32() for _ in range(4)]
+        L.swd_osdw_info(self._h, *[C.byref(x) for x in i])
+        self.new_n, self.rank = i[2].value, i[3].value
+        # per-object state the reference keeps between decodes
+        self._hist = np.zeros((4, self.n), dtype=np.float64)
+        self._last = dict(status=EXIT_PRE, iters=0, min_pm=0.0)
+        self._bp_decoding = np.zeros(self.n, dtype=np.int64)
+        self._osdw_decoding = np.zeros(self.n, dtype=np.int64)
+        self._osd0_decoding = np.zeros(self.n, dtype=np.int64)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().swd_osdw_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- reference surface -------------------------------------------------------------
+    def decode(self, input_vector):
+        """One syndrome -> int64[n] (osd_window.pyx:158-199).  The LLR history persists between
+        calls exactly like the reference object's."""
+        s = _as_synd(input_vector, self.m)
+        out = np.zeros(self.n, dtype=np.uint8)
+        st, it = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        pm = np.zeros(1, np.float64)
+        osd0 = np.zeros(self.n, dtype=np.uint8)
+        rc = _lib.lib().swd_osdw_decode_batch(self._h, 1, s.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                              it.ctypes.data, pm.ctypes.data, self._hist.ctypes.data, 1,
+                                              osd0.ctypes.data)
+        if rc:
+            raise RuntimeError(f"swd_osdw_decode_batch failed: {_lib.last_error()}")
+        self._last = dict(status=int(st[0]), iters=int(it[0]), min_pm=float(pm[0]))
+        res = out.astype(np.int64)
+        if (int(st[0]) & 0xFF) == EXIT_OSD:
+            self._osdw_decoding = res
+            self._osd0_decoding = osd0.astype(np.int64)
+        else:
+            self._bp_decoding = res
+        return res
+
+    def decode_batch(self, syndromes, return_history=False, return_osd0=False):
+        """B syndromes [B, m] -> uint8 [B, n]; every shot starts from a zero LLR history (the state
+        of a freshly constructed reference object).  Per-shot results are kept in
+        ``last_status`` / ``last_iterations`` / ``last_min_pm`` (and ``last_history`` [B,4,n])."""
+        s = np.asarray(syndromes)
+        if s.ndim != 2 or s.shape[1] != self.m:
+            raise ValueError(f"syndromes must have shape [B, {self.m}]")
+        s = np.ascontiguousarray((s.astype(np.int64) & 0xFF).astype(np.uint8))
+        B = s.shape[0]
+        out = np.zeros((B, self.n), dtype=np.uint8)
+        st, it = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        pm = np.zeros(B, np.float64)
+        hist = np.zeros((B, 4, self.n), np.float64) if return_history else None
+        osd0 = np.zeros((B, self.n), np.uint8) if return_osd0 else None
+        rc = _lib.lib().swd_osdw_decode_batch(self._h, B, s.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                              it.ctypes.data, pm.ctypes.data,
+                                              hist.ctypes.data if hist is not None else None, 0,
+                                              osd0.ctypes.data if osd0 is not None else None)
+        if rc:
+            raise RuntimeError(f"swd_osdw_decode_batch failed: {_lib.last_error()}")
+        self.last_status, self.last_iterations, self.last_min_pm = st, it, pm
+        self.last_history, self.last_osd0 = hist, osd0
+        return out
+
+    def decode_batch_device(self, synd, out=None, status=None, iters=None, min_pm=None, stream=None):
+        """Device-resident batch: ``synd`` is a torch uint8 CUDA tensor [B, m] (row stride free).
+        Asynchronous on the current (or given) torch stream.  Returns (out, status, iters, min_pm)
+        tensors."""
+        import torch
+        B = synd.shape[0]
+        dev = synd.device
+        out = torch.empty((B, self.n), dtype=torch.uint8, device=dev) if out is None else out
+        status = torch.empty(B, dtype=torch.int32, device=dev) if status is None else status
+        iters = torch.empty(B, dtype=torch.int32, device=dev) if iters is None else iters
+        min_pm = torch.empty(B, dtype=torch.float64, device=dev) if min_pm is None else min_pm
+        st = torch.cuda.current_stream(dev) if stream is None else stream
+        rc = _lib.lib().swd_osdw_decode_batch_dev(self._h, B, synd.data_ptr(), synd.stride(0), out.data_ptr(),
+                                                  out.stride(0), status.data_ptr(), iters.data_ptr(),
+                                                  min_pm.data_ptr(), None, 0, None, st.cuda_stream)
+        if rc:
+            raise RuntimeError(f"swd_osdw_decode_batch_dev failed: {_lib.last_error()}")
+        return out, status, iters, min_pm
+
+    def set_timing(self, on=True):
+        _lib.lib().swd_osdw_set_timing(self._h, 1 if on else 0)
+
+    def get_timing(self):
+        ms, k = C.c_double(), C.c_int64()
+        _lib.lib().swd_osdw_get_timing(self._h, C.byref(ms), C.byref(k))
+        return ms.value, k.value
+
+    @property
+    def bp_iteration(self):
+        return self._last["iters"]
+
+    @property
+    def converge(self):
+        return 1 if (self._last["status"] & STATUS_CONVERGE) else 0
+
+    @property
+    def min_pm(self):
+        return self._last["min_pm"]
+
+    @property
+    def exit_class(self):
+        return self._last["status"] & 0xFF
+
+    @property
+    def bp_decoding(self):
+        return self._bp_decoding.copy()
+
+    @property
+    def osdw_decoding(self):
+        return self._osdw_decoding.copy()
+
+    @property
+    def osd0_decoding(self):
+        return self._osd0_decoding.copy()
+
+    @property
+    def log_prob_ratios(self):
+        return np.ascontiguousarray(self._hist.T)
