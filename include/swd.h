@@ -65,12 +65,20 @@ void swd_osdw_destroy(swd_osdw *d);
 /* properties fixed at construction: rank (osd_window.pyx:87), new_n, m, n */
 int swd_osdw_info(const swd_osdw *d, int32_t *m, int32_t *n, int32_t *new_n, int32_t *rank);
 
+/* per-decode record, SWD_STAT_WORDS int32 words:
+ *   [0] exit class | SWD_STATUS_CONVERGE   (property `converge`)
+ *   [1] property `bp_iteration` (pre + post iterations executed)
+ *   [2] pre-processing iterations   [3] post-processing iterations
+ *   [4] live variable nodes, [5] live checks, [6] live edges of the shortened graph (post phase)
+ *   [7] GF(2) row additions applied by the OSD elimination
+ * words 2..7 feed the algorithmic-bytes accounting of bench.py. */
+#define SWD_STAT_WORDS 8
+
 /* replaces the per-shot loop around osd_window.decode (osd.py:166-167): B independent
  * syndromes in one launch.  Host pointers.
  *   synd   [B*m]   in
  *   out    [B*n]   returned vector of decode() (bp_decoding or osdw_decoding)
- *   status [B]     exit class | SWD_STATUS_CONVERGE        (property `converge`)
- *   iters  [B]     property `bp_iteration`
+ *   stats  [B*SWD_STAT_WORDS]
  *   min_pm [B]     property `min_pm`
  *   hist   [B*4*n] nullable; LLR history, layout [shot][slot][vn]  (property log_prob_ratios is
  *                  its transpose).  If hist_is_state != 0 the buffer is read as the initial
@@ -78,20 +86,52 @@ int swd_osdw_info(const swd_osdw *d, int32_t *m, int32_t *n, int32_t *new_n, int
  *                  every shot starts from a zero history like a freshly built object.
  *   osd0   [B*n]   nullable; property osd0_decoding (only written for SWD_EXIT_OSD shots)   */
 int swd_osdw_decode_batch(swd_osdw *d, int32_t B, const uint8_t *synd, uint8_t *out,
-                          int32_t *status, int32_t *iters, double *min_pm, double *hist,
-                          int32_t hist_is_state, uint8_t *osd0);
+                          int32_t *stats, double *min_pm, double *hist, int32_t hist_is_state,
+                          uint8_t *osd0);
 
-/* same, device-resident buffers, asynchronous on `stream` (hipStream_t).  hist may be NULL: the
- * decoder then uses its own scratch, grown to B shots on first use. */
+/* same, device-resident buffers, asynchronous on `stream` (hipStream_t).  stats / min_pm / hist /
+ * osd0 may be NULL; strides are in bytes between consecutive shots (0 = dense). */
 int swd_osdw_decode_batch_dev(swd_osdw *d, int32_t B, const uint8_t *synd, int64_t synd_stride,
-                              uint8_t *out, int64_t out_stride, int32_t *status, int32_t *iters,
-                              double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0,
-                              void *stream);
+                              uint8_t *out, int64_t out_stride, int32_t *stats, double *min_pm,
+                              double *hist, int32_t hist_is_state, uint8_t *osd0, void *stream);
 
 /* average duration (ms) of the decode kernel launches since the last call, measured with HIP
  * events on the launch stream when timing was enabled with swd_osdw_set_timing(d, 1) */
 int swd_osdw_set_timing(swd_osdw *d, int32_t on);
 int swd_osdw_get_timing(swd_osdw *d, double *total_ms, int64_t *launches);
+
+/* ---- sliding-window pipeline ---------------------------------------------------------------
+ * Replaces the window loop of the reference harness (/root/reference/osd.py:130-179, identical in
+ * guessing.py:135-214 and the notebooks): for every shot, decode window t on the residual
+ * syndrome, commit the first `commit` columns of the estimate into total_e_hat, update the
+ * residual syndrome det ^ chk * total_e_hat, go to window t+1.  One launch for B shots. */
+typedef struct swd_window_desc {
+    swd_graph_desc graph; /* window matrix incl. the merged noisy-syndrome identity (osd.py:103-113) */
+    int32_t row0;         /* first detector row of the window            (anchors[top_left][0]) */
+    int32_t col0;         /* first global column of the window           (anchors[top_left][1]) */
+    int32_t commit;       /* committed leading columns (osd.py:140,170-173) */
+    int32_t reserved;
+} swd_window_desc;
+
+typedef struct swd_pipeline swd_pipeline;
+
+/* chk = region-permuted global check matrix [num_det x num_col] (CSR), used for the residual
+ * update (osd.py:178).  All windows share the decoder parameters p (osd.py:152-161). */
+swd_pipeline *swd_pipeline_create(int32_t num_windows, const swd_window_desc *wins,
+                                  const swd_graph_desc *chk, const swd_osdw_params *p, int device);
+void swd_pipeline_destroy(swd_pipeline *pl);
+int swd_pipeline_info(const swd_pipeline *pl, int32_t *num_windows, int32_t *num_det,
+                      int32_t *num_col, int32_t *lds_bytes, int32_t *threads);
+/* det [B*num_det] in; total [B*num_col] out (total_e_hat); stats [B*W*SWD_STAT_WORDS] and
+ * min_pm [B*W] nullable.  Host pointers. */
+int swd_pipeline_decode(swd_pipeline *pl, int32_t B, const uint8_t *det, uint8_t *total,
+                        int32_t *stats, double *min_pm);
+/* device pointers, asynchronous on `stream` */
+int swd_pipeline_decode_dev(swd_pipeline *pl, int32_t B, const uint8_t *det, int64_t det_stride,
+                            uint8_t *total, int64_t total_stride, int32_t *stats, double *min_pm,
+                            void *stream);
+int swd_pipeline_set_timing(swd_pipeline *pl, int32_t on);
+int swd_pipeline_get_timing(swd_pipeline *pl, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

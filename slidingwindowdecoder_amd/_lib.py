@@ -19,6 +19,11 @@ class GraphDesc(C.Structure):
                 ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("channel_probs", C.c_void_p)]
 
 
+class WindowDesc(C.Structure):
+    _fields_ = [("graph", GraphDesc), ("row0", C.c_int32), ("col0", C.c_int32), ("commit", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class OsdwParams(C.Structure):
     _fields_ = [("pre_max_iter", C.c_int32), ("post_max_iter", C.c_int32),
                 ("ms_scaling_factor", C.c_double), ("new_n", C.c_int32),
@@ -34,11 +39,20 @@ SYMBOLS = [
     ("swd_osdw_create", _vp, [C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
     ("swd_osdw_destroy", None, [_vp]),
     ("swd_osdw_info", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
-    ("swd_osdw_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    ("swd_osdw_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    ("swd_osdw_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    ("swd_osdw_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     ("swd_osdw_set_timing", C.c_int, [_vp, _i32]),
     ("swd_osdw_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    ("swd_pipeline_create", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
+    ("swd_pipeline_destroy", None, [_vp]),
+    ("swd_pipeline_info", C.c_int, [_vp] + [C.POINTER(_i32)] * 5),
+    ("swd_pipeline_decode", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_decode_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    ("swd_pipeline_set_timing", C.c_int, [_vp, _i32]),
+    ("swd_pipeline_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
 ]
+
+STAT_WORDS = 8
 
 
 def _preload_torch_hip_runtime():

@@ -1,7 +1,13 @@
-// C-ABI for the batched osd_window decoder (include/swd.h) -- host side of
-// swd_osdw_kernel.h.  Replaces the reference's osd_window extension type
-// (/root/reference/src/osd_window.pyx) behind a batch interface.
+// C-ABI host side (include/swd.h) of the window decoder:
+//   swd_osdw_*      one window matrix, B syndromes per call  (replaces the reference's osd_window
+//                   extension type, /root/reference/src/osd_window.pyx, behind a batch interface)
+//   swd_pipeline_*  the whole (W,F) sliding-window loop of /root/reference/osd.py:130-179 for B
+//                   shots in one launch
+// Both run swd::pipeline_kernel (swd_osdw_kernel.h); a single window is a pipeline of length 1.
 #include <string.h>
+
+#include <map>
+#include <memory>
 
 #include "swd_host.h"
 #include "swd_osdw_kernel.h"
@@ -11,61 +17,147 @@ namespace swd {
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-struct Osdw {
-    Graph g;
-    swd_osdw_params p{};
-    int device = 0;
-    int new_n = 0;
-    int nt = 256;
+static int make_layout(const Graph &g, int new_n, SwdLdsLayout &L) {
+    const int m = g.m, n = g.n, E = g.E, wm = g.wm;
+    const int npad = std::max(next_pow2(n), 2);
+    L.npad = npad;
+    L.off_idx = npad * 8;
+    L.off_aux = align_up(npad * 10, 16);
+    const int osd_bytes = L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16;
+    const int rare_bytes = L.off_aux + n * 2;
+    int scratch = std::max(std::max(E * 8, osd_bytes), std::max(rare_bytes, n * 2));
+    scratch = align_up(scratch, 16);
+    int o = scratch;
+    L.off_livemask = o; o += m * 8;
+    L.off_par = o; o += m * 4;
+    L.off_lv = o; o = align_up(o + new_n * 2, 4);
+    L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
+    L.off_cnval = o; o += m;
+    L.off_cndeg = o; o += m;
+    L.off_vnval = o; o += n;
+    L.off_hard = o; o = align_up(o + n, 16);
+    L.off_misc = o; o += 64 * 4;
+    L.total = align_up(o, 16);
+    return 0;
+}
+
+struct WindowHost {
+    std::shared_ptr<Graph> g;
+    int new_n = 0, row0 = 0, col0 = 0, commit = 0;
     SwdLdsLayout L{};
-    DevBuf synd, out, status, iters, pm, hist, osd0;
+};
+
+// A decode plan: 1..W windows + (for W > 1 or commit > 0) the global check matrix in CSC form.
+struct Plan {
+    std::vector<WindowHost> wins;
+    swd_osdw_params p{};
+    int device = 0, nt = 256;
+    int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
+    DevBuf d_wins, d_chk;
+    const uint32_t *d_colptr = nullptr;
+    const uint16_t *d_rows = nullptr;
+    // host-pointer staging
+    DevBuf synd, out, stats, pm, hist, osd0, total;
     bool timing = false;
     double t_total_ms = 0;
     int64_t t_launches = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    int layout() {
-        const int m = g.m, n = g.n, E = g.E, wm = g.wm;
-        const int npad = std::max(next_pow2(n), 2);
-        L.npad = npad;
-        L.off_idx = npad * 8;
-        L.off_aux = align_up(npad * 10, 16);
-        const int osd_bytes = L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16;
-        const int rare_bytes = L.off_aux + n * 2;
-        int scratch = std::max(std::max(E * 8, osd_bytes), std::max(rare_bytes, n * 2));
-        scratch = align_up(scratch, 16);
-        int o = scratch;
-        L.off_livemask = o; o += m * 8;
-        L.off_par = o; o += m * 4;
-        L.off_lv = o; o = align_up(o + new_n * 2, 4);
-        L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
-        L.off_cnval = o; o += m;
-        L.off_cndeg = o; o += m;
-        L.off_vnval = o; o += n;
-        L.off_hard = o; o = align_up(o + n, 16);
-        L.off_misc = o; o += 64 * 4;
-        L.total = align_up(o, 16);
-        if (L.total > 160 * 1024) {
-            set_error("window graph needs %d bytes of LDS per shot (> 163840): m=%d n=%d nnz=%d", L.total, m, n, E);
+    ~Plan() {
+        if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    }
+
+    int add_window(const swd_graph_desc *gd, int row0, int col0, int commit,
+                   std::map<std::string, std::shared_ptr<Graph>> &cache) {
+        // identical window matrices (the mid windows of a memory experiment are translates of one
+        // another) share one device graph so the hot read-only data stays small in L2
+        std::string key((const char *)gd->row_ptr, (size_t)(gd->m + 1) * 4);
+        key.append((const char *)gd->col_idx, (size_t)gd->nnz * 4);
+        key.append((const char *)gd->channel_probs, (size_t)gd->n * 8);
+        WindowHost w;
+        auto itc = cache.find(key);
+        if (itc != cache.end()) w.g = itc->second;
+        else {
+            w.g = std::make_shared<Graph>();
+            if (w.g->build(gd)) return -1;
+            if (w.g->D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", w.g->D, SWD_DMAX); return -1; }
+            if (w.g->upload()) return -1;
+            cache[key] = w.g;
+        }
+        const int m = w.g->m, n = w.g->n;
+        w.new_n = (p.new_n <= 0) ? std::min(n, 2 * m) : std::min(p.new_n, n); // osd_window.pyx:60-63
+        if (p.osd_order > w.new_n - w.g->rank) {                              // osd_window.pyx:88-92
+            set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", w.new_n - w.g->rank);
             return -1;
+        }
+        w.row0 = row0; w.col0 = col0; w.commit = commit;
+        make_layout(*w.g, w.new_n, w.L);
+        wins.push_back(w);
+        return 0;
+    }
+
+    int finalize(const swd_graph_desc *chk) {
+        if (p.osd_order > 0) { set_error("osd_order > 0 is not available in this build of the device OSD"); return -1; }
+        nmax = 0;
+        int lmax = 0, mmax = 0;
+        for (auto &w : wins) { nmax = std::max(nmax, w.g->n); lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m); }
+        if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
+        if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
+        off_det = align_up(lmax, 16);
+        lds_total = off_det + align_up(num_det, 16);
+        if (lds_total > 160 * 1024) {
+            set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
+            return -1;
+        }
+        nt = nmax <= 192 ? 64 : nmax <= 768 ? 128 : nmax <= 3072 ? 256 : 1024;
+        std::vector<SwdWindowDev> hw(wins.size());
+        for (size_t i = 0; i < wins.size(); ++i) {
+            hw[i].g = wins[i].g->d;
+            hw[i].g.new_n = wins[i].new_n;
+            hw[i].L = wins[i].L;
+            hw[i].row0 = wins[i].row0; hw[i].col0 = wins[i].col0; hw[i].commit = wins[i].commit; hw[i].pad = 0;
+        }
+        if (d_wins.reserve(hw.size() * sizeof(SwdWindowDev))) return -1;
+        SWD_HIP(hipMemcpy(d_wins.p, hw.data(), hw.size() * sizeof(SwdWindowDev), hipMemcpyHostToDevice));
+        if (chk) {
+            // CSC of the global check matrix for the residual-syndrome update (osd.py:178)
+            if (chk->m > 65535) { set_error("more than 65535 detectors"); return -1; }
+            std::vector<uint32_t> cp(chk->n + 1, 0);
+            for (int e = 0; e < chk->nnz; ++e) {
+                if (chk->col_idx[e] < 0 || chk->col_idx[e] >= chk->n) { set_error("global check matrix: column out of range"); return -1; }
+                cp[chk->col_idx[e] + 1]++;
+            }
+            for (int c = 0; c < chk->n; ++c) cp[c + 1] += cp[c];
+            std::vector<uint16_t> rows(chk->nnz);
+            std::vector<uint32_t> fill(cp.begin(), cp.end() - 1);
+            for (int r = 0; r < chk->m; ++r)
+                for (int e = chk->row_ptr[r]; e < chk->row_ptr[r + 1]; ++e) rows[fill[chk->col_idx[e]]++] = (uint16_t)r;
+            size_t o_rows = align_up((int)(cp.size() * 4), 256);
+            if (d_chk.reserve(o_rows + rows.size() * 2)) return -1;
+            SWD_HIP(hipMemcpy(d_chk.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+            SWD_HIP(hipMemcpy((char *)d_chk.p + o_rows, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
+            d_colptr = (const uint32_t *)d_chk.p;
+            d_rows = (const uint16_t *)((char *)d_chk.p + o_rows);
+            for (auto &w : wins)
+                if (w.col0 + w.commit > num_col) { set_error("commit range exceeds the global column count"); return -1; }
         }
         return 0;
     }
 };
 
 template <int NT>
-static int launch_nt(Osdw *d, const SwdOsdwArgs &a, hipStream_t st) {
-    static int lds_limit[64] = {0}; // per device, monotone: the attribute is per function, not per decoder
-    if (d->L.total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)osdw_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
-        lds_limit[d->device & 63] = d->L.total;
+static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
+    static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
+    if (d->lds_total > lds_limit[d->device & 63]) {
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        lds_limit[d->device & 63] = d->lds_total;
     }
-    hipLaunchKernelGGL(osdw_kernel<NT>, dim3(a.B), dim3(NT), d->L.total, st, a);
+    hipLaunchKernelGGL(pipeline_kernel<NT>, dim3(a.B), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
 
-static int launch(Osdw *d, const SwdOsdwArgs &a, hipStream_t st) {
+static int launch(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
     if (d->timing) {
         if (!d->ev0) { SWD_HIP(hipEventCreate(&d->ev0)); SWD_HIP(hipEventCreate(&d->ev1)); }
         SWD_HIP(hipEventRecord(d->ev0, st));
@@ -75,7 +167,6 @@ static int launch(Osdw *d, const SwdOsdwArgs &a, hipStream_t st) {
     case 64: rc = launch_nt<64>(d, a, st); break;
     case 128: rc = launch_nt<128>(d, a, st); break;
     case 256: rc = launch_nt<256>(d, a, st); break;
-    case 512: rc = launch_nt<512>(d, a, st); break;
     default: rc = launch_nt<1024>(d, a, st); break;
     }
     if (rc) return rc;
@@ -90,67 +181,78 @@ static int launch(Osdw *d, const SwdOsdwArgs &a, hipStream_t st) {
     return 0;
 }
 
+static int check_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: the MI355X decoder has no CPU fallback");
+        return -1;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return -1; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return -1; }
+    return 0;
+}
+
+static int check_params(swd_osdw_params &p) {
+    if (p.osd_method == 0) p.osd_order = 0; // osd_window.pyx:69-71
+    if (p.osd_method < 0 || p.osd_method > 2) { set_error("ERROR: OSD method '%d' invalid.", p.osd_method); return -1; }
+    return 0;
+}
+
+static void fill_params(const Plan *d, SwdDecodeParams &P, bool hist_is_state, bool hist_is_output) {
+    P.pre_iter = d->p.pre_max_iter; P.post_iter = d->p.post_max_iter;
+    P.osd_method = d->p.osd_method; P.osd_order = d->p.osd_order; P.alpha = d->p.ms_scaling_factor;
+    P.hist_is_state = hist_is_state ? 1 : 0;
+    P.record_all = (hist_is_state || hist_is_output) ? 1 : 0;
+    // a fresh reference object has an all-zero history; only observable when fewer than four
+    // iterations ran or when the history is returned
+    P.zero_hist = (!hist_is_state && (hist_is_output || d->p.pre_max_iter < 4)) ? 1 : 0;
+}
+
 } // namespace swd
 
 using namespace swd;
 
+// ------------------------------------------------------------------------------------------
+// single window
+// ------------------------------------------------------------------------------------------
 extern "C" swd_osdw *swd_osdw_create(const swd_graph_desc *g, const swd_osdw_params *p, int device) {
-    if (!p) { set_error("null params"); return nullptr; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        set_error("no HIP device available: the MI355X decoder has no CPU fallback");
-        return nullptr;
-    }
-    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return nullptr; }
-    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return nullptr; }
-    Osdw *d = new Osdw();
+    if (!p || !g) { set_error("null argument"); return nullptr; }
+    if (check_device(device)) return nullptr;
+    Plan *d = new Plan();
     d->device = device;
     d->p = *p;
-    if (d->g.build(g)) { delete d; return nullptr; }
-    const int m = d->g.m, n = d->g.n;
-    if (d->g.D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", d->g.D, SWD_DMAX); delete d; return nullptr; }
-    d->new_n = (p->new_n <= 0) ? std::min(n, 2 * m) : std::min(p->new_n, n); // osd_window.pyx:60-63
-    if (d->p.osd_method == 0) d->p.osd_order = 0;                             // osd_window.pyx:69-71
-    if (d->p.osd_method < 0 || d->p.osd_method > 2) { set_error("ERROR: OSD method '%d' invalid.", d->p.osd_method); delete d; return nullptr; }
-    if (d->p.osd_order > d->new_n - d->g.rank) {                              // osd_window.pyx:88-92
-        set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", d->new_n - d->g.rank);
-        delete d; return nullptr;
-    }
-    if (d->p.osd_order > 0) { set_error("osd_order > 0 is not available in this build of the device OSD"); delete d; return nullptr; }
-    if (d->g.upload()) { delete d; return nullptr; }
-    d->g.d.new_n = d->new_n;
-    d->nt = n <= 192 ? 64 : n <= 768 ? 128 : n <= 3072 ? 256 : 1024;
-    if (d->layout()) { delete d; return nullptr; }
+    std::map<std::string, std::shared_ptr<Graph>> cache;
+    if (check_params(d->p) || d->add_window(g, 0, 0, 0, cache) || d->finalize(nullptr)) { delete d; return nullptr; }
     return (swd_osdw *)d;
 }
 
 extern "C" void swd_osdw_destroy(swd_osdw *h) {
-    Osdw *d = (Osdw *)h;
+    Plan *d = (Plan *)h;
     if (!d) return;
     (void)hipSetDevice(d->device);
-    if (d->ev0) { (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); }
     delete d;
 }
 
 extern "C" int swd_osdw_info(const swd_osdw *h, int32_t *m, int32_t *n, int32_t *new_n, int32_t *rank) {
-    const Osdw *d = (const Osdw *)h;
+    const Plan *d = (const Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
-    if (m) *m = d->g.m;
-    if (n) *n = d->g.n;
-    if (new_n) *new_n = d->new_n;
-    if (rank) *rank = d->g.rank;
+    const WindowHost &w = d->wins[0];
+    if (m) *m = w.g->m;
+    if (n) *n = w.g->n;
+    if (new_n) *new_n = w.new_n;
+    if (rank) *rank = w.g->rank;
     return 0;
 }
 
 extern "C" int swd_osdw_set_timing(swd_osdw *h, int32_t on) {
-    Osdw *d = (Osdw *)h;
+    Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     d->timing = on != 0; d->t_total_ms = 0; d->t_launches = 0;
     return 0;
 }
 
 extern "C" int swd_osdw_get_timing(swd_osdw *h, double *total_ms, int64_t *launches) {
-    Osdw *d = (Osdw *)h;
+    Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (total_ms) *total_ms = d->t_total_ms;
     if (launches) *launches = d->t_launches;
@@ -159,55 +261,133 @@ extern "C" int swd_osdw_get_timing(swd_osdw *h, double *total_ms, int64_t *launc
 }
 
 extern "C" int swd_osdw_decode_batch_dev(swd_osdw *h, int32_t B, const uint8_t *synd, int64_t synd_stride,
-                                         uint8_t *out, int64_t out_stride, int32_t *status, int32_t *iters,
-                                         double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0,
-                                         void *stream) {
-    Osdw *d = (Osdw *)h;
+                                         uint8_t *out, int64_t out_stride, int32_t *stats, double *min_pm,
+                                         double *hist, int32_t hist_is_state, uint8_t *osd0, void *stream) {
+    Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
-    if (!synd || !out || !status || !iters || !min_pm) { set_error("null output/input pointer"); return -1; }
+    if (!synd || !out) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
+    const int n = d->wins[0].g->n, m = d->wins[0].g->m;
+    const bool hist_out = hist != nullptr;
     if (!hist) {
         if (hist_is_state) { set_error("hist_is_state requires a caller-provided history buffer"); return -1; }
-        if (d->hist.reserve((size_t)B * 4 * d->g.n * sizeof(double))) return -1;
+        if (d->hist.reserve((size_t)B * 4 * n * sizeof(double))) return -1;
         hist = d->hist.as<double>();
     }
-    SwdOsdwArgs a{};
-    a.g = d->g.d; a.L = d->L;
-    a.pre_iter = d->p.pre_max_iter; a.post_iter = d->p.post_max_iter;
-    a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
-    a.B = B; a.hist_is_state = hist_is_state;
-    a.synd = synd; a.synd_stride = synd_stride ? synd_stride : d->g.m;
-    a.out = out; a.out_stride = out_stride ? out_stride : d->g.n;
-    a.status = status; a.iters = iters; a.min_pm = min_pm; a.hist = hist; a.osd0 = osd0;
+    SwdPipeArgs a{};
+    a.wins = d->d_wins.as<SwdWindowDev>(); a.W = 1; a.B = B;
+    fill_params(d, a.P, hist_is_state != 0, hist_out);
+    a.det = synd; a.det_stride = synd_stride ? synd_stride : m; a.num_det = m; a.off_det = d->off_det;
+    a.total = nullptr; a.win_out = out; a.win_out_stride = out_stride ? out_stride : n;
+    a.stats = stats; a.min_pm = min_pm; a.hist = hist; a.hist_stride = 4 * (int64_t)n; a.osd0 = osd0;
     return launch(d, a, (hipStream_t)stream);
 }
 
-extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *status,
-                                     int32_t *iters, double *min_pm, double *hist, int32_t hist_is_state,
-                                     uint8_t *osd0) {
-    Osdw *d = (Osdw *)h;
+extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
+                                     double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0) {
+    Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
+    if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
-    const size_t m = d->g.m, n = d->g.n;
-    if (d->synd.reserve(B * m) || d->out.reserve(B * n) || d->status.reserve(B * 4) || d->iters.reserve(B * 4) ||
-        d->pm.reserve(B * 8) || d->hist.reserve((size_t)B * 4 * n * 8))
+    const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
+    const size_t hbytes = (size_t)B * 4 * n * 8;
+    if (d->synd.reserve(B * m) || d->out.reserve(B * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
+        d->pm.reserve(B * 8) || d->hist.reserve(hbytes))
         return -1;
     if (osd0 && d->osd0.reserve(B * n)) return -1;
     SWD_HIP(hipMemcpy(d->synd.p, synd, B * m, hipMemcpyHostToDevice));
-    if (hist && hist_is_state) SWD_HIP(hipMemcpy(d->hist.p, hist, (size_t)B * 4 * n * 8, hipMemcpyHostToDevice));
+    if (hist && hist_is_state) SWD_HIP(hipMemcpy(d->hist.p, hist, hbytes, hipMemcpyHostToDevice));
     if (osd0) SWD_HIP(hipMemset(d->osd0.p, 0, B * n));
-    int rc = swd_osdw_decode_batch_dev(h, B, d->synd.as<uint8_t>(), 0, d->out.as<uint8_t>(), 0, d->status.as<int32_t>(),
-                                       d->iters.as<int32_t>(), d->pm.as<double>(), d->hist.as<double>(),
+    int rc = swd_osdw_decode_batch_dev(h, B, d->synd.as<uint8_t>(), 0, d->out.as<uint8_t>(), 0, d->stats.as<int32_t>(),
+                                       d->pm.as<double>(), hist ? d->hist.as<double>() : nullptr,
                                        (hist && hist_is_state) ? 1 : 0, osd0 ? d->osd0.as<uint8_t>() : nullptr, nullptr);
     if (rc) return rc;
     SWD_HIP(hipDeviceSynchronize());
     SWD_HIP(hipMemcpy(out, d->out.p, B * n, hipMemcpyDeviceToHost));
-    SWD_HIP(hipMemcpy(status, d->status.p, B * 4, hipMemcpyDeviceToHost));
-    SWD_HIP(hipMemcpy(iters, d->iters.p, B * 4, hipMemcpyDeviceToHost));
+    SWD_HIP(hipMemcpy(stats, d->stats.p, (size_t)B * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
     SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * 8, hipMemcpyDeviceToHost));
-    if (hist) SWD_HIP(hipMemcpy(hist, d->hist.p, (size_t)B * 4 * n * 8, hipMemcpyDeviceToHost));
+    if (hist) SWD_HIP(hipMemcpy(hist, d->hist.p, hbytes, hipMemcpyDeviceToHost));
     if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// sliding-window pipeline
+// ------------------------------------------------------------------------------------------
+extern "C" swd_pipeline *swd_pipeline_create(int32_t num_windows, const swd_window_desc *wins,
+                                             const swd_graph_desc *chk, const swd_osdw_params *p, int device) {
+    if (!p || !wins || !chk || num_windows <= 0) { set_error("null argument"); return nullptr; }
+    if (check_device(device)) return nullptr;
+    Plan *d = new Plan();
+    d->device = device;
+    d->p = *p;
+    std::map<std::string, std::shared_ptr<Graph>> cache;
+    if (check_params(d->p)) { delete d; return nullptr; }
+    for (int i = 0; i < num_windows; ++i)
+        if (d->add_window(&wins[i].graph, wins[i].row0, wins[i].col0, wins[i].commit, cache)) { delete d; return nullptr; }
+    if (d->finalize(chk)) { delete d; return nullptr; }
+    return (swd_pipeline *)d;
+}
+
+extern "C" void swd_pipeline_destroy(swd_pipeline *h) { swd_osdw_destroy((swd_osdw *)h); }
+
+extern "C" int swd_pipeline_info(const swd_pipeline *h, int32_t *num_windows, int32_t *num_det, int32_t *num_col,
+                                 int32_t *lds_bytes, int32_t *threads) {
+    const Plan *d = (const Plan *)h;
+    if (!d) { set_error("null pipeline"); return -1; }
+    if (num_windows) *num_windows = (int32_t)d->wins.size();
+    if (num_det) *num_det = d->num_det;
+    if (num_col) *num_col = d->num_col;
+    if (lds_bytes) *lds_bytes = d->lds_total;
+    if (threads) *threads = d->nt;
+    return 0;
+}
+
+extern "C" int swd_pipeline_set_timing(swd_pipeline *h, int32_t on) { return swd_osdw_set_timing((swd_osdw *)h, on); }
+extern "C" int swd_pipeline_get_timing(swd_pipeline *h, double *total_ms, int64_t *launches) {
+    return swd_osdw_get_timing((swd_osdw *)h, total_ms, launches);
+}
+
+extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t *det, int64_t det_stride,
+                                       uint8_t *total, int64_t total_stride, int32_t *stats, double *min_pm,
+                                       void *stream) {
+    Plan *d = (Plan *)h;
+    if (!d) { set_error("null pipeline"); return -1; }
+    if (B <= 0) return 0;
+    if (!det || !total) { set_error("null output/input pointer"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    if (d->hist.reserve((size_t)B * 4 * d->nmax * sizeof(double))) return -1;
+    SwdPipeArgs a{};
+    a.wins = d->d_wins.as<SwdWindowDev>(); a.W = (int)d->wins.size(); a.B = B;
+    fill_params(d, a.P, false, false);
+    a.det = det; a.det_stride = det_stride ? det_stride : d->num_det; a.num_det = d->num_det; a.off_det = d->off_det;
+    a.total = total; a.total_stride = total_stride ? total_stride : d->num_col;
+    a.chk_colptr = d->d_colptr; a.chk_rows = d->d_rows;
+    a.win_out = nullptr; a.stats = stats; a.min_pm = min_pm;
+    a.hist = d->hist.as<double>(); a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
+    return launch(d, a, (hipStream_t)stream);
+}
+
+extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats,
+                                   double *min_pm) {
+    Plan *d = (Plan *)h;
+    if (!d) { set_error("null pipeline"); return -1; }
+    if (B <= 0) return 0;
+    if (!det || !total) { set_error("null output/input pointer"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    const size_t W = d->wins.size();
+    if (d->synd.reserve((size_t)B * d->num_det) || d->total.reserve((size_t)B * d->num_col) ||
+        d->stats.reserve(B * W * SWD_STAT_WORDS * 4) || d->pm.reserve(B * W * 8))
+        return -1;
+    SWD_HIP(hipMemcpy(d->synd.p, det, (size_t)B * d->num_det, hipMemcpyHostToDevice));
+    int rc = swd_pipeline_decode_dev(h, B, d->synd.as<uint8_t>(), 0, d->total.as<uint8_t>(), 0, d->stats.as<int32_t>(),
+                                     d->pm.as<double>(), nullptr);
+    if (rc) return rc;
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(total, d->total.p, (size_t)B * d->num_col, hipMemcpyDeviceToHost));
+    if (stats) SWD_HIP(hipMemcpy(stats, d->stats.p, B * W * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
+    if (min_pm) SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * W * 8, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -23,22 +23,46 @@ struct SwdLdsLayout {
     int32_t off_aux;   // inside scratch: first byte after the sort arrays
 };
 
-struct SwdOsdwArgs {
-    SwdGraphDev g;
-    SwdLdsLayout L;
+// decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
+struct SwdDecodeParams {
     int32_t pre_iter, post_iter, osd_method, osd_order;
     double alpha;
-    int32_t B;
-    int32_t hist_is_state;
-    const uint8_t *synd;
-    int64_t synd_stride;
-    uint8_t *out;
-    int64_t out_stride;
-    int32_t *status;
-    int32_t *iters;
-    double *min_pm;
-    double *hist; // [B][4][n]
-    uint8_t *osd0; // nullable [B][n]
+    int32_t hist_is_state; // history buffer carries state in and out (single-shot decode())
+    int32_t zero_hist;     // start every decode from a zero history
+    int32_t record_all;    // store the posterior of every iteration (history is an output)
+};
+
+// one window of the sliding-window plan: its graph + where it sits in the global DEM
+struct SwdWindowDev {
+    SwdGraphDev g;
+    SwdLdsLayout L;
+    int32_t row0;   // first detector row        (anchors[t].row, osd.py:139)
+    int32_t col0;   // first global fault column (anchors[t].col)
+    int32_t commit; // leading columns committed after decoding (osd.py:140,170-173)
+    int32_t pad;
+};
+
+
+
+struct SwdPipeArgs {
+    const SwdWindowDev *wins;
+    int32_t W, B;
+    SwdDecodeParams P;
+    const uint8_t *det;       // [B][det_stride] detector bits (window 0 reads rows row0..)
+    int64_t det_stride;
+    int32_t num_det;
+    int32_t off_det;          // LDS offset of the residual-syndrome bytes
+    uint8_t *total;           // nullable [B][total_stride] committed faults (total_e_hat)
+    int64_t total_stride;
+    const uint32_t *chk_colptr; // CSC of the global check matrix (residual update, osd.py:178)
+    const uint16_t *chk_rows;
+    uint8_t *win_out;         // nullable [B][win_out_stride]: full estimate of window W-1
+    int64_t win_out_stride;
+    int32_t *stats;           // nullable [B][W][SWD_STAT_WORDS]
+    double *min_pm;           // nullable [B][W]
+    double *hist;             // [B][4][nmax]
+    int64_t hist_stride;      // doubles per shot
+    uint8_t *osd0;            // nullable [B][n] (single-window use)
 };
 
 namespace swd {
@@ -122,11 +146,10 @@ __device__ __forceinline__ void wave_fence() {
 // i+1, so an iteration costs two barriers.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool FULL>
-__device__ int bp_run(const SwdOsdwArgs &a, Lds &s, int max_iter, int nlive, double *hist_b,
-                      int &iters_done) {
-    const SwdGraphDev &g = a.g;
+__device__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
+                      double *hist_b, int &iters_done) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
-    const double alpha = a.alpha, nalpha = -a.alpha;
+    const double alpha = P.alpha, nalpha = -P.alpha;
     iters_done = 0;
     if (max_iter <= 0) return 0;
     for (int it = 0; it < max_iter; ++it) {
@@ -184,7 +207,7 @@ __device__ int bp_run(const SwdOsdwArgs &a, Lds &s, int max_iter, int nlive, dou
 #pragma unroll
             for (int k = 0; k < SWD_DMAX; ++k)
                 if (live[k]) { pre[k] = temp; temp += c[k]; }
-            hist_b[slot_h * n + v] = temp;
+            if (P.record_all || it >= max_iter - 4) hist_b[slot_h * n + v] = temp;
             const bool hd = (temp <= 0);
             s.hard[v] = hd ? 1 : 0;
             double suf = 0.0;
@@ -209,8 +232,7 @@ __device__ int bp_run(const SwdOsdwArgs &a, Lds &s, int max_iter, int nlive, dou
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every edge of every live VN
 template <int NT, bool FULL>
-__device__ void bp_init(const SwdOsdwArgs &a, Lds &s, int nlive) {
-    const SwdGraphDev &g = a.g;
+__device__ void bp_init(const SwdGraphDev &g, Lds &s, int nlive) {
     const int cnt = FULL ? g.n : nlive;
     for (int i = threadIdx.x; i < cnt; i += NT) {
         const int v = FULL ? i : (int)s.lv[i];
@@ -244,8 +266,8 @@ __device__ void sort_pairs(uint64_t *key, uint16_t *idx, int npad) {
 // sum of llr[v] over hard[v]==1 in ascending v (min_pm, osd_window.pyx:168-169 / 233-235).
 // `list` must hold n u16.  Result valid on every thread.
 template <int NT>
-__device__ double ordered_pm(const SwdOsdwArgs &a, Lds &s, uint16_t *list) {
-    const int n = a.g.n;
+__device__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint16_t *list) {
+    const int n = g.n;
     const int ch = (n + NT - 1) / NT;
     const int v0 = threadIdx.x * ch, v1 = min(n, v0 + ch);
     int cnt = 0;
@@ -258,7 +280,7 @@ __device__ double ordered_pm(const SwdOsdwArgs &a, Lds &s, uint16_t *list) {
     double *dres = (double *)(s.scal + 28);
     if (threadIdx.x == 0) {
         double pm = 0.0;
-        for (int i = 0; i < total; ++i) pm += a.g.llr[list[i]];
+        for (int i = 0; i < total; ++i) pm += g.llr[list[i]];
         *dres = pm;
     }
     __syncthreads();
@@ -334,14 +356,13 @@ __device__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
 // reference's LU + forward/backward substitution (mod2sparse_extra.cpp:78-106) because both
 // solve the same invertible pivot-row x pivot-column system with zeros elsewhere.
 // T is stored column-major: Tc[j*wm + w] = word w of column j (bit r = T[r][j]).
-__device__ void osd0_wave(const SwdOsdwArgs &a, Lds &s, const uint16_t *order, uint64_t *Tc,
-                          uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b) {
-    const SwdGraphDev &g = a.g;
+__device__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tc,
+                         uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b) {
     const int lane = threadIdx.x & 63;
     const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
     // this lane's words of the pivoted-row mask: w = lane, lane + 64, ... (wm <= 16 -> one word)
     uint64_t P = 0;
-    int npiv = 0;
+    int npiv = 0, rowadds = 0;
     for (int p = 0; p < n && npiv < rank; ++p) {
         const int v = order[p];
         const int deg = g.col_deg[v];
@@ -355,6 +376,14 @@ __device__ void osd0_wave(const SwdOsdwArgs &a, Lds &s, const uint16_t *order, u
         const uint64_t cw = __shfl(cand, ws, 64);
         const int bit = __ffsll((long long)cw) - 1;
         const int r = ws * 64 + bit;
+        {   // row additions the reference's LU would apply: unpivoted rows with a 1 in this column
+            uint64_t un = cand;
+            if (lane == ws) un &= ~(1ull << bit);
+            int c = (lane < wm) ? __popcll(un) : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+            rowadds += c;
+        }
         if (lane == ws) { P |= 1ull << bit; red &= ~(1ull << bit); }
         if (lane == 0) { piv_col[npiv] = (uint16_t)v; piv_row[npiv] = (uint16_t)r; }
         ++npiv;
@@ -379,184 +408,254 @@ __device__ void osd0_wave(const SwdOsdwArgs &a, Lds &s, const uint16_t *order, u
         s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
     }
     wave_fence();
+    return rowadds;
 }
 
-template <int NT>
-__global__ void __launch_bounds__(NT) osdw_kernel(const SwdOsdwArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SwdGraphDev &g = a.g;
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int m = g.m, n = g.n;
-    Lds s;
+struct WinResult {
+    int exit_class, conv, total_it, pre_it, post_it, live_vn, live_cn, live_e, osd_rowadds;
+    double pm;
+};
+
+__device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout &L) {
     s.scratch = smem;
     s.msg = (double *)smem;
-    s.livemask = (uint64_t *)(smem + a.L.off_livemask);
-    s.par = (uint32_t *)(smem + a.L.off_par);
-    s.lv = (uint16_t *)(smem + a.L.off_lv);
-    s.jptr = (uint16_t *)(smem + a.L.off_jptr);
-    s.cn_val = (int8_t *)(smem + a.L.off_cnval);
-    s.cn_deg = (uint8_t *)(smem + a.L.off_cndeg);
-    s.vn_val = (int8_t *)(smem + a.L.off_vnval);
-    s.hard = (uint8_t *)(smem + a.L.off_hard);
-    s.flags = (int *)(smem + a.L.off_misc);
+    s.livemask = (uint64_t *)(smem + L.off_livemask);
+    s.par = (uint32_t *)(smem + L.off_par);
+    s.lv = (uint16_t *)(smem + L.off_lv);
+    s.jptr = (uint16_t *)(smem + L.off_jptr);
+    s.cn_val = (int8_t *)(smem + L.off_cnval);
+    s.cn_deg = (uint8_t *)(smem + L.off_cndeg);
+    s.vn_val = (int8_t *)(smem + L.off_vnval);
+    s.hard = (uint8_t *)(smem + L.off_hard);
+    s.flags = (int *)(smem + L.off_misc);
     s.scal = s.flags + 32;
-    s.fpar = 0;
+}
 
-    const uint8_t *synd_b = a.synd + (int64_t)b * a.synd_stride;
-    uint8_t *out_b = a.out + (int64_t)b * a.out_stride;
-    double *hist_b = a.hist + (int64_t)b * 4 * n;
+// osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
+// order).  On return s.hard[0..n) is the vector decode() returns.
+template <int NT>
+__device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, WinResult &R) {
+    const int tid = threadIdx.x;
+    const int m = g.m, n = g.n;
 
     // reset (osd_window.pyx:288-303)
     for (int l = tid; l < m; l += NT) {
         const int d = g.row_deg[l];
-        s.cn_val[l] = (int8_t)(synd_b[g.perm[l]] ? 1 : 0);
+        s.cn_val[l] = (int8_t)(synd[g.perm[l]] ? 1 : 0);
         s.cn_deg[l] = (uint8_t)d;
         s.livemask[l] = (d >= 64) ? ~0ull : ((1ull << d) - 1ull);
     }
     for (int v = tid; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
     for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
-    if (!a.hist_is_state)
+    if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
-    bp_init<NT, true>(a, s, n);
+    __syncthreads(); // jptr visible before bp_init uses slots (slots come packed; keeps later code simple)
+    bp_init<NT, true>(g, s, n);
     __syncthreads();
 
-    int exit_class, conv = 0, total_it = 0, it = 0;
-    double pm = 0.0;
+    int it = 0;
+    R.conv = 0; R.pm = 0.0; R.pre_it = R.post_it = 0;
+    R.live_vn = n; R.live_cn = m; R.live_e = g.E; R.osd_rowadds = 0;
     uint16_t *list0 = (uint16_t *)s.scratch;
 
-    conv = bp_run<NT, true>(a, s, a.pre_iter, n, hist_b, it);
-    total_it = it;
-    if (conv) {
-        exit_class = SWD_EXIT_PRE;
-        pm = ordered_pm<NT>(a, s, list0);
-    } else {
-        // ---- order columns by summed LLR history (osd_window.pyx:172-176)
-        uint64_t *key = (uint64_t *)s.scratch;
-        uint16_t *idx = (uint16_t *)(s.scratch + a.L.off_idx);
-        __syncthreads(); // history stores of the last VN pass are visible block-wide
-        for (int v = tid; v < a.L.npad; v += NT) {
-            if (v < n) {
-                const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
-                key[v] = f2key(sum);
-                idx[v] = (uint16_t)v;
-            } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+    R.conv = bp_run<NT, true>(g, P, s, P.pre_iter, n, hist_b, it);
+    R.pre_it = it;
+    if (R.conv) {
+        R.exit_class = SWD_EXIT_PRE;
+        R.pm = ordered_pm<NT>(g, s, list0);
+        R.total_it = R.pre_it;
+        return;
+    }
+    // ---- order columns by summed LLR history (osd_window.pyx:172-176)
+    uint64_t *key = (uint64_t *)s.scratch;
+    uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
+    __syncthreads();
+    for (int v = tid; v < L.npad; v += NT) {
+        if (v < n) {
+            const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+            key[v] = f2key(sum);
+            idx[v] = (uint16_t)v;
+        } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+    }
+    __syncthreads();
+    sort_pairs<NT>(key, idx, L.npad);
+    // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
+    for (int i = g.new_n + tid; i < n; i += NT) s.vn_val[idx[i]] = 0;
+    __syncthreads();
+    bool contra = false;
+    for (int l = tid; l < m; l += NT) {
+        const int d = g.row_deg[l];
+        uint64_t mk = 0;
+        int cntl = 0;
+        for (int j = 0; j < d; ++j) {
+            const int v = g.row_col[s.jptr[j] + l];
+            if (s.vn_val[v] < 0) { mk |= 1ull << j; ++cntl; }
         }
-        __syncthreads();
-        sort_pairs<NT>(key, idx, a.L.npad);
-        // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
-        for (int i = g.new_n + tid; i < n; i += NT) s.vn_val[idx[i]] = 0;
-        __syncthreads();
-        bool contra = false;
-        for (int l = tid; l < m; l += NT) {
-            const int d = g.row_deg[l];
-            uint64_t mk = 0;
-            int cntl = 0;
-            for (int j = 0; j < d; ++j) {
-                const int v = g.row_col[s.jptr[j] + l];
-                if (s.vn_val[v] < 0) { mk |= 1ull << j; ++cntl; }
-            }
-            s.livemask[l] = mk;
-            s.cn_deg[l] = (uint8_t)cntl;
-            if (cntl == 0) {
-                if (s.cn_val[l] != 0) contra = true;
-                else s.cn_val[l] = -1;
-            }
-        }
-        const bool any_contra = block_any<NT>(contra, s);
-        if (any_contra) {
-            // "setting vn failed" (osd_window.pyx:179-181): the reference stops at the first
-            // decimation that empties an unsatisfied check; only VNs up to that sorted position
-            // have been zeroed in bp_decoding.
-            uint16_t *pos = (uint16_t *)(s.scratch + a.L.off_aux);
-            for (int i = tid; i < n; i += NT) pos[idx[i]] = (uint16_t)i;
-            if (tid == 0) s.scal[0] = 0x7fffffff;
-            __syncthreads();
-            for (int l = tid; l < m; l += NT) {
-                if (s.cn_deg[l] == 0 && s.cn_val[l] > 0) {
-                    int mx = 0;
-                    const int d = g.row_deg[l];
-                    for (int j = 0; j < d; ++j) mx = max(mx, (int)pos[g.row_col[s.jptr[j] + l]]);
-                    atomicMin(&s.scal[0], mx);
-                }
-            }
-            __syncthreads();
-            const int kstop = s.scal[0];
-            for (int i = g.new_n + tid; i <= kstop && i < n; i += NT) s.hard[idx[i]] = 0;
-            __syncthreads();
-            exit_class = SWD_EXIT_FAIL_SET;
-        } else {
-            for (int i = g.new_n + tid; i < n; i += NT) s.hard[idx[i]] = 0;
-            __syncthreads();
-            // ---- peel (osd_window.pyx:184-186)
-            if (tid < 64) {
-                const bool bad = peel_wave(g, s);
-                if (tid == 0) s.scal[1] = bad ? 1 : 0;
-            }
-            __syncthreads();
-            if (s.scal[1]) {
-                exit_class = SWD_EXIT_FAIL_PEEL;
-            } else {
-                // ---- compact the live VNs, re-initialise their messages (osd_window.pyx:187)
-                const int ch = (n + NT - 1) / NT;
-                const int v0 = tid * ch, v1 = min(n, v0 + ch);
-                int cnt = 0;
-                for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] < 0) ? 1 : 0;
-                int nlive;
-                int pos = block_exscan<NT>(cnt, s, nlive);
-                for (int v = v0; v < v1; ++v)
-                    if (s.vn_val[v] < 0) s.lv[pos++] = (uint16_t)v;
-                __syncthreads();
-                bp_init<NT, false>(a, s, nlive);
-                __syncthreads();
-                conv = bp_run<NT, false>(a, s, a.post_iter, nlive, hist_b, it);
-                total_it += it;
-                if (conv) {
-                    exit_class = SWD_EXIT_POST;
-                    pm = ordered_pm<NT>(a, s, list0);
-                } else if (a.osd_order < 0) {
-                    exit_class = SWD_EXIT_NO_OSD;
-                } else {
-                    // ---- OSD (osd_window.pyx:201-284): keys -1000 / +1000 / history sum
-                    __syncthreads();
-                    for (int v = tid; v < a.L.npad; v += NT) {
-                        if (v < n) {
-                            double sum;
-                            const int vv = s.vn_val[v];
-                            if (vv == 1) sum = -1000.0;
-                            else if (vv == 0) sum = 1000.0;
-                            else sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
-                            key[v] = f2key(sum);
-                            idx[v] = (uint16_t)v;
-                        } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
-                    }
-                    __syncthreads();
-                    sort_pairs<NT>(key, idx, a.L.npad);
-                    uint64_t *Tc = (uint64_t *)(s.scratch + a.L.off_aux);
-                    uint64_t *Sbuf = Tc + m * g.wm;
-                    uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
-                    uint16_t *piv_row = piv_col + g.rank;
-                    uint16_t *list1 = piv_row + g.rank;
-                    for (int i = tid; i < m * g.wm; i += NT) {
-                        const int j = i / g.wm, w = i - j * g.wm;
-                        Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
-                    }
-                    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
-                    __syncthreads();
-                    if (tid < 64) osd0_wave(a, s, idx, Tc, Sbuf, piv_col, piv_row, synd_b);
-                    __syncthreads();
-                    if (a.osd0)
-                        for (int v = tid; v < n; v += NT) a.osd0[(int64_t)b * n + v] = s.hard[v];
-                    pm = ordered_pm<NT>(a, s, list1);
-                    exit_class = SWD_EXIT_OSD;
-                }
-            }
+        s.livemask[l] = mk;
+        s.cn_deg[l] = (uint8_t)cntl;
+        if (cntl == 0) {
+            if (s.cn_val[l] != 0) contra = true;
+            else s.cn_val[l] = -1;
         }
     }
-    for (int v = tid; v < n; v += NT) out_b[v] = s.hard[v];
-    if (tid == 0) {
-        a.status[b] = exit_class | (conv ? 0x100 : 0);
-        a.iters[b] = total_it;
-        a.min_pm[b] = pm;
+    const bool any_contra = block_any<NT>(contra, s);
+    if (any_contra) {
+        // "setting vn failed" (osd_window.pyx:179-181): the reference stops at the first decimation
+        // that empties an unsatisfied check; only VNs up to that sorted position were zeroed.
+        uint16_t *pos = (uint16_t *)(s.scratch + L.off_aux);
+        for (int i = tid; i < n; i += NT) pos[idx[i]] = (uint16_t)i;
+        if (tid == 0) s.scal[0] = 0x7fffffff;
+        __syncthreads();
+        for (int l = tid; l < m; l += NT) {
+            if (s.cn_deg[l] == 0 && s.cn_val[l] > 0) {
+                int mx = 0;
+                const int d = g.row_deg[l];
+                for (int j = 0; j < d; ++j) mx = max(mx, (int)pos[g.row_col[s.jptr[j] + l]]);
+                atomicMin(&s.scal[0], mx);
+            }
+        }
+        __syncthreads();
+        const int kstop = s.scal[0];
+        for (int i = g.new_n + tid; i <= kstop && i < n; i += NT) s.hard[idx[i]] = 0;
+        __syncthreads();
+        R.exit_class = SWD_EXIT_FAIL_SET;
+        R.total_it = R.pre_it;
+        return;
+    }
+    for (int i = g.new_n + tid; i < n; i += NT) s.hard[idx[i]] = 0;
+    __syncthreads();
+    // ---- peel (osd_window.pyx:184-186)
+    if (tid < 64) {
+        const bool bad = peel_wave(g, s);
+        if (tid == 0) { s.scal[1] = bad ? 1 : 0; s.scal[2] = 0; s.scal[3] = 0; }
+    }
+    __syncthreads();
+    if (s.scal[1]) {
+        R.exit_class = SWD_EXIT_FAIL_PEEL;
+        R.total_it = R.pre_it;
+        return;
+    }
+    // ---- compact the live VNs, re-initialise their messages (osd_window.pyx:187)
+    int nlive;
+    {
+        const int ch = (n + NT - 1) / NT;
+        const int v0 = tid * ch, v1 = min(n, v0 + ch);
+        int cnt = 0;
+        for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] < 0) ? 1 : 0;
+        int pos = block_exscan<NT>(cnt, s, nlive);
+        for (int v = v0; v < v1; ++v)
+            if (s.vn_val[v] < 0) s.lv[pos++] = (uint16_t)v;
+        int lc = 0, le = 0;
+        for (int l = tid; l < m; l += NT)
+            if (s.cn_val[l] >= 0) { ++lc; le += __popcll(s.livemask[l]); }
+        if (lc) { atomicAdd(&s.scal[2], lc); atomicAdd(&s.scal[3], le); }
+    }
+    __syncthreads();
+    R.live_vn = nlive; R.live_cn = s.scal[2]; R.live_e = s.scal[3];
+    bp_init<NT, false>(g, s, nlive);
+    __syncthreads();
+    R.conv = bp_run<NT, false>(g, P, s, P.post_iter, nlive, hist_b, it);
+    R.post_it = it;
+    R.total_it = R.pre_it + R.post_it;
+    if (R.conv) {
+        R.exit_class = SWD_EXIT_POST;
+        R.pm = ordered_pm<NT>(g, s, list0);
+        return;
+    }
+    if (P.osd_order < 0) { R.exit_class = SWD_EXIT_NO_OSD; return; }
+    // ---- OSD (osd_window.pyx:201-284): keys -1000 / +1000 / history sum
+    __syncthreads();
+    for (int v = tid; v < L.npad; v += NT) {
+        if (v < n) {
+            double sum;
+            const int vv = s.vn_val[v];
+            if (vv == 1) sum = -1000.0;
+            else if (vv == 0) sum = 1000.0;
+            else sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+            key[v] = f2key(sum);
+            idx[v] = (uint16_t)v;
+        } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+    }
+    __syncthreads();
+    sort_pairs<NT>(key, idx, L.npad);
+    uint64_t *Tc = (uint64_t *)(s.scratch + L.off_aux);
+    uint64_t *Sbuf = Tc + m * g.wm;
+    uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
+    uint16_t *piv_row = piv_col + g.rank;
+    uint16_t *list1 = piv_row + g.rank;
+    for (int i = tid; i < m * g.wm; i += NT) {
+        const int j = i / g.wm, w = i - j * g.wm;
+        Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
+    }
+    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+    __syncthreads();
+    if (tid < 64) {
+        const int ra = osd0_wave(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd);
+        if (tid == 0) s.scal[2] = ra;
+    }
+    __syncthreads();
+    R.osd_rowadds = s.scal[2];
+    if (osd0_b)
+        for (int v = tid; v < n; v += NT) osd0_b[v] = s.hard[v];
+    R.pm = ordered_pm<NT>(g, s, list1);
+    R.exit_class = SWD_EXIT_OSD;
+}
+
+// One workgroup carries one shot through all W windows of the sliding-window plan
+// (/root/reference/osd.py:130-179): decode window t on the residual syndrome, commit the
+// leading `commit` columns into total_e_hat, fold the committed faults back into the
+// residual syndrome (osd.py:178, done sparsely on the shot's LDS copy), next window.  Windows
+// of one shot are sequentially dependent, shots are independent, so there is no inter-workgroup
+// traffic at all.  W = 1 with commit = 0 is the plain batched osd_window.decode.
+template <int NT>
+__global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    uint8_t *sdet = (uint8_t *)(smem + a.off_det);
+    const uint8_t *det_b = a.det + (int64_t)b * a.det_stride;
+    for (int r = tid; r < a.num_det; r += NT) sdet[r] = det_b[r] ? 1 : 0;
+    double *hist_b = a.hist + (int64_t)b * a.hist_stride;
+    Lds s;
+    s.fpar = 0;
+    __syncthreads();
+    for (int wi = 0; wi < a.W; ++wi) {
+        const SwdWindowDev &w = a.wins[wi];
+        const SwdGraphDev g = w.g;
+        const SwdLdsLayout L = w.L;
+        lds_bind(s, smem, L);
+        WinResult R;
+        decode_window<NT>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
+        __syncthreads();
+        if (a.total) {
+            uint8_t *tot_b = a.total + (int64_t)b * a.total_stride + w.col0;
+            uint32_t *sdet_w = (uint32_t *)sdet;
+            for (int i = tid; i < w.commit; i += NT) {
+                const uint8_t hv = s.hard[i];
+                tot_b[i] = hv;
+                if (hv) {
+                    const int c = w.col0 + i;
+                    for (uint32_t e = a.chk_colptr[c]; e < a.chk_colptr[c + 1]; ++e) {
+                        const int r = a.chk_rows[e];
+                        atomicXor(&sdet_w[r >> 2], 1u << ((r & 3) * 8));
+                    }
+                }
+            }
+        }
+        if (a.win_out && wi == a.W - 1) {
+            uint8_t *o = a.win_out + (int64_t)b * a.win_out_stride;
+            for (int v = tid; v < g.n; v += NT) o[v] = s.hard[v];
+        }
+        if (tid == 0) {
+            if (a.stats) {
+                int32_t *st = a.stats + ((int64_t)b * a.W + wi) * SWD_STAT_WORDS;
+                st[0] = R.exit_class | (R.conv ? SWD_STATUS_CONVERGE : 0);
+                st[1] = R.total_it; st[2] = R.pre_it; st[3] = R.post_it;
+                st[4] = R.live_vn; st[5] = R.live_cn; st[6] = R.live_e; st[7] = R.osd_rowadds;
+            }
+            if (a.min_pm) a.min_pm[(int64_t)b * a.W + wi] = R.pm;
+        }
+        __syncthreads();
     }
 }
 

@@ -117,15 +117,14 @@ class osd_window:
         calls exactly like the reference object's."""
         s = _as_synd(input_vector, self.m)
         out = np.zeros(self.n, dtype=np.uint8)
-        st, it = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        st = np.zeros(_lib.STAT_WORDS, np.int32)
         pm = np.zeros(1, np.float64)
         osd0 = np.zeros(self.n, dtype=np.uint8)
         rc = _lib.lib().swd_osdw_decode_batch(self._h, 1, s.ctypes.data, out.ctypes.data, st.ctypes.data,
-                                              it.ctypes.data, pm.ctypes.data, self._hist.ctypes.data, 1,
-                                              osd0.ctypes.data)
+                                              pm.ctypes.data, self._hist.ctypes.data, 1, osd0.ctypes.data)
         if rc:
             raise RuntimeError(f"swd_osdw_decode_batch failed: {_lib.last_error()}")
-        self._last = dict(status=int(st[0]), iters=int(it[0]), min_pm=float(pm[0]))
+        self._last = dict(status=int(st[0]), iters=int(st[1]), min_pm=float(pm[0]))
         res = out.astype(np.int64)
         if (int(st[0]) & 0xFF) == EXIT_OSD:
             self._osdw_decoding = res
@@ -144,38 +143,37 @@ class osd_window:
         s = np.ascontiguousarray((s.astype(np.int64) & 0xFF).astype(np.uint8))
         B = s.shape[0]
         out = np.zeros((B, self.n), dtype=np.uint8)
-        st, it = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        st = np.zeros((B, _lib.STAT_WORDS), np.int32)
         pm = np.zeros(B, np.float64)
         hist = np.zeros((B, 4, self.n), np.float64) if return_history else None
         osd0 = np.zeros((B, self.n), np.uint8) if return_osd0 else None
         rc = _lib.lib().swd_osdw_decode_batch(self._h, B, s.ctypes.data, out.ctypes.data, st.ctypes.data,
-                                              it.ctypes.data, pm.ctypes.data,
-                                              hist.ctypes.data if hist is not None else None, 0,
+                                              pm.ctypes.data, hist.ctypes.data if hist is not None else None, 0,
                                               osd0.ctypes.data if osd0 is not None else None)
         if rc:
             raise RuntimeError(f"swd_osdw_decode_batch failed: {_lib.last_error()}")
-        self.last_status, self.last_iterations, self.last_min_pm = st, it, pm
+        self.last_stats = st
+        self.last_status, self.last_iterations, self.last_min_pm = st[:, 0].copy(), st[:, 1].copy(), pm
         self.last_history, self.last_osd0 = hist, osd0
         return out
 
-    def decode_batch_device(self, synd, out=None, status=None, iters=None, min_pm=None, stream=None):
+    def decode_batch_device(self, synd, out=None, stats=None, min_pm=None, stream=None):
         """Device-resident batch: ``synd`` is a torch uint8 CUDA tensor [B, m] (row stride free).
-        Asynchronous on the current (or given) torch stream.  Returns (out, status, iters, min_pm)
-        tensors."""
+        Asynchronous on the current (or given) torch stream.  Returns (out, stats[B, 8], min_pm)
+        tensors; stats[:, 0] = exit class | 0x100 * converge, stats[:, 1] = bp_iteration."""
         import torch
         B = synd.shape[0]
         dev = synd.device
         out = torch.empty((B, self.n), dtype=torch.uint8, device=dev) if out is None else out
-        status = torch.empty(B, dtype=torch.int32, device=dev) if status is None else status
-        iters = torch.empty(B, dtype=torch.int32, device=dev) if iters is None else iters
+        stats = torch.empty((B, _lib.STAT_WORDS), dtype=torch.int32, device=dev) if stats is None else stats
         min_pm = torch.empty(B, dtype=torch.float64, device=dev) if min_pm is None else min_pm
         st = torch.cuda.current_stream(dev) if stream is None else stream
         rc = _lib.lib().swd_osdw_decode_batch_dev(self._h, B, synd.data_ptr(), synd.stride(0), out.data_ptr(),
-                                                  out.stride(0), status.data_ptr(), iters.data_ptr(),
-                                                  min_pm.data_ptr(), None, 0, None, st.cuda_stream)
+                                                  out.stride(0), stats.data_ptr(), min_pm.data_ptr(), None, 0, None,
+                                                  st.cuda_stream)
         if rc:
             raise RuntimeError(f"swd_osdw_decode_batch_dev failed: {_lib.last_error()}")
-        return out, status, iters, min_pm
+        return out, stats, min_pm
 
     def set_timing(self, on=True):
         _lib.lib().swd_osdw_set_timing(self._h, 1 if on else 0)
@@ -216,3 +214,92 @@ class osd_window:
     @property
     def log_prob_ratios(self):
         return np.ascontiguousarray(self._hist.T)
+
+
+class SlidingWindowDecoder:
+    """The (W,F) sliding-window loop of the reference harness (/root/reference/osd.py:130-179) for
+    a whole batch of shots in ONE launch: a workgroup carries a shot through all its windows,
+    committing ``commit`` columns per window and folding them back into the residual syndrome.
+
+    ``plan`` is a ``windows.WindowPlan``; decoder kwargs are those of ``osd_window`` and apply to
+    every window like in osd.py:152-161."""
+
+    def __init__(self, plan, device=0, **kwargs):
+        L = _lib.lib()
+        self.plan = plan
+        self.W = len(plan.windows)
+        self.num_det, self.num_col = plan.chk.shape
+        method, order = _parse_osd_method(kwargs.get("osd_method", "osd_0"), kwargs.get("osd_order", 0))
+        new_n = kwargs.get("new_n", None)
+        p = _lib.OsdwParams(int(kwargs.get("pre_max_iter", 8)), int(kwargs.get("post_max_iter", 100)),
+                            float(kwargs.get("ms_scaling_factor", 1.0)), int(new_n) if new_n else 0, method, order)
+        self._keep = []
+        descs = (_lib.WindowDesc * self.W)()
+        for i, w in enumerate(plan.windows):
+            c = _Csr(w.mat, w.prior)
+            self._keep.append(c)
+            descs[i].graph = c.desc
+            descs[i].row0, descs[i].col0, descs[i].commit = int(w.row0), int(w.col0), int(w.commit)
+        chk = _Csr(plan.chk, plan.priors)
+        self._keep.append(chk)
+        self.device = int(device)
+        self._h = L.swd_pipeline_create(self.W, C.cast(descs, C.c_void_p), C.byref(chk.desc), C.byref(p), self.device)
+        if not self._h:
+            msg = _lib.last_error()
+            if "OSD order" in msg or "invalid" in msg:
+                raise ValueError(msg)
+            raise RuntimeError(f"swd_pipeline_create failed: {msg}")
+        i = [C.c_int32() for _ in range(5)]
+        L.swd_pipeline_info(self._h, *[C.byref(x) for x in i])
+        self.lds_bytes, self.threads = i[3].value, i[4].value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().swd_pipeline_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def decode(self, det_data):
+        """det_data [B, num_det] (host) -> total_e_hat uint8 [B, num_col]; per-window records in
+        ``last_stats`` [B, W, 8] and ``last_min_pm`` [B, W]."""
+        d = np.asarray(det_data)
+        if d.ndim != 2 or d.shape[1] != self.num_det:
+            raise ValueError(f"det_data must have shape [B, {self.num_det}]")
+        d = np.ascontiguousarray((d.astype(np.int64) & 0xFF).astype(np.uint8))
+        B = d.shape[0]
+        total = np.zeros((B, self.num_col), np.uint8)
+        st = np.zeros((B, self.W, _lib.STAT_WORDS), np.int32)
+        pm = np.zeros((B, self.W), np.float64)
+        rc = _lib.lib().swd_pipeline_decode(self._h, B, d.ctypes.data, total.ctypes.data, st.ctypes.data, pm.ctypes.data)
+        if rc:
+            raise RuntimeError(f"swd_pipeline_decode failed: {_lib.last_error()}")
+        self.last_stats, self.last_min_pm = st, pm
+        return total
+
+    def decode_device(self, det, total=None, stats=None, min_pm=None, stream=None, want_stats=True):
+        """torch uint8 CUDA tensor [B, num_det] -> (total [B, num_col], stats [B, W, 8], min_pm [B, W]);
+        asynchronous on the current torch stream."""
+        import torch
+        B, dev = det.shape[0], det.device
+        total = torch.empty((B, self.num_col), dtype=torch.uint8, device=dev) if total is None else total
+        if want_stats:
+            stats = torch.empty((B, self.W, _lib.STAT_WORDS), dtype=torch.int32, device=dev) if stats is None else stats
+            min_pm = torch.empty((B, self.W), dtype=torch.float64, device=dev) if min_pm is None else min_pm
+        st = torch.cuda.current_stream(dev) if stream is None else stream
+        rc = _lib.lib().swd_pipeline_decode_dev(self._h, B, det.data_ptr(), det.stride(0), total.data_ptr(),
+                                                total.stride(0), stats.data_ptr() if stats is not None else None,
+                                                min_pm.data_ptr() if min_pm is not None else None, st.cuda_stream)
+        if rc:
+            raise RuntimeError(f"swd_pipeline_decode_dev failed: {_lib.last_error()}")
+        return total, stats, min_pm
+
+    def set_timing(self, on=True):
+        _lib.lib().swd_pipeline_set_timing(self._h, 1 if on else 0)
+
+    def get_timing(self):
+        ms, k = C.c_double(), C.c_int64()
+        _lib.lib().swd_pipeline_get_timing(self._h, C.byref(ms), C.byref(k))
+        return ms.value, k.value

@@ -1,0 +1,83 @@
+"""GPU parity of the whole sliding-window pipeline (one launch for all shots and windows) against
+the reference's own sliding run recorded in tests/golden (osd.py:130-179 semantics)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from tests import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def load_plan(f, nwin):
+    from slidingwindowdecoder_amd.windows import Window, WindowPlan
+    chk, priors = fx.graph(f, "chk_")
+    wins = []
+    for wi in range(nwin):
+        mat, pr = fx.graph(f, f"win{wi}_")
+        r0, r1, c0, ncg, commit, last = (int(x) for x in f[f"win{wi}_meta"])
+        wins.append(Window(r0, r1, c0, ncg, commit, mat, pr, bool(last)))
+    obs = fx.graph(f, "obs_")[0] if "obs_indptr" in f else sp.csr_matrix((0, chk.shape[1]), dtype=np.uint8)
+    return WindowPlan(chk, obs, priors, np.arange(chk.shape[1]), [tuple(a) for a in f["anchors"]], wins,
+                      float(f["noisy_prior"]), 0)
+
+
+def test_bb144_pipeline_matches_reference_run():
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "osd0_params")
+    shots = int(f["num_shots"])
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    dec = SlidingWindowDecoder(plan, **kw)
+    total = dec.decode(det)
+    want = fx.unpack(f["osd0_total"], plan.chk.shape[1])
+    bad = np.flatnonzero((total != want).any(axis=1))
+    assert bad.size == 0, f"{bad.size}/{shots} shots differ: {bad[:8]}"
+    # every window decode agrees with the recorded one (iterations, converge, min_pm)
+    for wi in range(11):
+        tr = fx.Trace(f, f"osd0_win{wi}_", *plan.windows[wi].mat.shape)
+        assert np.array_equal(dec.last_stats[:, wi, 1], tr.bp_iteration), f"window {wi}: bp_iteration"
+        assert np.array_equal((dec.last_stats[:, wi, 0] & 0x100) != 0, tr.converge != 0), f"window {wi}: converge"
+        assert np.array_equal(dec.last_min_pm[:, wi], tr.min_pm), f"window {wi}: min_pm"
+    # logical-error accounting of osd.py:184-191 on the same shots
+    from slidingwindowdecoder_amd.windows import logical_error_stats
+    obs = fx.unpack(f["obs_data"], 12)
+    flagged, logical = logical_error_stats(plan, det, obs, total)
+    assert not flagged.any()
+    assert np.array_equal(logical.astype(np.uint8), f["osd0_logical"])
+
+
+def test_bb144_pipeline_device_tensors_and_stats():
+    import torch
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    dec = SlidingWindowDecoder(plan, **fx.params(f, "osd0_params"))
+    d = torch.from_numpy(np.ascontiguousarray(det)).cuda()
+    total, stats, pm = dec.decode_device(d)
+    torch.cuda.synchronize()
+    assert np.array_equal(total.cpu().numpy(), fx.unpack(f["osd0_total"], plan.chk.shape[1]))
+    st = stats.cpu().numpy()
+    cls = st[..., 0] & 0xFF
+    assert (st[..., 1] == st[..., 2] + st[..., 3]).all()
+    post = cls >= 1
+    # shortened graphs keep at most new_n = 432 live variable nodes
+    assert (st[..., 4][post] <= 432).all() and (st[..., 6][post] < 5976).all()
+    assert (st[..., 7][cls == 2] > 0).all() and (st[..., 7][cls != 2] == 0).all()
+
+
+def test_bb288_pipeline_vs_oracle_host_loop():
+    """[[288,12,18]] (4,1): device pipeline against the oracle driven through the host-side window
+    loop (same commit rule), OSD order 0."""
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    from slidingwindowdecoder_amd.windows import sliding_window_decode_host
+    f = fx.load("bb288_circuit_p005_w4f1.npz")
+    plan = load_plan(f, 4)
+    kw = dict(fx.params(f, "osd10_params"), osd_order=0)
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    total = SlidingWindowDecoder(plan, **kw).decode(det)
+    want, _ = sliding_window_decode_host(plan, det, lambda w: O.osd_window(w.mat, channel_probs=w.prior, **kw))
+    assert np.array_equal(total, want)
