@@ -122,14 +122,19 @@ swd_pipeline *swd_pipeline_create(int32_t num_windows, const swd_window_desc *wi
 void swd_pipeline_destroy(swd_pipeline *pl);
 int swd_pipeline_info(const swd_pipeline *pl, int32_t *num_windows, int32_t *num_det,
                       int32_t *num_col, int32_t *lds_bytes, int32_t *threads);
-/* det [B*num_det] in; total [B*num_col] out (total_e_hat); stats [B*W*SWD_STAT_WORDS] and
- * min_pm [B*W] nullable.  Host pointers. */
+/* optional: observables matrix obs [num_obs x num_col] (CSR, num_obs <= 32) for the on-device
+ * logical accounting of osd.py:184-187 */
+int swd_pipeline_set_observables(swd_pipeline *pl, const swd_graph_desc *obs);
+/* det [B*num_det] in; total [B*num_col] out (total_e_hat); stats [B*W*SWD_STAT_WORDS], min_pm
+ * [B*W] and shot_result [B*2] nullable.  shot_result[2b] = bit mask of the observables the
+ * committed faults flip (obs @ total_e_hat, needs swd_pipeline_set_observables), shot_result[2b+1]
+ * = 1 if the residual syndrome det ^ chk @ total_e_hat is non-zero ("flagged").  Host pointers. */
 int swd_pipeline_decode(swd_pipeline *pl, int32_t B, const uint8_t *det, uint8_t *total,
-                        int32_t *stats, double *min_pm);
+                        int32_t *stats, double *min_pm, int32_t *shot_result);
 /* device pointers, asynchronous on `stream` */
 int swd_pipeline_decode_dev(swd_pipeline *pl, int32_t B, const uint8_t *det, int64_t det_stride,
                             uint8_t *total, int64_t total_stride, int32_t *stats, double *min_pm,
-                            void *stream);
+                            int32_t *shot_result, void *stream);
 int swd_pipeline_set_timing(swd_pipeline *pl, int32_t on);
 int swd_pipeline_get_timing(swd_pipeline *pl, double *total_ms, int64_t *launches);
 

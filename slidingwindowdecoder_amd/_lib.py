@@ -46,8 +46,9 @@ SYMBOLS = [
     ("swd_pipeline_create", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
     ("swd_pipeline_destroy", None, [_vp]),
     ("swd_pipeline_info", C.c_int, [_vp] + [C.POINTER(_i32)] * 5),
-    ("swd_pipeline_decode", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
-    ("swd_pipeline_decode_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    ("swd_pipeline_set_observables", C.c_int, [_vp, C.POINTER(GraphDesc)]),
+    ("swd_pipeline_decode", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_decode_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     ("swd_pipeline_set_timing", C.c_int, [_vp, _i32]),
     ("swd_pipeline_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
 ]

@@ -53,7 +53,8 @@ struct Plan {
     swd_osdw_params p{};
     int device = 0, nt = 256;
     int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
-    DevBuf d_wins, d_chk;
+    DevBuf d_wins, d_chk, d_obs;
+    DevBuf shot;
     const uint32_t *d_colptr = nullptr;
     const uint16_t *d_rows = nullptr;
     // host-pointer staging
@@ -103,7 +104,7 @@ struct Plan {
         for (auto &w : wins) { nmax = std::max(nmax, w.g->n); lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m); }
         if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
         if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
-        off_det = align_up(lmax, 16);
+        off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
         lds_total = off_det + align_up(num_det, 16);
         if (lds_total > 160 * 1024) {
             set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
@@ -350,9 +351,26 @@ extern "C" int swd_pipeline_get_timing(swd_pipeline *h, double *total_ms, int64_
     return swd_osdw_get_timing((swd_osdw *)h, total_ms, launches);
 }
 
+extern "C" int swd_pipeline_set_observables(swd_pipeline *h, const swd_graph_desc *obs) {
+    Plan *d = (Plan *)h;
+    if (!d || !obs) { set_error("null argument"); return -1; }
+    if (obs->m > 32) { set_error("at most 32 observables are supported (got %d)", obs->m); return -1; }
+    if (obs->n != d->num_col) { set_error("observable matrix has %d columns, expected %d", obs->n, d->num_col); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    std::vector<uint32_t> mask(d->num_col, 0);
+    for (int k = 0; k < obs->m; ++k)
+        for (int e = obs->row_ptr[k]; e < obs->row_ptr[k + 1]; ++e) {
+            if (obs->col_idx[e] < 0 || obs->col_idx[e] >= obs->n) { set_error("observable matrix: column out of range"); return -1; }
+            mask[obs->col_idx[e]] ^= 1u << k;
+        }
+    if (d->d_obs.reserve(mask.size() * 4)) return -1;
+    SWD_HIP(hipMemcpy(d->d_obs.p, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t *det, int64_t det_stride,
                                        uint8_t *total, int64_t total_stride, int32_t *stats, double *min_pm,
-                                       void *stream) {
+                                       int32_t *shot_result, void *stream) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null pipeline"); return -1; }
     if (B <= 0) return 0;
@@ -367,11 +385,13 @@ extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t
     a.chk_colptr = d->d_colptr; a.chk_rows = d->d_rows;
     a.win_out = nullptr; a.stats = stats; a.min_pm = min_pm;
     a.hist = d->hist.as<double>(); a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
+    a.obs_mask = d->d_obs.p ? d->d_obs.as<uint32_t>() : nullptr;
+    a.shot_result = shot_result;
     return launch(d, a, (hipStream_t)stream);
 }
 
 extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats,
-                                   double *min_pm) {
+                                   double *min_pm, int32_t *shot_result) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null pipeline"); return -1; }
     if (B <= 0) return 0;
@@ -379,14 +399,15 @@ extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *de
     SWD_HIP(hipSetDevice(d->device));
     const size_t W = d->wins.size();
     if (d->synd.reserve((size_t)B * d->num_det) || d->total.reserve((size_t)B * d->num_col) ||
-        d->stats.reserve(B * W * SWD_STAT_WORDS * 4) || d->pm.reserve(B * W * 8))
+        d->stats.reserve(B * W * SWD_STAT_WORDS * 4) || d->pm.reserve(B * W * 8) || d->shot.reserve((size_t)B * 8))
         return -1;
     SWD_HIP(hipMemcpy(d->synd.p, det, (size_t)B * d->num_det, hipMemcpyHostToDevice));
     int rc = swd_pipeline_decode_dev(h, B, d->synd.as<uint8_t>(), 0, d->total.as<uint8_t>(), 0, d->stats.as<int32_t>(),
-                                     d->pm.as<double>(), nullptr);
+                                     d->pm.as<double>(), d->shot.as<int32_t>(), nullptr);
     if (rc) return rc;
     SWD_HIP(hipDeviceSynchronize());
     SWD_HIP(hipMemcpy(total, d->total.p, (size_t)B * d->num_col, hipMemcpyDeviceToHost));
+    if (shot_result) SWD_HIP(hipMemcpy(shot_result, d->shot.p, (size_t)B * 8, hipMemcpyDeviceToHost));
     if (stats) SWD_HIP(hipMemcpy(stats, d->stats.p, B * W * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
     if (min_pm) SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * W * 8, hipMemcpyDeviceToHost));
     return 0;

@@ -63,6 +63,8 @@ struct SwdPipeArgs {
     double *hist;             // [B][4][nmax]
     int64_t hist_stride;      // doubles per shot
     uint8_t *osd0;            // nullable [B][n] (single-window use)
+    const uint32_t *obs_mask; // nullable [num_col]: bit k set if fault flips observable k (obs matrix)
+    int32_t *shot_result;     // nullable [B][2]: predicted observable flips, residual syndrome != 0
 };
 
 namespace swd {
@@ -618,6 +620,8 @@ __global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
     double *hist_b = a.hist + (int64_t)b * a.hist_stride;
     Lds s;
     s.fpar = 0;
+    uint32_t *acc = (uint32_t *)(smem + a.off_det) - 4; // 16 bytes below sdet are reserved by the host
+    if (tid == 0) { acc[0] = 0; acc[1] = 0; }
     __syncthreads();
     for (int wi = 0; wi < a.W; ++wi) {
         const SwdWindowDev &w = a.wins[wi];
@@ -635,6 +639,7 @@ __global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
                 tot_b[i] = hv;
                 if (hv) {
                     const int c = w.col0 + i;
+                    if (a.obs_mask) { const uint32_t om = a.obs_mask[c]; if (om) atomicXor(&acc[0], om); }
                     for (uint32_t e = a.chk_colptr[c]; e < a.chk_colptr[c + 1]; ++e) {
                         const int r = a.chk_rows[e];
                         atomicXor(&sdet_w[r >> 2], 1u << ((r & 3) * 8));
@@ -656,6 +661,14 @@ __global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
             if (a.min_pm) a.min_pm[(int64_t)b * a.W + wi] = R.pm;
         }
         __syncthreads();
+    }
+    if (a.shot_result) {
+        // osd.py:184-187: flagged = residual syndrome of the whole run non-zero; observable flips
+        // predicted by the committed faults (compared with the sampled ones by the caller)
+        bool nz = false;
+        for (int r = tid; r < a.num_det; r += NT) nz |= (sdet[r] != 0);
+        const bool any = block_any<NT>(nz, s);
+        if (tid == 0) { a.shot_result[2 * b] = (int32_t)acc[0]; a.shot_result[2 * b + 1] = any ? 1 : 0; }
     }
 }
 

@@ -252,6 +252,14 @@ class SlidingWindowDecoder:
         i = [C.c_int32() for _ in range(5)]
         L.swd_pipeline_info(self._h, *[C.byref(x) for x in i])
         self.lds_bytes, self.threads = i[3].value, i[4].value
+        self.num_obs = int(plan.obs.shape[0]) if plan.obs is not None else 0
+        if 0 < self.num_obs <= 32:
+            a = sp.csr_matrix(plan.obs)
+            a.sort_indices()
+            rp, ci = np.ascontiguousarray(a.indptr, np.int32), np.ascontiguousarray(a.indices, np.int32)
+            od = _lib.GraphDesc(a.shape[0], a.shape[1], int(rp[-1]), rp.ctypes.data, ci.ctypes.data, None)
+            if L.swd_pipeline_set_observables(self._h, C.byref(od)):
+                raise RuntimeError(f"swd_pipeline_set_observables failed: {_lib.last_error()}")
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -273,15 +281,20 @@ class SlidingWindowDecoder:
         total = np.zeros((B, self.num_col), np.uint8)
         st = np.zeros((B, self.W, _lib.STAT_WORDS), np.int32)
         pm = np.zeros((B, self.W), np.float64)
-        rc = _lib.lib().swd_pipeline_decode(self._h, B, d.ctypes.data, total.ctypes.data, st.ctypes.data, pm.ctypes.data)
+        shot = np.zeros((B, 2), np.int32)
+        rc = _lib.lib().swd_pipeline_decode(self._h, B, d.ctypes.data, total.ctypes.data, st.ctypes.data,
+                                            pm.ctypes.data, shot.ctypes.data)
         if rc:
             raise RuntimeError(f"swd_pipeline_decode failed: {_lib.last_error()}")
         self.last_stats, self.last_min_pm = st, pm
+        self.last_obs_flips, self.last_flagged = shot[:, 0].astype(np.uint32), shot[:, 1].astype(bool)
         return total
 
-    def decode_device(self, det, total=None, stats=None, min_pm=None, stream=None, want_stats=True):
+    def decode_device(self, det, total=None, stats=None, min_pm=None, shot_result=None, stream=None,
+                      want_stats=True):
         """torch uint8 CUDA tensor [B, num_det] -> (total [B, num_col], stats [B, W, 8], min_pm [B, W]);
-        asynchronous on the current torch stream."""
+        asynchronous on the current torch stream.  ``shot_result`` (int32 [B, 2] CUDA tensor, optional)
+        receives the predicted observable-flip mask and the flagged bit of every shot."""
         import torch
         B, dev = det.shape[0], det.device
         total = torch.empty((B, self.num_col), dtype=torch.uint8, device=dev) if total is None else total
@@ -291,7 +304,9 @@ class SlidingWindowDecoder:
         st = torch.cuda.current_stream(dev) if stream is None else stream
         rc = _lib.lib().swd_pipeline_decode_dev(self._h, B, det.data_ptr(), det.stride(0), total.data_ptr(),
                                                 total.stride(0), stats.data_ptr() if stats is not None else None,
-                                                min_pm.data_ptr() if min_pm is not None else None, st.cuda_stream)
+                                                min_pm.data_ptr() if min_pm is not None else None,
+                                                shot_result.data_ptr() if shot_result is not None else None,
+                                                st.cuda_stream)
         if rc:
             raise RuntimeError(f"swd_pipeline_decode_dev failed: {_lib.last_error()}")
         return total, stats, min_pm

@@ -46,6 +46,13 @@ def test_bb144_pipeline_matches_reference_run():
     flagged, logical = logical_error_stats(plan, det, obs, total)
     assert not flagged.any()
     assert np.array_equal(logical.astype(np.uint8), f["osd0_logical"])
+    # the same accounting done on the device: predicted observable flips + flagged bit per shot
+    pred = (sp.csr_matrix(total) @ plan.obs.T.astype(np.int32)).toarray() % 2
+    pred_mask = (pred.astype(np.uint32) << np.arange(12, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(dec.last_obs_flips, pred_mask)
+    assert not dec.last_flagged.any()
+    obs_mask = (obs.astype(np.uint32) << np.arange(12, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal((dec.last_obs_flips != obs_mask) | dec.last_flagged, logical)
 
 
 def test_bb144_pipeline_device_tensors_and_stats():
