@@ -17,13 +17,20 @@ namespace swd {
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-static int make_layout(const Graph &g, int new_n, SwdLdsLayout &L) {
+static int make_layout(const Graph &g, int new_n, int nt, SwdLdsLayout &L) {
     const int m = g.m, n = g.n, E = g.E, wm = g.wm;
     const int npad = std::max(next_pow2(n), 2);
     L.npad = npad;
     L.off_idx = npad * 8;
     L.off_aux = align_up(npad * 10, 16);
-    const int osd_bytes = L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16;
+    int osd_bytes = align_up(L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16, 16);
+    // higher-order OSD arrays: over the dead sort keys when they fit there, else after the OSD-0 arrays
+    L.cs_par = std::min(nt, 256);
+    const int kset = std::max(new_n - g.rank, 0);
+    const int cs_bytes = align_up(n * 2 + kset * 2 + g.rank * 4 + 64 + 8, 8) + g.rank * 8 +
+                         std::max(wm * L.cs_par, 64 + wm) * 8;
+    if (cs_bytes <= npad * 8) L.off_cs = 0;
+    else { L.off_cs = osd_bytes; osd_bytes += align_up(cs_bytes, 16); }
     const int rare_bytes = L.off_aux + n * 2;
     int scratch = std::max(std::max(E * 8, osd_bytes), std::max(rare_bytes, n * 2));
     scratch = align_up(scratch, 16);
@@ -92,16 +99,20 @@ struct Plan {
             return -1;
         }
         w.row0 = row0; w.col0 = col0; w.commit = commit;
-        make_layout(*w.g, w.new_n, w.L);
         wins.push_back(w);
         return 0;
     }
 
     int finalize(const swd_graph_desc *chk) {
-        if (p.osd_order > 0) { set_error("osd_order > 0 is not available in this build of the device OSD"); return -1; }
+        if (p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
         nmax = 0;
         int lmax = 0, mmax = 0;
-        for (auto &w : wins) { nmax = std::max(nmax, w.g->n); lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m); }
+        for (auto &w : wins) nmax = std::max(nmax, w.g->n);
+        nt = nmax <= 192 ? 64 : nmax <= 768 ? 128 : nmax <= 3072 ? 256 : 1024;
+        for (auto &w : wins) {
+            make_layout(*w.g, w.new_n, nt, w.L);
+            lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
+        }
         if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
         if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
         off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
@@ -110,7 +121,6 @@ struct Plan {
             set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
             return -1;
         }
-        nt = nmax <= 192 ? 64 : nmax <= 768 ? 128 : nmax <= 3072 ? 256 : 1024;
         std::vector<SwdWindowDev> hw(wins.size());
         for (size_t i = 0; i < wins.size(); ++i) {
             hw[i].g = wins[i].g->d;

@@ -21,6 +21,8 @@ struct SwdLdsLayout {
     int32_t npad;      // power of two >= n (bitonic sort size)
     int32_t off_idx;   // inside scratch: u16 idx[npad] after u64 key[npad]
     int32_t off_aux;   // inside scratch: first byte after the sort arrays
+    int32_t off_cs;    // inside scratch: arrays of the higher-order OSD sweep
+    int32_t cs_par;    // threads that evaluate OSD candidates concurrently (<= 256)
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -359,7 +361,8 @@ __device__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
 // solve the same invertible pivot-row x pivot-column system with zeros elsewhere.
 // T is stored column-major: Tc[j*wm + w] = word w of column j (bit r = T[r][j]).
 __device__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tc,
-                         uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b) {
+                         uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b,
+                         int *npiv_out) {
     const int lane = threadIdx.x & 63;
     const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
     // this lane's words of the pivoted-row mask: w = lane, lane + 64, ... (wm <= 16 -> one word)
@@ -410,7 +413,199 @@ __device__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, ui
         s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
     }
     wave_fence();
+    *npiv_out = npiv;
     return rowadds;
+}
+
+// Higher-order OSD sweep (osd_window.pyx:242-284): after OSD-0, try the osd_cs candidates (every
+// weight-1 pattern on the k = new_n - rank non-pivot columns of the first new_n sorted columns, then
+// the weight-2 patterns on the first `order` of them, osd_cs_setup :134-155) or the 2^order osd_e
+// patterns (osd_e_setup :128-132); a candidate x gives y = pivot solution of (s ^ Ht x) with x on its
+// own columns, scored by pm = sum of llr over y in ascending column order; the first strictly smaller
+// pm wins (:276).  With T the accumulated row transform of osd0_wave, the pivot solution of s ^ Ht x
+// is y0 ^ XOR_c T*H[:,c]: no second elimination.  One candidate per thread; the ordered sum is a
+// merge of the pivots sorted by column with the candidate's own columns.
+struct CsBest { double pm; int l; };
+
+__device__ __forceinline__ bool cs_better(double pa, int la, double pb, int lb) {
+    return (pa < pb) || (pa == pb && la < lb);
+}
+
+template <int NT>
+__device__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+                            const uint16_t *idx, const uint64_t *Tc, const uint64_t *y0,
+                            const uint16_t *piv_col, const uint16_t *piv_row, int npiv, double pm0) {
+    const int tid = threadIdx.x, n = g.n, wm = g.wm, kset = g.new_n - g.rank, CP = L.cs_par;
+    const int order = P.osd_order;
+    char *cs = s.scratch + L.off_cs;
+    uint16_t *prow_of = (uint16_t *)cs;          // [n]
+    uint16_t *Ht = prow_of + n;                  // [kset]
+    uint16_t *pcs = Ht + kset;                   // [rank] pivot columns ascending
+    uint16_t *prs = pcs + g.rank;                // [rank] their pivot rows
+    uint16_t *hts_col = prs + g.rank;            // [16]  osd_e: first `order` Ht columns sorted by column
+    uint16_t *hts_bit = hts_col + 16;            // [16]
+    double *pllr = (double *)(((uintptr_t)(hts_bit + 16) + 7) & ~(uintptr_t)7); // [rank]
+    uint64_t *ybuf = (uint64_t *)(pllr + g.rank); // [wm * CP]
+
+    for (int v = tid; v < n; v += NT) prow_of[v] = 0xFFFF;
+    __syncthreads();
+    for (int i = tid; i < npiv; i += NT) prow_of[piv_col[i]] = piv_row[i];
+    __syncthreads();
+    {   // Ht_cols: non-pivot columns among the first new_n sorted positions, in sorted order
+        const int ch = (g.new_n + NT - 1) / NT;
+        const int p0 = tid * ch, p1 = min(g.new_n, p0 + ch);
+        int cnt = 0;
+        for (int p = p0; p < p1; ++p) cnt += (prow_of[idx[p]] == 0xFFFF) ? 1 : 0;
+        int tot;
+        int pos = block_exscan<NT>(cnt, s, tot);
+        for (int p = p0; p < p1; ++p)
+            if (prow_of[idx[p]] == 0xFFFF) { if (pos < kset) Ht[pos] = idx[p]; ++pos; }
+    }
+    {   // pivots sorted by column
+        const int ch = (n + NT - 1) / NT;
+        const int v0 = tid * ch, v1 = min(n, v0 + ch);
+        int cnt = 0;
+        for (int v = v0; v < v1; ++v) cnt += (prow_of[v] != 0xFFFF) ? 1 : 0;
+        int tot;
+        int pos = block_exscan<NT>(cnt, s, tot);
+        for (int v = v0; v < v1; ++v)
+            if (prow_of[v] != 0xFFFF) { pcs[pos] = (uint16_t)v; prs[pos] = prow_of[v]; pllr[pos] = g.llr[v]; ++pos; }
+    }
+    __syncthreads();
+    const bool exhaustive = (P.osd_method == 1);
+    if (exhaustive && tid == 0) { // first `order` Ht columns by ascending column (insertion sort, <= 15)
+        for (int i = 0; i < order; ++i) {
+            const uint16_t c = Ht[i];
+            int j = i;
+            while (j > 0 && hts_col[j - 1] > c) { hts_col[j] = hts_col[j - 1]; hts_bit[j] = hts_bit[j - 1]; --j; }
+            hts_col[j] = c; hts_bit[j] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const long ncand = exhaustive ? (1L << order) : (long)kset + (long)order * (order - 1) / 2;
+    double best_pm = pm0;
+    int best_l = -1;
+    const int INF = 0x7fffffff;
+    for (long base = 0; base < ncand; base += CP) {
+        const long l = base + tid;
+        if (tid < CP && l < ncand) {
+            int c1 = INF, c2 = INF;
+            if (!exhaustive) {
+                if (l < kset) c1 = Ht[l];
+                else {
+                    int rem = (int)(l - kset), i = 0;
+                    while (rem >= order - 1 - i) { rem -= order - 1 - i; ++i; }
+                    c1 = Ht[i]; c2 = Ht[i + 1 + rem];
+                }
+            }
+            for (int w = 0; w < wm; ++w) {
+                uint64_t yw = y0[w];
+                if (!exhaustive) {
+                    const int d1 = g.col_deg[c1];
+                    for (int k = 0; k < d1; ++k) yw ^= Tc[(int)g.vn_row[k * n + c1] * wm + w];
+                    if (c2 != INF) {
+                        const int d2 = g.col_deg[c2];
+                        for (int k = 0; k < d2; ++k) yw ^= Tc[(int)g.vn_row[k * n + c2] * wm + w];
+                    }
+                } else {
+                    for (int i = 0; i < order; ++i)
+                        if ((l >> i) & 1) {
+                            const int c = Ht[i], dc = g.col_deg[c];
+                            for (int k = 0; k < dc; ++k) yw ^= Tc[(int)g.vn_row[k * n + c] * wm + w];
+                        }
+                }
+                ybuf[w * CP + tid] = yw;
+            }
+            double pm = 0.0;
+            int cA = min(c1, c2), cB = max(c1, c2), q = 0;
+            for (int i = 0; i < npiv; ++i) {
+                const int pc = pcs[i];
+                if (!exhaustive) {
+                    if (cA < pc) { pm += g.llr[cA]; cA = cB; cB = INF; }
+                    if (cA < pc) { pm += g.llr[cA]; cA = cB; cB = INF; }
+                } else {
+                    while (q < order && (int)hts_col[q] < pc) {
+                        if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
+                        ++q;
+                    }
+                }
+                const int r = prs[i];
+                if ((ybuf[(r >> 6) * CP + tid] >> (r & 63)) & 1ull) pm += pllr[i];
+            }
+            if (!exhaustive) {
+                if (cA != INF) { pm += g.llr[cA]; cA = cB; }
+                if (cA != INF) pm += g.llr[cA];
+            } else {
+                while (q < order) {
+                    if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
+                    ++q;
+                }
+            }
+            if (pm < best_pm) { best_pm = pm; best_l = (int)l; }
+        }
+    }
+    // block arg-min; ties go to the earliest candidate, OSD-0 itself (l = -1) first
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const double opm = __shfl_xor(best_pm, d, 64);
+        const int ol = __shfl_xor(best_l, d, 64);
+        if (cs_better(opm, ol, best_pm, best_l)) { best_pm = opm; best_l = ol; }
+    }
+    double *wpm = (double *)ybuf; // candidates are done with ybuf
+    int *wl = (int *)(wpm + 16);
+    __syncthreads();
+    if ((tid & 63) == 0) { wpm[tid >> 6] = best_pm; wl[tid >> 6] = best_l; }
+    __syncthreads();
+    for (int w = 0; w < NT / 64; ++w)
+        if (cs_better(wpm[w], wl[w], best_pm, best_l)) { best_pm = wpm[w]; best_l = wl[w]; }
+    __syncthreads();
+    if (best_l < 0) return pm0;
+    // rebuild the winner into s.hard
+    const long l = best_l;
+    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+    for (int w = tid; w < wm; w += NT) {
+        uint64_t yw = y0[w];
+        if (!exhaustive) {
+            int c1, c2 = INF;
+            if (l < kset) c1 = Ht[l];
+            else {
+                int rem = (int)(l - kset), i = 0;
+                while (rem >= order - 1 - i) { rem -= order - 1 - i; ++i; }
+                c1 = Ht[i]; c2 = Ht[i + 1 + rem];
+            }
+            for (int k = 0; k < g.col_deg[c1]; ++k) yw ^= Tc[(int)g.vn_row[k * n + c1] * wm + w];
+            if (c2 != INF)
+                for (int k = 0; k < g.col_deg[c2]; ++k) yw ^= Tc[(int)g.vn_row[k * n + c2] * wm + w];
+        } else {
+            for (int i = 0; i < order; ++i)
+                if ((l >> i) & 1) {
+                    const int c = Ht[i];
+                    for (int k = 0; k < g.col_deg[c]; ++k) yw ^= Tc[(int)g.vn_row[k * n + c] * wm + w];
+                }
+        }
+        ybuf[32 + w] = yw; // wpm/wl occupy the first 24 words
+    }
+    __syncthreads();
+    for (int i = tid; i < npiv; i += NT) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((ybuf[32 + (r >> 6)] >> (r & 63)) & 1ull);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (!exhaustive) {
+            if (l < kset) s.hard[Ht[l]] = 1;
+            else {
+                int rem = (int)(l - kset), i = 0;
+                while (rem >= order - 1 - i) { rem -= order - 1 - i; ++i; }
+                s.hard[Ht[i]] = 1; s.hard[Ht[i + 1 + rem]] = 1;
+            }
+        } else {
+            for (int i = 0; i < order; ++i)
+                if ((l >> i) & 1) s.hard[Ht[i]] = 1;
+        }
+    }
+    __syncthreads();
+    return best_pm;
 }
 
 struct WinResult {
@@ -593,14 +788,17 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
     for (int v = tid; v < n; v += NT) s.hard[v] = 0;
     __syncthreads();
     if (tid < 64) {
-        const int ra = osd0_wave(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd);
-        if (tid == 0) s.scal[2] = ra;
+        int npiv;
+        const int ra = osd0_wave(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, &npiv);
+        if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
     }
     __syncthreads();
     R.osd_rowadds = s.scal[2];
+    const int npiv = s.scal[3];
     if (osd0_b)
         for (int v = tid; v < n; v += NT) osd0_b[v] = s.hard[v];
     R.pm = ordered_pm<NT>(g, s, list1);
+    if (P.osd_order > 0) R.pm = osd_sweep<NT>(g, L, P, s, idx, Tc, Sbuf, piv_col, piv_row, npiv, R.pm);
     R.exit_class = SWD_EXIT_OSD;
 }
 

@@ -30,7 +30,7 @@ def check_batch_vs_trace(dec, tr, kw_pre):
     assert np.array_equal(dec.last_min_pm, tr.min_pm)
 
 
-@pytest.mark.parametrize("tag", ["c1", "osd0"])
+@pytest.mark.parametrize("tag", ["c1", "osd0", "cs10", "e6", "short"])
 def test_bb72_sequential_decode_matches_reference(tag):
     """decode() one at a time on one object: also reproduces the reference object's stateful LLR
     history (hash after every decode)."""
@@ -49,7 +49,7 @@ def test_bb72_sequential_decode_matches_reference(tag):
             assert (dec.osd0_decoding == tr.osd0[k]).all()
 
 
-@pytest.mark.parametrize("tag", ["c1", "osd0"])
+@pytest.mark.parametrize("tag", ["c1", "osd0", "cs10", "e6"])
 def test_bb72_batch_matches_reference(tag):
     f = fx.load("bb72_capacity.npz")
     mat, priors = fx.graph(f, tag + "_")
@@ -58,16 +58,17 @@ def test_bb72_batch_matches_reference(tag):
     check_batch_vs_trace(dec, fx.Trace(f, tag + "_", *mat.shape), kw)
 
 
-def test_bb144_sliding_trace_batch():
-    """Config 2 shape: every window of the recorded reference sliding-window run (OSD order 0),
-    192 shots per window in one launch."""
+@pytest.mark.parametrize("tag", ["osd0", "osd10"])
+def test_bb144_sliding_trace_batch(tag):
+    """Config 2 shape: every window of the recorded reference sliding-window run (OSD-CS order 0 and
+    the notebooks' default order 10), 192 shots per window in one launch."""
     f = fx.load("bb144_circuit_p003_w3f1.npz")
-    kw = fx.params(f, "osd0_params")
+    kw = fx.params(f, tag + "_params")
     classes = np.zeros(6, int)
     for wi in range(11):
         mat, priors = fx.graph(f, f"win{wi}_")
         dec = _dev_cls()(mat, channel_probs=priors, **kw)
-        tr = fx.Trace(f, f"osd0_win{wi}_", *mat.shape)
+        tr = fx.Trace(f, f"{tag}_win{wi}_", *mat.shape)
         check_batch_vs_trace(dec, tr, kw)
         classes += np.bincount(dec.last_status & 0xFF, minlength=6)
     assert classes[0] > 500 and classes[1] > 300 and classes[2] > 50, classes
@@ -88,18 +89,29 @@ def test_bb144_history_values():
     assert np.array_equal(got, want), f"max |diff| {np.abs(got - want).max()}"
 
 
-def test_bb144_rank_deficient_inconsistent():
+@pytest.mark.parametrize("order", [0, 10])
+def test_bb144_rank_deficient_inconsistent(order):
     f = fx.load("bb144_circuit_p003_w3f1.npz")
     mat, priors = fx.graph(f, "win10_")
-    kw = dict(fx.params(f, "incons_params"), osd_order=0)
+    kw = dict(fx.params(f, "incons_params"), osd_order=order)
     dec = _dev_cls()(mat, channel_probs=priors, **kw)
     assert dec.rank == 210
-    check_batch_vs_trace(dec, fx.Trace(f, "incons0_", *mat.shape), kw)
+    check_batch_vs_trace(dec, fx.Trace(f, f"incons{order}_", *mat.shape), kw)
+
+
+def test_bb288_windows_match_reference():
+    """Config 4 shape ([[288,12,18]] (4,1), 576 x 4896 windows, 16992 edges), OSD-CS order 10: the
+    recorded reference run."""
+    f = fx.load("bb288_circuit_p005_w4f1.npz")
+    kw = fx.params(f, "osd10_params")
+    for wi in range(4):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        dec = _dev_cls()(mat, channel_probs=priors, **kw)
+        check_batch_vs_trace(dec, fx.Trace(f, f"osd10_win{wi}_", *mat.shape), kw)
 
 
 def test_bb288_windows_vs_oracle():
-    """Config 4 shape ([[288,12,18]] (4,1), 576 x 4896 windows, 16992 edges): OSD order 0 against
-    the oracle on the recorded syndromes."""
+    """Same windows, OSD order 0, against the oracle on the recorded syndromes."""
     f = fx.load("bb288_circuit_p005_w4f1.npz")
     kw = dict(fx.params(f, "osd10_params"), osd_order=0)
     O = _oracle()
@@ -120,8 +132,8 @@ def test_random_small_codes_vs_oracle():
     """Ragged random matrices (uneven row/column weights, new_n < n, scaling factor != 1)."""
     rng = np.random.default_rng(11)
     O = _oracle()
-    for trial in range(6):
-        m, n = int(rng.integers(8, 40)), int(rng.integers(40, 200))
+    for trial in range(9):
+        m, n = int(rng.integers(8, 21)), int(rng.integers(40, 200))
         H = (rng.random((m, n)) < 3.0 / m).astype(np.uint8)
         for c in range(n):
             if H[:, c].sum() == 0:
@@ -133,8 +145,9 @@ def test_random_small_codes_vs_oracle():
             continue
         p = rng.uniform(0.01, 0.08, size=n)
         kw = dict(channel_probs=p, pre_max_iter=int(rng.integers(1, 9)), post_max_iter=int(rng.integers(1, 40)),
-                  ms_scaling_factor=float(rng.choice([1.0, 0.9, 0.625])), osd_method="osd_0",
-                  new_n=int(rng.integers(m, n + 1)))
+                  ms_scaling_factor=float(rng.choice([1.0, 0.9, 0.625])),
+                  osd_method=["osd_0", "osd_cs", "osd_e"][trial % 3], osd_order=[0, 3, 4][trial % 3],
+                  new_n=int(rng.integers(2 * m, n + 1)))
         dec, ora = _dev_cls()(H, **kw), O.osd_window(H, **kw)
         e = (rng.random((300, n)) < p).astype(np.uint8)
         synd = (e @ H.T) % 2

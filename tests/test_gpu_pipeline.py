@@ -22,21 +22,22 @@ def load_plan(f, nwin):
                       float(f["noisy_prior"]), 0)
 
 
-def test_bb144_pipeline_matches_reference_run():
+@pytest.mark.parametrize("tag", ["osd0", "osd10"])
+def test_bb144_pipeline_matches_reference_run(tag):
     from slidingwindowdecoder_amd import SlidingWindowDecoder
     f = fx.load("bb144_circuit_p003_w3f1.npz")
     plan = load_plan(f, 11)
-    kw = fx.params(f, "osd0_params")
+    kw = fx.params(f, tag + "_params")
     shots = int(f["num_shots"])
     det = fx.unpack(f["det"], plan.chk.shape[0])
     dec = SlidingWindowDecoder(plan, **kw)
     total = dec.decode(det)
-    want = fx.unpack(f["osd0_total"], plan.chk.shape[1])
+    want = fx.unpack(f[tag + "_total"], plan.chk.shape[1])
     bad = np.flatnonzero((total != want).any(axis=1))
     assert bad.size == 0, f"{bad.size}/{shots} shots differ: {bad[:8]}"
     # every window decode agrees with the recorded one (iterations, converge, min_pm)
     for wi in range(11):
-        tr = fx.Trace(f, f"osd0_win{wi}_", *plan.windows[wi].mat.shape)
+        tr = fx.Trace(f, f"{tag}_win{wi}_", *plan.windows[wi].mat.shape)
         assert np.array_equal(dec.last_stats[:, wi, 1], tr.bp_iteration), f"window {wi}: bp_iteration"
         assert np.array_equal((dec.last_stats[:, wi, 0] & 0x100) != 0, tr.converge != 0), f"window {wi}: converge"
         assert np.array_equal(dec.last_min_pm[:, wi], tr.min_pm), f"window {wi}: min_pm"
@@ -45,7 +46,7 @@ def test_bb144_pipeline_matches_reference_run():
     obs = fx.unpack(f["obs_data"], 12)
     flagged, logical = logical_error_stats(plan, det, obs, total)
     assert not flagged.any()
-    assert np.array_equal(logical.astype(np.uint8), f["osd0_logical"])
+    assert np.array_equal(logical.astype(np.uint8), f[tag + "_logical"])
     # the same accounting done on the device: predicted observable flips + flagged bit per shot
     pred = (sp.csr_matrix(total) @ plan.obs.T.astype(np.int32)).toarray() % 2
     pred_mask = (pred.astype(np.uint32) << np.arange(12, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
