@@ -135,6 +135,10 @@ int swd_pipeline_decode(swd_pipeline *pl, int32_t B, const uint8_t *det, uint8_t
 int swd_pipeline_decode_dev(swd_pipeline *pl, int32_t B, const uint8_t *det, int64_t det_stride,
                             uint8_t *total, int64_t total_stride, int32_t *stats, double *min_pm,
                             int32_t *shot_result, void *stream);
+/* diagnostics: device-side phase timers (100 MHz ticks) of the last launch, out [B*W*8]:
+ * init, pre BP, sort, shorten+peel, post BP, OSD sort, OSD elimination, OSD sweep + epilogue */
+int swd_pipeline_set_profiling(swd_pipeline *pl, int32_t on);
+int swd_pipeline_get_profile(swd_pipeline *pl, int32_t B, int64_t *out);
 int swd_pipeline_set_timing(swd_pipeline *pl, int32_t on);
 int swd_pipeline_get_timing(swd_pipeline *pl, double *total_ms, int64_t *launches);
 

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Cycle split of the post-phase BP iteration (diagnostic build libswd_hip_bpprof.so, -DSWD_BPPROF)."""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slidingwindowdecoder_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libswd_hip_bpprof.so")
+import bench
+from slidingwindowdecoder_amd import SlidingWindowDecoder
+from slidingwindowdecoder_amd.windows import sample_dem
+shots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+plan = bench.build_problem()
+dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=0))
+det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=1)
+d = torch.from_numpy(det).cuda()
+dec.decode_device(d); torch.cuda.synchronize()
+dec.set_profiling(True)
+total, stats, pm = dec.decode_device(d); torch.cuda.synchronize()
+prof = dec.get_profile(shots).astype(np.float64)
+st = stats.cpu().numpy()
+post = st[..., 3].astype(np.float64)
+sel = post > 0
+for name, k in (("CN pass", 0), ("block_any(+barrier)", 5), ("VN pass", 6), ("end barrier", 7)):
+    print(f"{name:22s} cycles per post iteration: {prof[..., k][sel].sum() / post[sel].sum():8.0f}")
+for name, k in (("  CN setup (to loop1)", 1), ("  CN loop 1", 2), ("  wmax (sum)", 3)):
+    print(f"{name:22s} per post iteration: {prof[..., k][sel].sum() / post[sel].sum():8.1f}")
+print("post ticks(100MHz)/iter: %.1f us" % (prof[..., 4][sel].sum() / post[sel].sum() / 100.0))

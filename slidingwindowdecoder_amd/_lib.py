@@ -49,6 +49,8 @@ SYMBOLS = [
     ("swd_pipeline_set_observables", C.c_int, [_vp, C.POINTER(GraphDesc)]),
     ("swd_pipeline_decode", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("swd_pipeline_decode_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_set_profiling", C.c_int, [_vp, _i32]),
+    ("swd_pipeline_get_profile", C.c_int, [_vp, _i32, _vp]),
     ("swd_pipeline_set_timing", C.c_int, [_vp, _i32]),
     ("swd_pipeline_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
 ]

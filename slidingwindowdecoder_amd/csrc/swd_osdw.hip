@@ -32,15 +32,18 @@ static int make_layout(const Graph &g, int new_n, int nt, SwdLdsLayout &L) {
     if (cs_bytes <= npad * 8) L.off_cs = 0;
     else { L.off_cs = osd_bytes; osd_bytes += align_up(cs_bytes, 16); }
     const int rare_bytes = L.off_aux + n * 2;
-    int scratch = std::max(std::max(E * 8, osd_bytes), std::max(rare_bytes, n * 2));
+    int scratch = std::max(std::max((E + 1) * 8, osd_bytes), std::max(rare_bytes, n * 2)); // +1: sacrificial slot E
     scratch = align_up(scratch, 16);
     int o = scratch;
     L.off_livemask = o; o += m * 8;
     L.off_par = o; o += m * 4;
     L.off_lv = o; o = align_up(o + new_n * 2, 4);
     L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
+    // live-slot lists of the post phase are staged in the (then dead) scratch region
+    L.off_lslot = (g.K * m * 2 <= scratch) ? 0 : -1;
     L.off_cnval = o; o += m;
     L.off_cndeg = o; o += m;
+    L.off_cndeg0 = o; o += m;
     L.off_vnval = o; o += n;
     L.off_hard = o; o = align_up(o + n, 16);
     L.off_misc = o; o += 64 * 4;
@@ -54,11 +57,21 @@ struct WindowHost {
     SwdLdsLayout L{};
 };
 
+struct Plan;
+// Kernel variants: threads per shot, VNs per thread, column-degree bound, groups of four row positions.
+// A plan uses the first variant with NT >= m, NT*VF >= n, DM >= D, 4*KG >= K over all its windows.
+struct Variant {
+    int nt, vf, dm, kg;
+    int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);
+};
+static const Variant *select_variant(int mmax, int nmax, int dm, int kmax);
+
 // A decode plan: 1..W windows + (for W > 1 or commit > 0) the global check matrix in CSC form.
 struct Plan {
     std::vector<WindowHost> wins;
     swd_osdw_params p{};
-    int device = 0, nt = 256;
+    int device = 0, nt = 256, vf = 7, dm = 8;
+    const Variant *variant = nullptr;
     int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
     DevBuf d_wins, d_chk, d_obs;
     DevBuf shot;
@@ -66,6 +79,8 @@ struct Plan {
     const uint16_t *d_rows = nullptr;
     // host-pointer staging
     DevBuf synd, out, stats, pm, hist, osd0, total;
+    DevBuf prof;
+    bool profiling = false;
     bool timing = false;
     double t_total_ms = 0;
     int64_t t_launches = 0;
@@ -107,8 +122,18 @@ struct Plan {
         if (p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
         nmax = 0;
         int lmax = 0, mmax = 0;
-        for (auto &w : wins) nmax = std::max(nmax, w.g->n);
-        nt = nmax <= 192 ? 64 : nmax <= 768 ? 128 : nmax <= 3072 ? 256 : 1024;
+        dm = 0;
+        for (auto &w : wins) { nmax = std::max(nmax, w.g->n); dm = std::max(dm, w.g->D); }
+        int kmax = 0;
+        mmax = 0;
+        for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
+        variant = select_variant(mmax, nmax, dm, kmax);
+        if (!variant) {
+            set_error("no kernel variant for m=%d n=%d column weight %d row weight %d", mmax, nmax, dm, kmax);
+            return -1;
+        }
+        nt = variant->nt; vf = variant->vf;
+        mmax = 0;
         for (auto &w : wins) {
             make_layout(*w.g, w.new_n, nt, w.L);
             lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
@@ -156,16 +181,36 @@ struct Plan {
     }
 };
 
-template <int NT>
+
+template <int NT, int VF, int DM, int KG>
+static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st);
+template <int NT, int VF, int DM, int KG>
 static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
     static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
     if (d->lds_total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
     }
-    hipLaunchKernelGGL(pipeline_kernel<NT>, dim3(a.B), dim3(NT), d->lds_total, st, a);
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG>), dim3(a.B), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
+}
+
+static const Variant kVariants[] = {
+    {64, 4, 4, 2, launch_nt<64, 4, 4, 2>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
+    {64, 4, 8, 16, launch_nt<64, 4, 8, 16>},
+    {256, 2, 8, 16, launch_nt<256, 2, 8, 16>},
+    {256, 4, 8, 16, launch_nt<256, 4, 8, 16>},
+    {256, 7, 6, 9, launch_nt<256, 7, 6, 9>},      // [[144,12,12]] circuit-level windows
+    {256, 7, 8, 16, launch_nt<256, 7, 8, 16>},
+    {1024, 5, 6, 9, launch_nt<1024, 5, 6, 9>},    // [[288,12,18]] circuit-level windows
+    {1024, 8, 8, 16, launch_nt<1024, 8, 8, 16>},
+};
+
+static const Variant *select_variant(int mmax, int nmax, int dm, int kmax) {
+    for (const Variant &v : kVariants)
+        if (v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm && 4 * v.kg >= kmax) return &v;
+    return nullptr;
 }
 
 static int launch(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
@@ -174,12 +219,7 @@ static int launch(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
         SWD_HIP(hipEventRecord(d->ev0, st));
     }
     int rc;
-    switch (d->nt) {
-    case 64: rc = launch_nt<64>(d, a, st); break;
-    case 128: rc = launch_nt<128>(d, a, st); break;
-    case 256: rc = launch_nt<256>(d, a, st); break;
-    default: rc = launch_nt<1024>(d, a, st); break;
-    }
+    rc = d->variant->launch(d, a, st);
     if (rc) return rc;
     if (d->timing) {
         SWD_HIP(hipEventRecord(d->ev1, st));
@@ -397,6 +437,10 @@ extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t
     a.hist = d->hist.as<double>(); a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
     a.obs_mask = d->d_obs.p ? d->d_obs.as<uint32_t>() : nullptr;
     a.shot_result = shot_result;
+    if (d->profiling) {
+        if (d->prof.reserve((size_t)B * a.W * 8 * sizeof(int64_t))) return -1;
+        a.prof = d->prof.as<int64_t>();
+    }
     return launch(d, a, (hipStream_t)stream);
 }
 
@@ -420,5 +464,21 @@ extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *de
     if (shot_result) SWD_HIP(hipMemcpy(shot_result, d->shot.p, (size_t)B * 8, hipMemcpyDeviceToHost));
     if (stats) SWD_HIP(hipMemcpy(stats, d->stats.p, B * W * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
     if (min_pm) SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * W * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// diagnostics: per-phase device timers of the last pipeline launch (100 MHz ticks), [B][W][8]
+extern "C" int swd_pipeline_set_profiling(swd_pipeline *h, int32_t on) {
+    Plan *d = (Plan *)h;
+    if (!d) { set_error("null pipeline"); return -1; }
+    d->profiling = on != 0;
+    return 0;
+}
+extern "C" int swd_pipeline_get_profile(swd_pipeline *h, int32_t B, int64_t *out) {
+    Plan *d = (Plan *)h;
+    if (!d || !out) { set_error("null argument"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(out, d->prof.p, (size_t)B * d->wins.size() * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return 0;
 }

@@ -13,10 +13,10 @@
 #include "swd.h"
 #include "swd_graph.h"
 
-#define SWD_DMAX 8 // unrolled variable-node degree bound of this build (col degree <= 8)
+#define SWD_DMAX 8 // largest column degree any kernel variant of this build supports
 
 struct SwdLdsLayout {
-    int32_t off_livemask, off_par, off_lv, off_jptr, off_cnval, off_cndeg, off_vnval, off_hard,
+    int32_t off_livemask, off_par, off_lv, off_jptr, off_lslot, off_cnval, off_cndeg, off_cndeg0, off_vnval, off_hard,
         off_misc, total;
     int32_t npad;      // power of two >= n (bitonic sort size)
     int32_t off_idx;   // inside scratch: u16 idx[npad] after u64 key[npad]
@@ -67,6 +67,7 @@ struct SwdPipeArgs {
     uint8_t *osd0;            // nullable [B][n] (single-window use)
     const uint32_t *obs_mask; // nullable [num_col]: bit k set if fault flips observable k (obs matrix)
     int32_t *shot_result;     // nullable [B][2]: predicted observable flips, residual syndrome != 0
+    int64_t *prof;            // nullable [B][W][8]: 100 MHz ticks per phase (diagnostics only)
 };
 
 namespace swd {
@@ -78,8 +79,10 @@ struct Lds {
     uint32_t *par;      // [m]
     uint16_t *lv;       // [new_n]
     uint16_t *jptr;     // [K+1]
+    uint16_t *lslot;    // [K*m] post phase: lslot[k*m + l] = k-th live edge slot of check lane l
     int8_t *cn_val;     // [m]  residual check value, -1 = cleared
-    uint8_t *cn_deg;    // [m]
+    uint8_t *cn_deg;    // [m]  live degree
+    uint8_t *cn_deg0;   // [m]  original degree
     int8_t *vn_val;     // [n]  -1 live / decided value
     uint8_t *hard;      // [n]  bp_decoding
     int *flags;         // [32]
@@ -149,83 +152,247 @@ __device__ __forceinline__ void wave_fence() {
 // The parity words of iteration i are inspected at the start of the CN pass of iteration
 // i+1, so an iteration costs two barriers.
 // ------------------------------------------------------------------------------------------
-template <int NT, bool FULL>
-__device__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
-                      double *hist_b, int &iters_done) {
-    const int tid = threadIdx.x, m = g.m, n = g.n;
-    const double alpha = P.alpha, nalpha = -P.alpha;
-    iters_done = 0;
-    if (max_iter <= 0) return 0;
-    for (int it = 0; it < max_iter; ++it) {
-        bool unsat = false;
-        for (int l = tid; l < m; l += NT) {
-            const int cv = s.cn_val[l];
-            if (cv < 0) continue;
-            if (it > 0 && s.par[l] != 0u) unsat = true;
-            s.par[l] = (uint32_t)cv;
-            const uint64_t mk = s.livemask[l];
-            double min1 = 1e308, min2 = 1e308;
-            int arg = -1, sg = cv;
-            uint64_t negm = 0, t = mk;
-            while (t) {
-                const int j = __ffsll((long long)t) - 1;
-                t &= t - 1;
-                double x = s.msg[s.jptr[j] + l];
-                if (x > 50.0) x = 50.0;
-                else if (x < -50.0) x = -50.0;
-                const double ax = fabs(x);
-                if (ax < min1) { min2 = min1; min1 = ax; arg = j; }
-                else if (ax < min2) min2 = ax;
-                if (x <= 0) { negm |= 1ull << j; sg ^= 1; }
-            }
-            t = mk;
-            while (t) {
-                const int j = __ffsll((long long)t) - 1;
-                t &= t - 1;
-                const double mag = (j == arg) ? min2 : min1;
-                const int sgn = sg ^ (int)((negm >> j) & 1ull);
-                s.msg[s.jptr[j] + l] = mag * (sgn ? nalpha : alpha);
-            }
-        }
-        const bool any = block_any<NT>(unsat, s);
-        if (it > 0 && !any) { iters_done = it; return 1; }
+// Per-thread register cache of the variable nodes a thread owns during one BP phase: thread t owns
+// entries t, t+NT, ... of the VN list (all VNs in the pre phase, the compacted live list in the post
+// phase).  Edge metadata, priors and live-edge masks are loaded once per phase, so the iteration loop
+// touches only LDS.  DM = exact bound on the column degree of this kernel variant.
+template <int VF, int DM>
+struct VnCache {
+    double llr[VF];
+    uint32_t ed[VF][DM];
+    uint32_t mask[(VF + 3) / 4]; // 8 bits per VN: bit k = edge k exists and its check is live
+    __device__ __forceinline__ uint32_t m8(int i) const { return (mask[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
+};
 
-        const int cnt = FULL ? n : nlive;
-        const int slot_h = it & 3;
-        for (int i = tid; i < cnt; i += NT) {
-            const int v = FULL ? i : (int)s.lv[i];
-            const int deg = g.col_deg[v];
-            uint32_t ed[SWD_DMAX];
-            double c[SWD_DMAX], pre[SWD_DMAX];
-            bool live[SWD_DMAX];
+template <int NT, int VF, int DM, bool FULL>
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCache<VF, DM> &c) {
+    const int n = g.n, cnt = FULL ? n : nlive;
 #pragma unroll
-            for (int k = 0; k < SWD_DMAX; ++k) {
-                live[k] = false;
+    for (int i = 0; i < (VF + 3) / 4; ++i) c.mask[i] = 0;
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        c.llr[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) c.ed[i][k] = 0;
+        if (idx < cnt) {
+            const int v = FULL ? idx : (int)s.lv[idx];
+            const int deg = g.col_deg[v];
+            c.llr[i] = g.llr[v];
+            uint32_t mk = 0;
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
                 if (k < deg) {
-                    ed[k] = g.vn_edge[k * n + v];
-                    live[k] = FULL ? true : (s.cn_val[swd_edge_lane(ed[k])] >= 0);
-                    if (live[k]) c[k] = s.msg[swd_edge_slot(ed[k])];
+                    const uint32_t e = g.vn_edge[k * n + v];
+                    c.ed[i][k] = e;
+                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) mk |= 1u << k;
                 }
             }
-            double temp = g.llr[v];
+            c.mask[i >> 2] |= mk << ((i & 3) * 8);
+        }
+    }
+}
+
+// bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
+template <int VF, int DM>
+__device__ __forceinline__ void bp_init(Lds &s, const VnCache<VF, DM> &c) {
 #pragma unroll
-            for (int k = 0; k < SWD_DMAX; ++k)
-                if (live[k]) { pre[k] = temp; temp += c[k]; }
-            if (P.record_all || it >= max_iter - 4) hist_b[slot_h * n + v] = temp;
+    for (int i = 0; i < VF; ++i) {
+        const uint32_t mk = c.m8(i);
+#pragma unroll
+        for (int k = 0; k < DM; ++k)
+            if ((mk >> k) & 1u) s.msg[swd_edge_slot(c.ed[i][k])] = c.llr[i];
+    }
+}
+
+__device__ __forceinline__ int wave_max(int x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x = max(x, __shfl_xor(x, d, 64));
+    return x;
+}
+
+// Per-thread register cache of the check a lane owns during one BP phase: the LDS slots of its
+// edges (u16, two per register) in walk order; unused / dead positions hold the sacrificial slot
+// g.E, which is how the inner loops recognise them.  KG = groups of four positions.
+template <int KG>
+struct CnCache {
+    uint32_t sl[KG * 2];
+    uint64_t vmask; // bit k: position k carries a live edge
+    int cnt;        // positions to walk (0 for lanes without a live check)
+    __device__ __forceinline__ int slot(int k) const { return (int)((sl[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu); }
+};
+
+template <int NT, int KG, bool FULL>
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, CnCache<KG> &cc) {
+    const int l = threadIdx.x, m = g.m, dummy = g.E;
+    const bool act = (l < m) && (s.cn_val[l] >= 0);
+    // list mode walks the compacted live edges, otherwise all original positions (dead ones masked)
+    const bool bylist = !FULL && uselist;
+    const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
+    const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : s.livemask[l];
+    cc.cnt = cnt;
+    cc.vmask = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) & lmask;
+#pragma unroll
+    for (int q = 0; q < KG * 2; ++q) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * q + h;
+            int sv = dummy;
+            if (k < cnt && ((lmask >> (k & 63)) & 1ull))
+                sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
+            w |= (uint32_t)sv << (16 * h);
+        }
+        cc.sl[q] = w;
+    }
+}
+
+template <int NT, int VF, int DM, int KG, bool FULL>
+__device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
+                      const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done) {
+    const int tid = threadIdx.x, m = g.m, n = g.n;
+    const int dummy = g.E;
+    const int vcnt = FULL ? n : nlive;
+    const double alpha = P.alpha, nalpha = -P.alpha;
+    const bool record_all = P.record_all != 0;
+    uint32_t maskw[(VF + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (VF + 3) / 4; ++i) maskw[i] = c.mask[i];
+    const int l = tid;                       // NT >= m: one check per lane
+    const int cv = (l < m) ? (int)s.cn_val[l] : -1;
+    const int cnt = cn.cnt;
+    const int wmax = wave_max(cnt);
+    iters_done = 0;
+    if (max_iter <= 0) return 0;
+#ifdef SWD_BPPROF
+    long long tc0, tc1, tc2, tc3;
+    long long acc_cn = 0, acc_any = 0, acc_vn = 0, acc_bar = 0;
+#define BPT(x) x = clock64()
+#else
+#define BPT(x)
+#endif
+    for (int it = 0; it < max_iter; ++it) {
+        bool unsat = false;
+        BPT(tc0);
+        // keep the per-edge predicates from being hoisted out of the loop as ~2 SGPRs each
+#pragma unroll
+        for (int i = 0; i < (VF + 3) / 4; ++i) asm volatile("" : "+v"(maskw[i]));
+        {
+            if (cv >= 0) {
+                if (it > 0 && s.par[l] != 0u) unsat = true;
+                s.par[l] = (uint32_t)cv;
+            }
+            double min1 = 1e308, min2 = 1e308;
+            int arg = -1;
+            uint32_t neg_lo = 0, neg_hi = 0; // bit k: clipped b2c of position k is <= 0
+            const uint32_t vm_lo = (uint32_t)cn.vmask, vm_hi = (uint32_t)(cn.vmask >> 32);
+            // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
+            // group of four are independent; after the reads everything is min/max/select (hipcc turns
+            // if/else here into exec-mask branches with an exposed LDS round trip each).  The two-minimum
+            // update min2 = min(min2, max(min1, a)); min1 = min(min1, a) equals the reference's
+            // left/right running minima; fmin/fmax ignore NaN like its `<` tests do.
+            // software pipeline of depth one: the reads of group gq+1 are in flight while group gq is
+            // reduced; the scheduling barriers keep the compiler from hoisting every group's reads to
+            // the top (which costs > 70 VGPRs and a wave of occupancy)
+            double xn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xn[u] = s.msg[cn.slot(u)];
+#pragma unroll
+            for (int gq = 0; gq < KG; ++gq) {
+                if (gq * 4 < wmax) { // wave-uniform
+                    double xs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xs[u] = xn[u];
+                    if (gq + 1 < KG) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) xn[u] = s.msg[cn.slot(min(gq + 1, KG - 1) * 4 + u)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = gq * 4 + u;
+                        const bool valid = (((k < 32) ? vm_lo : vm_hi) >> (k & 31)) & 1u;
+                        const double x = fmin(fmax(xs[u], -50.0), 50.0);
+                        const double ax = valid ? fabs(x) : 1e308;
+                        arg = (ax < min1) ? k : arg;
+                        min2 = fmin(min2, fmax(min1, ax));
+                        min1 = fmin(min1, ax);
+                        const uint32_t nb = (valid && (x <= 0)) ? (1u << (k & 31)) : 0u;
+                        if (k < 32) neg_lo |= nb; else neg_hi |= nb;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int sg = (cv ^ (__popc(neg_lo) + __popc(neg_hi))) & 1;
+#pragma unroll
+            for (int gq = 0; gq < KG; ++gq) {
+                if (gq * 4 < wmax) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = gq * 4 + u;
+                        const double mag = (k == arg) ? min2 : min1;
+                        const int sgn = sg ^ (int)((((k < 32) ? neg_lo : neg_hi) >> (k & 31)) & 1u);
+                        s.msg[cn.slot(k)] = mag * (sgn ? nalpha : alpha); // dead positions hit slot g.E
+                    }
+                }
+            }
+        }
+        BPT(tc1);
+        const bool any = block_any<NT>(unsat, s);
+        BPT(tc2);
+#ifdef SWD_BPPROF
+        acc_cn += tc1 - tc0; acc_any += tc2 - tc1;
+        if (it > 0 && !any && !FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
+#endif
+        if (it > 0 && !any) { iters_done = it; return 1; }
+
+        const int slot_h = it & 3;
+        const bool record = record_all || it >= max_iter - 4;
+#pragma unroll
+        for (int i = 0; i < VF; ++i) {
+            const int idx = tid + i * NT;
+            if (idx >= vcnt) continue;
+            const int v = FULL ? idx : (int)s.lv[idx];
+            const uint32_t mk = (maskw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+            double cc[DM], pre[DM];
+            // dead edges carry slot 0 in the cache: the loads are unconditional (and independent),
+            // their values are dropped by the selects below
+#pragma unroll
+            for (int k = 0; k < DM; ++k) cc[k] = s.msg[swd_edge_slot(c.ed[i][k])];
+            double temp = c.llr[i];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                const bool lv_ = (mk >> k) & 1u;
+                pre[k] = temp;
+                const double t2 = temp + cc[k];
+                temp = lv_ ? t2 : temp;
+            }
+            if (record) hist_b[slot_h * n + v] = temp;
             const bool hd = (temp <= 0);
             s.hard[v] = hd ? 1 : 0;
             double suf = 0.0;
 #pragma unroll
-            for (int k = SWD_DMAX - 1; k >= 0; --k)
-                if (live[k]) { s.msg[swd_edge_slot(ed[k])] = pre[k] + suf; suf += c[k]; }
+            for (int k = DM - 1; k >= 0; --k) {
+                const bool lv_ = (mk >> k) & 1u;
+                const double out = pre[k] + suf;
+                const double s2 = suf + cc[k];
+                suf = lv_ ? s2 : suf;
+                s.msg[lv_ ? (int)swd_edge_slot(c.ed[i][k]) : dummy] = out; // dead edges: sacrificial slot
+            }
             if (hd) {
 #pragma unroll
-                for (int k = 0; k < SWD_DMAX; ++k)
-                    if (live[k]) atomicXor(&s.par[swd_edge_lane(ed[k])], 1u);
+                for (int k = 0; k < DM; ++k)
+                    if ((mk >> k) & 1u) atomicXor(&s.par[swd_edge_lane(c.ed[i][k])], 1u);
             }
         }
+        BPT(tc3);
         __syncthreads();
+#ifdef SWD_BPPROF
+        acc_vn += tc3 - tc2; acc_bar += clock64() - tc3;
+#endif
     }
+#ifdef SWD_BPPROF
+    if (!FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
+#endif
     bool unsat = false;
     for (int l = tid; l < m; l += NT)
         if (s.cn_val[l] >= 0 && s.par[l] != 0u) unsat = true;
@@ -234,22 +401,10 @@ __device__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, in
     return any ? 0 : 1;
 }
 
-// bp_init (osd_window.pyx:370-379): b2c <- prior on every edge of every live VN
-template <int NT, bool FULL>
-__device__ void bp_init(const SwdGraphDev &g, Lds &s, int nlive) {
-    const int cnt = FULL ? g.n : nlive;
-    for (int i = threadIdx.x; i < cnt; i += NT) {
-        const int v = FULL ? i : (int)s.lv[i];
-        const int deg = g.col_deg[v];
-        const double l = g.llr[v];
-        for (int k = 0; k < deg; ++k) s.msg[swd_edge_slot(g.vn_edge[k * g.n + v])] = l;
-    }
-}
-
 // Bitonic sort of (key, idx) pairs, ascending lexicographic == the reference's stable
 // ascending argsort (index_sort, src/include/bpgd.cpp:384-389).
 template <int NT>
-__device__ void sort_pairs(uint64_t *key, uint16_t *idx, int npad) {
+__device__ __forceinline__ void sort_pairs(uint64_t *key, uint16_t *idx, int npad) {
     const int half = npad >> 1;
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -270,7 +425,7 @@ __device__ void sort_pairs(uint64_t *key, uint16_t *idx, int npad) {
 // sum of llr[v] over hard[v]==1 in ascending v (min_pm, osd_window.pyx:168-169 / 233-235).
 // `list` must hold n u16.  Result valid on every thread.
 template <int NT>
-__device__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint16_t *list) {
+__device__ __forceinline__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint16_t *list) {
     const int n = g.n;
     const int ch = (n + NT - 1) / NT;
     const int v0 = threadIdx.x * ch, v1 = min(n, v0 + ch);
@@ -322,7 +477,7 @@ __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, 
 // peel (osd_window.pyx:306-338) on wave 0, reproducing the reference's sweep order: the next
 // check handled is the lowest original index >= sweep pointer with live degree 1, wrapping to
 // a new sweep when the current one is exhausted.  Returns true on contradiction.
-__device__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
+__device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
     const int lane = threadIdx.x & 63;
     int ptr = 0;
     for (;;) {
@@ -360,7 +515,7 @@ __device__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
 // reference's LU + forward/backward substitution (mod2sparse_extra.cpp:78-106) because both
 // solve the same invertible pivot-row x pivot-column system with zeros elsewhere.
 // T is stored column-major: Tc[j*wm + w] = word w of column j (bit r = T[r][j]).
-__device__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tc,
+__device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tc,
                          uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b,
                          int *npiv_out) {
     const int lane = threadIdx.x & 63;
@@ -432,7 +587,7 @@ __device__ __forceinline__ bool cs_better(double pa, int la, double pb, int lb) 
 }
 
 template <int NT>
-__device__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+__device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                             const uint16_t *idx, const uint64_t *Tc, const uint64_t *y0,
                             const uint16_t *piv_col, const uint16_t *piv_row, int npiv, double pm0) {
     const int tid = threadIdx.x, n = g.n, wm = g.wm, kset = g.new_n - g.rank, CP = L.cs_par;
@@ -611,6 +766,7 @@ __device__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLayout &L, const S
 struct WinResult {
     int exit_class, conv, total_it, pre_it, post_it, live_vn, live_cn, live_e, osd_rowadds;
     double pm;
+    long long t[9]; // phase boundaries (wall_clock64 ticks): init, pre, sort, shorten, post, osd sort, elim, sweep
 };
 
 __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout &L) {
@@ -620,8 +776,10 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
     s.par = (uint32_t *)(smem + L.off_par);
     s.lv = (uint16_t *)(smem + L.off_lv);
     s.jptr = (uint16_t *)(smem + L.off_jptr);
+    s.lslot = (uint16_t *)(smem + (L.off_lslot >= 0 ? L.off_lslot : 0));
     s.cn_val = (int8_t *)(smem + L.off_cnval);
     s.cn_deg = (uint8_t *)(smem + L.off_cndeg);
+    s.cn_deg0 = (uint8_t *)(smem + L.off_cndeg0);
     s.vn_val = (int8_t *)(smem + L.off_vnval);
     s.hard = (uint8_t *)(smem + L.off_hard);
     s.flags = (int *)(smem + L.off_misc);
@@ -630,34 +788,43 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 
 // osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
 // order).  On return s.hard[0..n) is the vector decode() returns.
-template <int NT>
-__device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+template <int NT, int VF, int DM, int KG>
+__device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                               const uint8_t *synd, double *hist_b, uint8_t *osd0_b, WinResult &R) {
     const int tid = threadIdx.x;
     const int m = g.m, n = g.n;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R.t[i] = 0;
+    R.t[0] = wall_clock64();
 
     // reset (osd_window.pyx:288-303)
     for (int l = tid; l < m; l += NT) {
         const int d = g.row_deg[l];
         s.cn_val[l] = (int8_t)(synd[g.perm[l]] ? 1 : 0);
         s.cn_deg[l] = (uint8_t)d;
+        s.cn_deg0[l] = (uint8_t)d;
         s.livemask[l] = (d >= 64) ? ~0ull : ((1ull << d) - 1ull);
     }
     for (int v = tid; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
     for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
     if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
-    __syncthreads(); // jptr visible before bp_init uses slots (slots come packed; keeps later code simple)
-    bp_init<NT, true>(g, s, n);
+    VnCache<VF, DM> vc;
+    vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
+    bp_init<VF, DM>(s, vc);
+    CnCache<KG> cn;
+    cn_cache_load<NT, KG, true>(g, s, false, cn);
     __syncthreads();
 
     int it = 0;
     R.conv = 0; R.pm = 0.0; R.pre_it = R.post_it = 0;
     R.live_vn = n; R.live_cn = m; R.live_e = g.E; R.osd_rowadds = 0;
     uint16_t *list0 = (uint16_t *)s.scratch;
+    R.t[1] = wall_clock64();
 
-    R.conv = bp_run<NT, true>(g, P, s, P.pre_iter, n, hist_b, it);
+    R.conv = bp_run<NT, VF, DM, KG, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it);
     R.pre_it = it;
+    R.t[2] = wall_clock64();
     if (R.conv) {
         R.exit_class = SWD_EXIT_PRE;
         R.pm = ordered_pm<NT>(g, s, list0);
@@ -677,6 +844,7 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
     }
     __syncthreads();
     sort_pairs<NT>(key, idx, L.npad);
+    R.t[3] = wall_clock64();
     // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
     for (int i = g.new_n + tid; i < n; i += NT) s.vn_val[idx[i]] = 0;
     __syncthreads();
@@ -734,6 +902,7 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
         return;
     }
     // ---- compact the live VNs, re-initialise their messages (osd_window.pyx:187)
+    const bool uselist = L.off_lslot >= 0;
     int nlive;
     {
         const int ch = (n + NT - 1) / NT;
@@ -745,15 +914,32 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
             if (s.vn_val[v] < 0) s.lv[pos++] = (uint16_t)v;
         int lc = 0, le = 0;
         for (int l = tid; l < m; l += NT)
-            if (s.cn_val[l] >= 0) { ++lc; le += __popcll(s.livemask[l]); }
+            if (s.cn_val[l] >= 0) {
+                ++lc;
+                le += __popcll(s.livemask[l]);
+                // compact list of the live edge slots of this check (post-phase CN pass)
+                uint64_t mk = uselist ? s.livemask[l] : 0ull;
+                int k = 0;
+                while (mk) {
+                    const int j = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    s.lslot[k * m + l] = (uint16_t)(s.jptr[j] + l);
+                    ++k;
+                }
+            }
         if (lc) { atomicAdd(&s.scal[2], lc); atomicAdd(&s.scal[3], le); }
     }
     __syncthreads();
     R.live_vn = nlive; R.live_cn = s.scal[2]; R.live_e = s.scal[3];
-    bp_init<NT, false>(g, s, nlive);
+    vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
+    cn_cache_load<NT, KG, false>(g, s, uselist, cn);
+    __syncthreads(); // every lane has read its slot list before the messages are re-initialised
+    bp_init<VF, DM>(s, vc);
     __syncthreads();
-    R.conv = bp_run<NT, false>(g, P, s, P.post_iter, nlive, hist_b, it);
+    R.t[4] = wall_clock64();
+    R.conv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it);
     R.post_it = it;
+    R.t[5] = wall_clock64();
     R.total_it = R.pre_it + R.post_it;
     if (R.conv) {
         R.exit_class = SWD_EXIT_POST;
@@ -776,6 +962,7 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
     }
     __syncthreads();
     sort_pairs<NT>(key, idx, L.npad);
+    R.t[6] = wall_clock64();
     uint64_t *Tc = (uint64_t *)(s.scratch + L.off_aux);
     uint64_t *Sbuf = Tc + m * g.wm;
     uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
@@ -795,6 +982,7 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
     __syncthreads();
     R.osd_rowadds = s.scal[2];
     const int npiv = s.scal[3];
+    R.t[7] = wall_clock64();
     if (osd0_b)
         for (int v = tid; v < n; v += NT) osd0_b[v] = s.hard[v];
     R.pm = ordered_pm<NT>(g, s, list1);
@@ -808,8 +996,8 @@ __device__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const
 // residual syndrome (osd.py:178, done sparsely on the shot's LDS copy), next window.  Windows
 // of one shot are sequentially dependent, shots are independent, so there is no inter-workgroup
 // traffic at all.  W = 1 with commit = 0 is the plain batched osd_window.decode.
-template <int NT>
-__global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
+template <int NT, int VF, int DM, int KG>
+__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, b = blockIdx.x;
     uint8_t *sdet = (uint8_t *)(smem + a.off_det);
@@ -823,11 +1011,14 @@ __global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
     __syncthreads();
     for (int wi = 0; wi < a.W; ++wi) {
         const SwdWindowDev &w = a.wins[wi];
-        const SwdGraphDev g = w.g;
-        const SwdLdsLayout L = w.L;
+        const SwdGraphDev &g = w.g;
+        const SwdLdsLayout &L = w.L;
         lds_bind(s, smem, L);
         WinResult R;
-        decode_window<NT>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
+#ifdef SWD_BPPROF
+        if (tid == 0) { s.scal[24] = s.scal[25] = s.scal[26] = s.scal[27] = 0; s.scal[20] = s.scal[21] = s.scal[22] = 0; }
+#endif
+        decode_window<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
         __syncthreads();
         if (a.total) {
             uint8_t *tot_b = a.total + (int64_t)b * a.total_stride + w.col0;
@@ -857,6 +1048,22 @@ __global__ void __launch_bounds__(NT) pipeline_kernel(const SwdPipeArgs a) {
                 st[4] = R.live_vn; st[5] = R.live_cn; st[6] = R.live_e; st[7] = R.osd_rowadds;
             }
             if (a.min_pm) a.min_pm[(int64_t)b * a.W + wi] = R.pm;
+            if (a.prof) {
+                int64_t *pr = a.prof + ((int64_t)b * a.W + wi) * 8;
+                const long long tend = wall_clock64();
+                long long prev = R.t[0];
+#pragma unroll
+                for (int i = 1; i <= 7; ++i) {
+                    const long long cur = R.t[i] ? R.t[i] : prev;
+                    pr[i - 1] = cur - prev;
+                    prev = cur;
+                }
+                pr[7] = tend - prev;
+#ifdef SWD_BPPROF
+                pr[0] = s.scal[24]; pr[5] = s.scal[25]; pr[6] = s.scal[26]; pr[7] = s.scal[27];
+                pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22];
+#endif
+            }
         }
         __syncthreads();
     }

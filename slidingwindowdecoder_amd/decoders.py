@@ -311,6 +311,16 @@ class SlidingWindowDecoder:
             raise RuntimeError(f"swd_pipeline_decode_dev failed: {_lib.last_error()}")
         return total, stats, min_pm
 
+    def set_profiling(self, on=True):
+        _lib.lib().swd_pipeline_set_profiling(self._h, 1 if on else 0)
+
+    def get_profile(self, B):
+        """[B, W, 8] int64 ticks (100 MHz) per phase of the last launch (diagnostics)."""
+        out = np.zeros((B, self.W, 8), np.int64)
+        if _lib.lib().swd_pipeline_get_profile(self._h, B, out.ctypes.data):
+            raise RuntimeError(_lib.last_error())
+        return out
+
     def set_timing(self, on=True):
         _lib.lib().swd_pipeline_set_timing(self._h, 1 if on else 0)
 
