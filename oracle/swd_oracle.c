@@ -938,3 +938,4 @@ int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_
     }
     return 0;
 }
+

@@ -22,6 +22,8 @@ post = st[..., 3].astype(np.float64)
 sel = post > 0
 for name, k in (("CN pass", 0), ("block_any(+barrier)", 5), ("VN pass", 6), ("end barrier", 7)):
     print(f"{name:22s} cycles per post iteration: {prof[..., k][sel].sum() / post[sel].sum():8.0f}")
-for name, k in (("  CN setup (to loop1)", 1), ("  CN loop 1", 2), ("  wmax (sum)", 3)):
-    print(f"{name:22s} per post iteration: {prof[..., k][sel].sum() / post[sel].sum():8.1f}")
+osd = (st[..., 0] & 0xFF) == 2
+if osd.any():
+    print("OSD shots: steps mean %.0f max %.0f ; cycles: all step evaluations %.0f ; first fence %.0f ; T updates %.0f" % (
+        prof[..., 1][osd].mean(), prof[..., 1][osd].max(), 16 * prof[..., 2][osd].mean(), 16 * prof[..., 4][osd].mean(), 16 * prof[..., 3][osd].mean()))
 print("post ticks(100MHz)/iter: %.1f us" % (prof[..., 4][sel].sum() / post[sel].sum() / 100.0))

@@ -514,54 +514,132 @@ __device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
 // operations are applied to all rows (Gauss-Jordan) which gives the same solution as the
 // reference's LU + forward/backward substitution (mod2sparse_extra.cpp:78-106) because both
 // solve the same invertible pivot-row x pivot-column system with zeros elsewhere.
-// T is stored column-major: Tc[j*wm + w] = word w of column j (bit r = T[r][j]).
-__device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tc,
+//
+// T is stored word-major, Tw[w*m + j] = word w of column j (bit r of it = T[64w + r][j]), so that
+// lanes walking consecutive columns hit consecutive LDS words.  The wave evaluates 64/WG sorted
+// columns per step (WG = words per column rounded up to a power of two; lane = column*WG + word):
+// every column of the step that reduces to zero on the unpivoted rows is dependent and stays so,
+// which lets whole runs of dependent columns be skipped at once -- the scan typically walks ~900
+// columns for 216 pivots.  crows[p*DM + k] = original row of the k-th one of the p-th sorted column
+// (0xFFFF pad), staged in LDS by the whole workgroup for p < nst.
+__device__ __forceinline__ int osd_tidx(int row, int w, int m) { return w * m + row; }
+
+template <int DM>
+__device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw,
                          uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b,
-                         int *npiv_out) {
+                         const uint16_t *crows, int nst, int *npiv_out) {
     const int lane = threadIdx.x & 63;
     const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
-    // this lane's words of the pivoted-row mask: w = lane, lane + 64, ... (wm <= 16 -> one word)
-    uint64_t P = 0;
-    int npiv = 0, rowadds = 0;
-    for (int p = 0; p < n && npiv < rank; ++p) {
-        const int v = order[p];
-        const int deg = g.col_deg[v];
+    int WG = 1;
+    while (WG < wm) WG <<= 1;
+    const int NB = 64 / WG;            // columns per step
+    const int c = lane / WG, w = lane % WG;
+    const bool wact = w < wm;
+    const int wl = wact ? w : 0;
+    uint64_t Pw = 0;                    // word w of the pivoted-row mask (replicated per column group)
+    int npiv = 0, rowadds = 0, p = 0;
+#ifdef SWD_BPPROF
+    long long acc_scan = 0, acc_upd = 0, acc_f1 = 0; int nscan = 0;
+#endif
+    while (p < n && npiv < rank) {
+#ifdef SWD_BPPROF
+        long long t0 = clock64(); ++nscan;
+#endif
+        const int pc = p + c;
+        const bool cval = wact && pc < n;
+        int rows[DM];
+        if (p + NB <= nst) { // wave-uniform: whole step inside the staged prefix
+#pragma unroll
+            for (int k = 0; k < DM; ++k) rows[k] = crows[pc * DM + k];
+        } else {             // beyond the staged prefix (rare): straight from the graph
+            const int v = cval ? (int)order[pc] : 0;
+            const int deg = cval ? (int)g.col_deg[v] : 0;
+#pragma unroll
+            for (int k = 0; k < DM; ++k) rows[k] = (k < deg) ? (int)g.vn_row[k * n + v] : 0xFFFF;
+        }
+        uint64_t tw[DM];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) tw[k] = Tw[osd_tidx(rows[k] == 0xFFFF ? 0 : rows[k], wl, m)];
         uint64_t red = 0;
-        if (lane < wm)
-            for (int k = 0; k < deg; ++k) red ^= Tc[(int)g.vn_row[k * n + v] * wm + lane];
-        const uint64_t cand = red & ~P;
-        const unsigned long long bal = __ballot(lane < wm && cand != 0ull);
-        if (bal == 0ull) continue;
-        const int ws = __ffsll((long long)bal) - 1;
-        const uint64_t cw = __shfl(cand, ws, 64);
+#pragma unroll
+        for (int k = 0; k < DM; ++k) red ^= (rows[k] == 0xFFFF) ? 0ull : tw[k];
+        const uint64_t cand = cval ? (red & ~Pw) : 0ull;
+        const unsigned long long bal = __ballot(cand != 0ull);
+        if (bal == 0ull) {
+#ifdef SWD_BPPROF
+            acc_scan += clock64() - t0;
+#endif
+            p += NB;
+            continue;
+        }
+        const int fl = __ffsll((long long)bal) - 1; // first column of the step with a usable 1, its lowest word
+        const int cs = fl / WG, ws = fl % WG;
+        const uint64_t cw = __shfl(cand, fl, 64);
         const int bit = __ffsll((long long)cw) - 1;
         const int r = ws * 64 + bit;
         {   // row additions the reference's LU would apply: unpivoted rows with a 1 in this column
-            uint64_t un = cand;
-            if (lane == ws) un &= ~(1ull << bit);
-            int c = (lane < wm) ? __popcll(un) : 0;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-            rowadds += c;
+            // (statistics only: per-lane partial sums, reduced once after the loop)
+            uint64_t un = (c == cs) ? cand : 0ull;
+            if (lane == fl) un &= ~(1ull << bit);
+            rowadds += __popcll(un);
         }
-        if (lane == ws) { P |= 1ull << bit; red &= ~(1ull << bit); }
-        if (lane == 0) { piv_col[npiv] = (uint16_t)v; piv_row[npiv] = (uint16_t)r; }
+        if (c == cs && wact) Sbuf[w] = (w == ws) ? (red & ~(1ull << bit)) : red;
+        if (w == ws) Pw |= 1ull << bit;
+        if (lane == 0) { piv_col[npiv] = order[p + cs]; piv_row[npiv] = (uint16_t)r; }
         ++npiv;
-        if (lane < wm) Sbuf[lane] = red;
+#ifdef SWD_BPPROF
+        long long tA = clock64();
+#endif
         wave_fence();
-        const int rw = r >> 6;
+#ifdef SWD_BPPROF
+        long long tB = clock64();
+        acc_scan += tA - t0; acc_f1 += tB - tA;
+#endif
+        // T[:, j] ^= S for every column j of T with T[r][j] = 1: four columns per lane per round,
+        // reads first, select-XOR, unconditional write-back (no serial read-modify-write chains)
         const uint64_t rb = 1ull << (r & 63);
-        for (int j = lane; j < m; j += 64) {
-            if (Tc[j * wm + rw] & rb)
-                for (int w = 0; w < wm; ++w) Tc[j * wm + w] ^= Sbuf[w];
+        for (int j0 = 0; j0 < m; j0 += 256) {
+            bool hit[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hit[q] = (Tw[osd_tidx(min(j0 + q * 64 + lane, m - 1), ws, m)] & rb) != 0ull;
+            for (int x0 = 0; x0 < wm; x0 += 4) {
+                uint64_t sv[4], tv[4][4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) sv[x] = Sbuf[min(x0 + x, wm - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        tv[q][x] = Tw[osd_tidx(min(j0 + q * 64 + lane, m - 1), min(x0 + x, wm - 1), m)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = j0 + q * 64 + lane;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (j < m && x0 + x < wm) Tw[osd_tidx(j, x0 + x, m)] = tv[q][x] ^ (hit[q] ? sv[x] : 0ull);
+                }
+            }
         }
         wave_fence();
+        p += cs + 1;
+#ifdef SWD_BPPROF
+        acc_upd += clock64() - tB;
+#endif
     }
-    // y = T * s  (s in original row order)
-    uint64_t y = 0; // lane w < wm holds word w
-    for (int j = 0; j < m; ++j)
-        if (synd_b[j] && lane < wm) y ^= Tc[j * wm + lane];
-    if (lane < wm) Sbuf[lane] = y;
+#ifdef SWD_BPPROF
+    if (lane == 0) { s.scal[20] = nscan; s.scal[21] = (int)(acc_scan >> 4); s.scal[22] = (int)(acc_upd >> 4); s.scal[23] = (int)(acc_f1 >> 4); }
+#endif
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) rowadds += __shfl_xor(rowadds, d, 64);
+    // y = T * s  (s in original row order): lanes over the columns of T, then a wave XOR-reduction
+    for (int x = 0; x < wm; ++x) {
+        uint64_t acc = 0;
+        for (int j = lane; j < m; j += 64)
+            if (synd_b[j]) acc ^= Tw[osd_tidx(j, x, m)];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+        if (lane == 0) Sbuf[x] = acc;
+    }
     wave_fence();
     for (int i = lane; i < npiv; i += 64) {
         const int r = piv_row[i];
@@ -657,16 +735,16 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
                 uint64_t yw = y0[w];
                 if (!exhaustive) {
                     const int d1 = g.col_deg[c1];
-                    for (int k = 0; k < d1; ++k) yw ^= Tc[(int)g.vn_row[k * n + c1] * wm + w];
+                    for (int k = 0; k < d1; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c1], w, g.m)];
                     if (c2 != INF) {
                         const int d2 = g.col_deg[c2];
-                        for (int k = 0; k < d2; ++k) yw ^= Tc[(int)g.vn_row[k * n + c2] * wm + w];
+                        for (int k = 0; k < d2; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c2], w, g.m)];
                     }
                 } else {
                     for (int i = 0; i < order; ++i)
                         if ((l >> i) & 1) {
                             const int c = Ht[i], dc = g.col_deg[c];
-                            for (int k = 0; k < dc; ++k) yw ^= Tc[(int)g.vn_row[k * n + c] * wm + w];
+                            for (int k = 0; k < dc; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c], w, g.m)];
                         }
                 }
                 ybuf[w * CP + tid] = yw;
@@ -728,14 +806,14 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
                 while (rem >= order - 1 - i) { rem -= order - 1 - i; ++i; }
                 c1 = Ht[i]; c2 = Ht[i + 1 + rem];
             }
-            for (int k = 0; k < g.col_deg[c1]; ++k) yw ^= Tc[(int)g.vn_row[k * n + c1] * wm + w];
+            for (int k = 0; k < g.col_deg[c1]; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c1], w, g.m)];
             if (c2 != INF)
-                for (int k = 0; k < g.col_deg[c2]; ++k) yw ^= Tc[(int)g.vn_row[k * n + c2] * wm + w];
+                for (int k = 0; k < g.col_deg[c2]; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c2], w, g.m)];
         } else {
             for (int i = 0; i < order; ++i)
                 if ((l >> i) & 1) {
                     const int c = Ht[i];
-                    for (int k = 0; k < g.col_deg[c]; ++k) yw ^= Tc[(int)g.vn_row[k * n + c] * wm + w];
+                    for (int k = 0; k < g.col_deg[c]; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c], w, g.m)];
                 }
         }
         ybuf[32 + w] = yw; // wpm/wl occupy the first 24 words
@@ -968,15 +1046,24 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
     uint16_t *piv_row = piv_col + g.rank;
     uint16_t *list1 = piv_row + g.rank;
-    for (int i = tid; i < m * g.wm; i += NT) {
-        const int j = i / g.wm, w = i - j * g.wm;
+    for (int i = tid; i < m * g.wm; i += NT) { // word-major identity: Tw[w*m + j]
+        const int w = i / m, j = i - w * m;
         Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
     }
     for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+    // stage the row lists of the leading sorted columns over the (dead) sort keys
+    uint16_t *crows = (uint16_t *)s.scratch;
+    const int nst = min(n, (L.npad * 8) / (DM * 2));
+    for (int p = tid; p < nst; p += NT) {
+        const int v = idx[p];
+        const int deg = g.col_deg[v];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) crows[p * DM + k] = (k < deg) ? g.vn_row[k * n + v] : (uint16_t)0xFFFF;
+    }
     __syncthreads();
     if (tid < 64) {
         int npiv;
-        const int ra = osd0_wave(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, &npiv);
+        const int ra = osd0_wave<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
         if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
     }
     __syncthreads();
@@ -1061,7 +1148,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                 pr[7] = tend - prev;
 #ifdef SWD_BPPROF
                 pr[0] = s.scal[24]; pr[5] = s.scal[25]; pr[6] = s.scal[26]; pr[7] = s.scal[27];
-                pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22];
+                pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
 #endif
             }
         }
