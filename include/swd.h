@@ -100,6 +100,38 @@ int swd_osdw_decode_batch_dev(swd_osdw *d, int32_t B, const uint8_t *synd, int64
 int swd_osdw_set_timing(swd_osdw *d, int32_t on);
 int swd_osdw_get_timing(swd_osdw *d, double *total_ms, int64_t *launches);
 
+/* ---- guessing decoders --------------------------------------------------------------------
+ * Replace bpgdg_decoder (single-thread gdg(), the deterministic path), bpgd_decoder and
+ * bp_history_decoder of /root/reference/src/bp_guessing_decoder.pyx.  kwargs as in
+ * bp_guessing_decoder.pyx:7-9, 162-171, 475-478.  stats words for these decoders:
+ *   [0] exit class | SWD_STATUS_CONVERGE (property `converge`), [1] BP iterations in total,
+ *   [2] pre-processing iterations, [3] iterations inside decimation steps, [4] snapshots pushed,
+ *   [5] BP blocks run, [6] min_converge_depth, [7] 0.                                           */
+typedef struct swd_gdg_params {
+    int32_t max_iter;            /* pre-processing BP iterations (default 50; 8 in the notebooks) */
+    double ms_scaling_factor;
+    int32_t max_iter_per_step;   /* 6  */
+    int32_t max_step;            /* 25 */
+    int32_t max_tree_depth;      /* 3  */
+    int32_t max_side_depth;      /* 10 */
+    int32_t max_tree_branch_step;/* 10 (multi-thread ensemble only; unused by gdg()) */
+    int32_t max_side_branch_step;/* 10 */
+    double gdg_factor;           /* gdg_factor / gd_factor */
+    int32_t new_n;               /* <=0: min(n, 2m) */
+    int32_t low_error_mode;
+    int32_t mode;                /* 0 bpgdg_decoder, 1 bpgd_decoder, 2 bp_history_decoder */
+} swd_gdg_params;
+
+typedef struct swd_gdg swd_gdg;
+swd_gdg *swd_gdg_create(const swd_graph_desc *g, const swd_gdg_params *p, int device);
+void swd_gdg_destroy(swd_gdg *d);
+/* host pointers; hist [B*4*n] nullable as in swd_osdw_decode_batch (pre-processing BP history) */
+int swd_gdg_decode_batch(swd_gdg *d, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
+                         double *min_pm, double *hist, int32_t hist_is_state);
+int swd_gdg_decode_batch_dev(swd_gdg *d, int32_t B, const uint8_t *synd, int64_t synd_stride,
+                             uint8_t *out, int64_t out_stride, int32_t *stats, double *min_pm,
+                             void *stream);
+
 /* ---- sliding-window pipeline ---------------------------------------------------------------
  * Replaces the window loop of the reference harness (/root/reference/osd.py:130-179, identical in
  * guessing.py:135-214 and the notebooks): for every shot, decode window t on the residual
@@ -119,6 +151,9 @@ typedef struct swd_pipeline swd_pipeline;
  * update (osd.py:178).  All windows share the decoder parameters p (osd.py:152-161). */
 swd_pipeline *swd_pipeline_create(int32_t num_windows, const swd_window_desc *wins,
                                   const swd_graph_desc *chk, const swd_osdw_params *p, int device);
+/* same window loop with a guessing decoder in every window (guessing.py:135-214) */
+swd_pipeline *swd_pipeline_create_gdg(int32_t num_windows, const swd_window_desc *wins,
+                                      const swd_graph_desc *chk, const swd_gdg_params *p, int device);
 void swd_pipeline_destroy(swd_pipeline *pl);
 int swd_pipeline_info(const swd_pipeline *pl, int32_t *num_windows, int32_t *num_det,
                       int32_t *num_col, int32_t *lds_bytes, int32_t *threads);

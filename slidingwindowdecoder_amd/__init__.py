@@ -3,6 +3,7 @@
 Host-side problem construction (codes, circuit, windows) is pure numpy/scipy and importable
 anywhere; the decoder classes need libswd_hip.so and a gfx950 GPU and raise otherwise.
 """
-from .decoders import SlidingWindowDecoder, osd_window  # noqa: F401
+from .decoders import (SlidingWindowDecoder, bp_history_decoder, bpgd_decoder, bpgdg_decoder,  # noqa: F401
+                       osd_window)
 
-__all__ = ["osd_window", "SlidingWindowDecoder"]
+__all__ = ["osd_window", "bpgdg_decoder", "bpgd_decoder", "bp_history_decoder", "SlidingWindowDecoder"]

@@ -30,6 +30,14 @@ class OsdwParams(C.Structure):
                 ("osd_method", C.c_int32), ("osd_order", C.c_int32)]
 
 
+class GdgParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("ms_scaling_factor", C.c_double), ("max_iter_per_step", C.c_int32),
+                ("max_step", C.c_int32), ("max_tree_depth", C.c_int32), ("max_side_depth", C.c_int32),
+                ("max_tree_branch_step", C.c_int32), ("max_side_branch_step", C.c_int32),
+                ("gdg_factor", C.c_double), ("new_n", C.c_int32), ("low_error_mode", C.c_int32),
+                ("mode", C.c_int32)]
+
+
 # every symbol include/swd.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = [
@@ -43,6 +51,11 @@ SYMBOLS = [
     ("swd_osdw_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     ("swd_osdw_set_timing", C.c_int, [_vp, _i32]),
     ("swd_osdw_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    ("swd_gdg_create", _vp, [C.POINTER(GraphDesc), C.POINTER(GdgParams), C.c_int]),
+    ("swd_gdg_destroy", None, [_vp]),
+    ("swd_gdg_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),
+    ("swd_gdg_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    ("swd_pipeline_create_gdg", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(GdgParams), C.c_int]),
     ("swd_pipeline_create", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
     ("swd_pipeline_destroy", None, [_vp]),
     ("swd_pipeline_info", C.c_int, [_vp] + [C.POINTER(_i32)] * 5),

@@ -17,7 +17,7 @@ namespace swd {
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-static int make_layout(const Graph &g, int new_n, int nt, SwdLdsLayout &L) {
+static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     const int m = g.m, n = g.n, E = g.E, wm = g.wm;
     const int npad = std::max(next_pow2(n), 2);
     L.npad = npad;
@@ -39,14 +39,22 @@ static int make_layout(const Graph &g, int new_n, int nt, SwdLdsLayout &L) {
     L.off_par = o; o += m * 4;
     L.off_lv = o; o = align_up(o + new_n * 2, 4);
     L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
-    // live-slot lists of the post phase are staged in the (then dead) scratch region
+    // live-slot lists: osd_window stages them in the (then dead) scratch region; the guessing decoders
+    // keep their messages alive across decimation steps and get a dedicated region
     L.off_lslot = (g.K * m * 2 <= scratch) ? 0 : -1;
+    L.off_gdg = -1;
+    if (kind != 0) {
+        L.off_gdg = o;
+        o = align_up(o + new_n * 2 * 2 + 64 * 2 * 2 + new_n + n + 64 + new_n, 8);
+        L.off_lslot = o;
+        o = align_up(o + g.K * m * 2, 8);
+    }
     L.off_cnval = o; o += m;
     L.off_cndeg = o; o += m;
     L.off_cndeg0 = o; o += m;
     L.off_vnval = o; o += n;
     L.off_hard = o; o = align_up(o + n, 16);
-    L.off_misc = o; o += 64 * 4;
+    L.off_misc = o; o += 640; // flags[32] scal[32] dbl[24] iaux[32]
     L.total = align_up(o, 16);
     return 0;
 }
@@ -62,7 +70,8 @@ struct Plan;
 // A plan uses the first variant with NT >= m, NT*VF >= n, DM >= D, 4*KG >= K over all its windows.
 struct Variant {
     int nt, vf, dm, kg;
-    int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);
+    int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);      // osd_window kernels
+    int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing-decoder kernels
 };
 static const Variant *select_variant(int mmax, int nmax, int dm, int kmax);
 
@@ -70,6 +79,11 @@ static const Variant *select_variant(int mmax, int nmax, int dm, int kmax);
 struct Plan {
     std::vector<WindowHost> wins;
     swd_osdw_params p{};
+    swd_gdg_params gp{};
+    int kind = 0;           // 0 osd_window, 1 bpgdg, 2 bpgd, 3 bp_history
+    int max_guess = 0;
+    int64_t snap_stride = 0;
+    DevBuf snap;
     int device = 0, nt = 256, vf = 7, dm = 8;
     const Variant *variant = nullptr;
     int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
@@ -108,8 +122,9 @@ struct Plan {
             cache[key] = w.g;
         }
         const int m = w.g->m, n = w.g->n;
-        w.new_n = (p.new_n <= 0) ? std::min(n, 2 * m) : std::min(p.new_n, n); // osd_window.pyx:60-63
-        if (p.osd_order > w.new_n - w.g->rank) {                              // osd_window.pyx:88-92
+        const int req_new_n = (kind == 0) ? p.new_n : gp.new_n;
+        w.new_n = (req_new_n <= 0) ? std::min(n, 2 * m) : std::min(req_new_n, n); // osd_window.pyx:60-63
+        if (kind == 0 && p.osd_order > w.new_n - w.g->rank) {                              // osd_window.pyx:88-92
             set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", w.new_n - w.g->rank);
             return -1;
         }
@@ -119,7 +134,17 @@ struct Plan {
     }
 
     int finalize(const swd_graph_desc *chk) {
-        if (p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
+        if (kind == 0 && p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
+        if (kind != 0) {
+            max_guess = ((1 << gp.max_tree_depth) - 1) * 2 + gp.max_side_depth - gp.max_tree_depth; // bp_guessing_decoder.pyx:181
+            if (max_guess < 0) max_guess = 0;
+            if (max_guess > 64) { set_error("max_guess=%d exceeds the device limit of 64 snapshots", max_guess); return -1; }
+            snap_stride = 0;
+            for (auto &w : wins) {
+                const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
+                snap_stride = std::max(snap_stride, rec * std::max(max_guess, 1));
+            }
+        }
         nmax = 0;
         int lmax = 0, mmax = 0;
         dm = 0;
@@ -135,7 +160,7 @@ struct Plan {
         nt = variant->nt; vf = variant->vf;
         mmax = 0;
         for (auto &w : wins) {
-            make_layout(*w.g, w.new_n, nt, w.L);
+            make_layout(*w.g, w.new_n, nt, kind, w.L);
             lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
         }
         if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
@@ -182,29 +207,29 @@ struct Plan {
 };
 
 
-template <int NT, int VF, int DM, int KG>
+template <int NT, int VF, int DM, int KG, int KIND>
 static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st);
-template <int NT, int VF, int DM, int KG>
+template <int NT, int VF, int DM, int KG, int KIND>
 static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
     static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
     if (d->lds_total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
     }
-    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG>), dim3(a.B), dim3(NT), d->lds_total, st, a);
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND>), dim3(a.B), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
 
 static const Variant kVariants[] = {
-    {64, 4, 4, 2, launch_nt<64, 4, 4, 2>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
-    {64, 4, 8, 16, launch_nt<64, 4, 8, 16>},
-    {256, 2, 8, 16, launch_nt<256, 2, 8, 16>},
-    {256, 4, 8, 16, launch_nt<256, 4, 8, 16>},
-    {256, 7, 6, 9, launch_nt<256, 7, 6, 9>},      // [[144,12,12]] circuit-level windows
-    {256, 7, 8, 16, launch_nt<256, 7, 8, 16>},
-    {1024, 5, 6, 9, launch_nt<1024, 5, 6, 9>},    // [[288,12,18]] circuit-level windows
-    {1024, 8, 8, 16, launch_nt<1024, 8, 8, 16>},
+    {64, 4, 4, 2, launch_nt<64, 4, 4, 2, 0>, launch_nt<64, 4, 4, 2, 1>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
+    {64, 4, 8, 16, launch_nt<64, 4, 8, 16, 0>, launch_nt<64, 4, 8, 16, 1>},
+    {256, 2, 8, 16, launch_nt<256, 2, 8, 16, 0>, launch_nt<256, 2, 8, 16, 1>},
+    {256, 4, 8, 16, launch_nt<256, 4, 8, 16, 0>, launch_nt<256, 4, 8, 16, 1>},
+    {256, 7, 6, 9, launch_nt<256, 7, 6, 9, 0>, launch_nt<256, 7, 6, 9, 1>},      // [[144,12,12]] circuit-level windows
+    {256, 7, 8, 16, launch_nt<256, 7, 8, 16, 0>, launch_nt<256, 7, 8, 16, 1>},
+    {1024, 5, 6, 9, launch_nt<1024, 5, 6, 9, 0>, launch_nt<1024, 5, 6, 9, 1>},    // [[288,12,18]] circuit-level windows
+    {1024, 8, 8, 16, launch_nt<1024, 8, 8, 16, 0>, launch_nt<1024, 8, 8, 16, 1>},
 };
 
 static const Variant *select_variant(int mmax, int nmax, int dm, int kmax) {
@@ -219,7 +244,7 @@ static int launch(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
         SWD_HIP(hipEventRecord(d->ev0, st));
     }
     int rc;
-    rc = d->variant->launch(d, a, st);
+    rc = (d->kind == 0) ? d->variant->launch(d, a, st) : d->variant->launch_gdg(d, a, st);
     if (rc) return rc;
     if (d->timing) {
         SWD_HIP(hipEventRecord(d->ev1, st));
@@ -257,6 +282,16 @@ static void fill_params(const Plan *d, SwdDecodeParams &P, bool hist_is_state, b
     // a fresh reference object has an all-zero history; only observable when fewer than four
     // iterations ran or when the history is returned
     P.zero_hist = (!hist_is_state && (hist_is_output || d->p.pre_max_iter < 4)) ? 1 : 0;
+    P.kind = d->kind;
+    if (d->kind != 0) {
+        P.pre_iter = d->gp.max_iter; P.alpha = d->gp.ms_scaling_factor; P.post_iter = 0;
+        P.osd_method = 0; P.osd_order = -1;
+        P.max_iter_per_step = d->gp.max_iter_per_step; P.max_step = d->gp.max_step;
+        P.max_tree_depth = d->gp.max_tree_depth; P.max_side_depth = d->gp.max_side_depth;
+        P.max_side_branch_step = d->gp.max_side_branch_step; P.low_error_mode = d->gp.low_error_mode;
+        P.max_guess = d->max_guess; P.gdg_factor = d->gp.gdg_factor;
+        P.zero_hist = (!hist_is_state && (hist_is_output || d->gp.max_iter < 4)) ? 1 : 0;
+    }
 }
 
 } // namespace swd
@@ -332,6 +367,10 @@ extern "C" int swd_osdw_decode_batch_dev(swd_osdw *h, int32_t B, const uint8_t *
     a.det = synd; a.det_stride = synd_stride ? synd_stride : m; a.num_det = m; a.off_det = d->off_det;
     a.total = nullptr; a.win_out = out; a.win_out_stride = out_stride ? out_stride : n;
     a.stats = stats; a.min_pm = min_pm; a.hist = hist; a.hist_stride = 4 * (int64_t)n; a.osd0 = osd0;
+    if (d->kind != 0) {
+        if (d->snap.reserve((size_t)B * d->snap_stride + 8)) return -1;
+        a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
+    }
     return launch(d, a, (hipStream_t)stream);
 }
 
@@ -437,6 +476,10 @@ extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t
     a.hist = d->hist.as<double>(); a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
     a.obs_mask = d->d_obs.p ? d->d_obs.as<uint32_t>() : nullptr;
     a.shot_result = shot_result;
+    if (d->kind != 0) {
+        if (d->snap.reserve((size_t)B * d->snap_stride + 8)) return -1;
+        a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
+    }
     if (d->profiling) {
         if (d->prof.reserve((size_t)B * a.W * 8 * sizeof(int64_t))) return -1;
         a.prof = d->prof.as<int64_t>();
@@ -481,4 +524,57 @@ extern "C" int swd_pipeline_get_profile(swd_pipeline *h, int32_t B, int64_t *out
     SWD_HIP(hipDeviceSynchronize());
     SWD_HIP(hipMemcpy(out, d->prof.p, (size_t)B * d->wins.size() * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// guessing decoders (bpgdg_decoder / bpgd_decoder / bp_history_decoder)
+// ------------------------------------------------------------------------------------------
+static int check_gdg_params(const swd_gdg_params &gp) {
+    if (gp.mode < 0 || gp.mode > 2) { set_error("gdg mode %d invalid (0 bpgdg, 1 bpgd, 2 bp_history)", gp.mode); return -1; }
+    if (gp.max_iter_per_step < 0 || gp.max_step < 0 || gp.max_tree_depth < 0 || gp.max_tree_depth > 6) {
+        set_error("invalid guessing-decoder parameters"); return -1;
+    }
+    return 0;
+}
+
+extern "C" swd_gdg *swd_gdg_create(const swd_graph_desc *g, const swd_gdg_params *gp, int device) {
+    if (!gp || !g) { set_error("null argument"); return nullptr; }
+    if (check_device(device) || check_gdg_params(*gp)) return nullptr;
+    Plan *d = new Plan();
+    d->device = device;
+    d->gp = *gp;
+    d->kind = gp->mode + 1;
+    d->p.pre_max_iter = gp->max_iter; d->p.osd_order = -1; d->p.ms_scaling_factor = gp->ms_scaling_factor;
+    std::map<std::string, std::shared_ptr<Graph>> cache;
+    if (d->add_window(g, 0, 0, 0, cache) || d->finalize(nullptr)) { delete d; return nullptr; }
+    return (swd_gdg *)d;
+}
+
+extern "C" void swd_gdg_destroy(swd_gdg *h) { swd_osdw_destroy((swd_osdw *)h); }
+
+extern "C" int swd_gdg_decode_batch(swd_gdg *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
+                                    double *min_pm, double *hist, int32_t hist_is_state) {
+    return swd_osdw_decode_batch((swd_osdw *)h, B, synd, out, stats, min_pm, hist, hist_is_state, nullptr);
+}
+
+extern "C" int swd_gdg_decode_batch_dev(swd_gdg *h, int32_t B, const uint8_t *synd, int64_t synd_stride, uint8_t *out,
+                                        int64_t out_stride, int32_t *stats, double *min_pm, void *stream) {
+    return swd_osdw_decode_batch_dev((swd_osdw *)h, B, synd, synd_stride, out, out_stride, stats, min_pm, nullptr, 0,
+                                     nullptr, stream);
+}
+
+extern "C" swd_pipeline *swd_pipeline_create_gdg(int32_t num_windows, const swd_window_desc *wins,
+                                                 const swd_graph_desc *chk, const swd_gdg_params *gp, int device) {
+    if (!gp || !wins || !chk || num_windows <= 0) { set_error("null argument"); return nullptr; }
+    if (check_device(device) || check_gdg_params(*gp)) return nullptr;
+    Plan *d = new Plan();
+    d->device = device;
+    d->gp = *gp;
+    d->kind = gp->mode + 1;
+    d->p.pre_max_iter = gp->max_iter; d->p.osd_order = -1; d->p.ms_scaling_factor = gp->ms_scaling_factor;
+    std::map<std::string, std::shared_ptr<Graph>> cache;
+    for (int i = 0; i < num_windows; ++i)
+        if (d->add_window(&wins[i].graph, wins[i].row0, wins[i].col0, wins[i].commit, cache)) { delete d; return nullptr; }
+    if (d->finalize(chk)) { delete d; return nullptr; }
+    return (swd_pipeline *)d;
 }

@@ -23,6 +23,7 @@ struct SwdLdsLayout {
     int32_t off_aux;   // inside scratch: first byte after the sort arrays
     int32_t off_cs;    // inside scratch: arrays of the higher-order OSD sweep
     int32_t cs_par;    // threads that evaluate OSD candidates concurrently (<= 256)
+    int32_t off_gdg;   // guessing decoders: persistent per-shot arrays (outside scratch), -1 if unused
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -32,6 +33,12 @@ struct SwdDecodeParams {
     int32_t hist_is_state; // history buffer carries state in and out (single-shot decode())
     int32_t zero_hist;     // start every decode from a zero history
     int32_t record_all;    // store the posterior of every iteration (history is an output)
+    // guessing decoders (bp_guessing_decoder.pyx): kind 0 = osd_window, 1 = bpgdg (single-thread gdg),
+    // 2 = bpgd, 3 = plain bp_history_decoder.  pre_iter / alpha double as max_iter / ms_scaling_factor.
+    int32_t kind;
+    int32_t max_iter_per_step, max_step, max_tree_depth, max_side_depth, max_side_branch_step, low_error_mode;
+    int32_t max_guess;
+    double gdg_factor;
 };
 
 // one window of the sliding-window plan: its graph + where it sits in the global DEM
@@ -65,6 +72,8 @@ struct SwdPipeArgs {
     double *hist;             // [B][4][nmax]
     int64_t hist_stride;      // doubles per shot
     uint8_t *osd0;            // nullable [B][n] (single-window use)
+    uint8_t *snap;            // guessing decoders: [B][snap_stride] snapshot stack in HBM
+    int64_t snap_stride;
     const uint32_t *obs_mask; // nullable [num_col]: bit k set if fault flips observable k (obs matrix)
     int32_t *shot_result;     // nullable [B][2]: predicted observable flips, residual syndrome != 0
     int64_t *prof;            // nullable [B][W][8]: 100 MHz ticks per phase (diagnostics only)
@@ -87,6 +96,8 @@ struct Lds {
     uint8_t *hard;      // [n]  bp_decoding
     int *flags;         // [32]
     int *scal;          // [32]
+    double *dbl;        // [24]
+    int *iaux;          // [32]
     int fpar;
 };
 
@@ -249,11 +260,12 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
 
 template <int NT, int VF, int DM, int KG, bool FULL>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
-                      const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done) {
+                      const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
+                      double alpha, bool force_unsat = false) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int dummy = g.E;
     const int vcnt = FULL ? n : nlive;
-    const double alpha = P.alpha, nalpha = -P.alpha;
+    const double nalpha = -alpha;
     const bool record_all = P.record_all != 0;
     uint32_t maskw[(VF + 3) / 4];
 #pragma unroll
@@ -272,7 +284,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #define BPT(x)
 #endif
     for (int it = 0; it < max_iter; ++it) {
-        bool unsat = false;
+        bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
         BPT(tc0);
         // keep the per-edge predicates from being hoisted out of the loop as ~2 SGPRs each
 #pragma unroll
@@ -393,7 +405,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #ifdef SWD_BPPROF
     if (!FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
 #endif
-    bool unsat = false;
+    bool unsat = force_unsat;
     for (int l = tid; l < m; l += NT)
         if (s.cn_val[l] >= 0 && s.par[l] != 0u) unsat = true;
     const bool any = block_any<NT>(unsat, s);
@@ -436,7 +448,7 @@ __device__ __forceinline__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint1
     for (int v = v0; v < v1; ++v)
         if (s.hard[v]) list[pos++] = (uint16_t)v;
     __syncthreads();
-    double *dres = (double *)(s.scal + 28);
+    double *dres = s.dbl;
     if (threadIdx.x == 0) {
         double pm = 0.0;
         for (int i = 0; i < total; ++i) pm += g.llr[list[i]];
@@ -862,6 +874,8 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
     s.hard = (uint8_t *)(smem + L.off_hard);
     s.flags = (int *)(smem + L.off_misc);
     s.scal = s.flags + 32;
+    s.dbl = (double *)(s.scal + 32);
+    s.iaux = (int *)(s.dbl + 24);
 }
 
 // osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
@@ -900,7 +914,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     uint16_t *list0 = (uint16_t *)s.scratch;
     R.t[1] = wall_clock64();
 
-    R.conv = bp_run<NT, VF, DM, KG, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it);
+    R.conv = bp_run<NT, VF, DM, KG, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha);
     R.pre_it = it;
     R.t[2] = wall_clock64();
     if (R.conv) {
@@ -1015,7 +1029,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     bp_init<VF, DM>(s, vc);
     __syncthreads();
     R.t[4] = wall_clock64();
-    R.conv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it);
+    R.conv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it, P.alpha);
     R.post_it = it;
     R.t[5] = wall_clock64();
     R.total_it = R.pre_it + R.post_it;
@@ -1077,13 +1091,15 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     R.exit_class = SWD_EXIT_OSD;
 }
 
+#include "swd_gdg_kernel.h"
+
 // One workgroup carries one shot through all W windows of the sliding-window plan
 // (/root/reference/osd.py:130-179): decode window t on the residual syndrome, commit the
 // leading `commit` columns into total_e_hat, fold the committed faults back into the
 // residual syndrome (osd.py:178, done sparsely on the shot's LDS copy), next window.  Windows
 // of one shot are sequentially dependent, shots are independent, so there is no inter-workgroup
 // traffic at all.  W = 1 with commit = 0 is the plain batched osd_window.decode.
-template <int NT, int VF, int DM, int KG>
+template <int NT, int VF, int DM, int KG, int KIND>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1105,7 +1121,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
 #ifdef SWD_BPPROF
         if (tid == 0) { s.scal[24] = s.scal[25] = s.scal[26] = s.scal[27] = 0; s.scal[20] = s.scal[21] = s.scal[22] = 0; }
 #endif
-        decode_window<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
+        if constexpr (KIND == 0)
+            decode_window<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
+        else
+            decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.snap + (int64_t)b * a.snap_stride, R);
         __syncthreads();
         if (a.total) {
             uint8_t *tot_b = a.total + (int64_t)b * a.total_stride + w.col0;

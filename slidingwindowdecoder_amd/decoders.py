@@ -216,6 +216,88 @@ class osd_window:
         return np.ascontiguousarray(self._hist.T)
 
 
+def _gdg_params(kwargs, mode):
+    new_n = kwargs.get("new_n", None)
+    return _lib.GdgParams(int(kwargs.get("max_iter", 50)), float(kwargs.get("ms_scaling_factor", 1.0)),
+                          int(kwargs.get("max_iter_per_step", 6)), int(kwargs.get("max_step", 25)),
+                          int(kwargs.get("max_tree_depth", 3)), int(kwargs.get("max_side_depth", 10)),
+                          int(kwargs.get("max_tree_branch_step", 10)), int(kwargs.get("max_side_branch_step", 10)),
+                          float(kwargs.get("gdg_factor", kwargs.get("gd_factor", 1.0))),
+                          int(new_n) if new_n else 0, int(bool(kwargs.get("low_error_mode", False))), mode)
+
+
+class bp_history_decoder:
+    """Plain min-sum BP with a 4-deep posterior history (reference: src/bp_guessing_decoder.pyx:5-158)
+    and base class of the guessing decoders.  ``multi_thread=True`` is accepted for call
+    compatibility but the deterministic single-thread search is what runs (the reference's threaded
+    ensemble is not reproducible run to run)."""
+    _mode = 2
+
+    def __init__(self, parity_check_matrix, **kwargs):
+        L = _lib.lib()
+        self._csr = _Csr(parity_check_matrix, kwargs.get("channel_probs"))
+        self.m, self.n = self._csr.m, self._csr.n
+        self.device = int(kwargs.get("device", 0))
+        p = _gdg_params(kwargs, self._mode)
+        self._h = L.swd_gdg_create(C.byref(self._csr.desc), C.byref(p), self.device)
+        if not self._h:
+            raise RuntimeError(f"swd_gdg_create failed: {_lib.last_error()}")
+        self._hist = np.zeros((4, self.n), dtype=np.float64)
+        self._last = dict(status=0, iters=0, min_pm=0.0)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().swd_gdg_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def decode(self, input_vector):
+        s = _as_synd(input_vector, self.m)
+        out = np.zeros(self.n, dtype=np.uint8)
+        st = np.zeros(_lib.STAT_WORDS, np.int32)
+        pm = np.zeros(1, np.float64)
+        rc = _lib.lib().swd_gdg_decode_batch(self._h, 1, s.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                             pm.ctypes.data, None, 0)
+        if rc:
+            raise RuntimeError(f"swd_gdg_decode_batch failed: {_lib.last_error()}")
+        self._last = dict(status=int(st[0]), iters=int(st[1]), min_pm=float(pm[0]))
+        return out.astype(np.int64)
+
+    def decode_batch(self, syndromes):
+        s = np.asarray(syndromes)
+        if s.ndim != 2 or s.shape[1] != self.m:
+            raise ValueError(f"syndromes must have shape [B, {self.m}]")
+        s = np.ascontiguousarray((s.astype(np.int64) & 0xFF).astype(np.uint8))
+        B = s.shape[0]
+        out = np.zeros((B, self.n), dtype=np.uint8)
+        st = np.zeros((B, _lib.STAT_WORDS), np.int32)
+        pm = np.zeros(B, np.float64)
+        rc = _lib.lib().swd_gdg_decode_batch(self._h, B, s.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                             pm.ctypes.data, None, 0)
+        if rc:
+            raise RuntimeError(f"swd_gdg_decode_batch failed: {_lib.last_error()}")
+        self.last_stats, self.last_min_pm = st, pm
+        self.last_status = st[:, 0].copy()
+        return out
+
+    @property
+    def converge(self):
+        return bool(self._last["status"] & STATUS_CONVERGE)
+
+
+class bpgdg_decoder(bp_history_decoder):
+    """BP + guided decimation guessing (reference: src/bp_guessing_decoder.pyx:160-442)."""
+    _mode = 0
+
+
+class bpgd_decoder(bp_history_decoder):
+    """BP + guided decimation (reference: src/bp_guessing_decoder.pyx:473-571)."""
+    _mode = 1
+
+
 class SlidingWindowDecoder:
     """The (W,F) sliding-window loop of the reference harness (/root/reference/osd.py:130-179) for
     a whole batch of shots in ONE launch: a workgroup carries a shot through all its windows,
@@ -224,15 +306,21 @@ class SlidingWindowDecoder:
     ``plan`` is a ``windows.WindowPlan``; decoder kwargs are those of ``osd_window`` and apply to
     every window like in osd.py:152-161."""
 
-    def __init__(self, plan, device=0, **kwargs):
+    def __init__(self, plan, device=0, decoder="osd_window", **kwargs):
         L = _lib.lib()
         self.plan = plan
         self.W = len(plan.windows)
         self.num_det, self.num_col = plan.chk.shape
-        method, order = _parse_osd_method(kwargs.get("osd_method", "osd_0"), kwargs.get("osd_order", 0))
-        new_n = kwargs.get("new_n", None)
-        p = _lib.OsdwParams(int(kwargs.get("pre_max_iter", 8)), int(kwargs.get("post_max_iter", 100)),
-                            float(kwargs.get("ms_scaling_factor", 1.0)), int(new_n) if new_n else 0, method, order)
+        self.decoder = decoder
+        if decoder == "osd_window":
+            method, order = _parse_osd_method(kwargs.get("osd_method", "osd_0"), kwargs.get("osd_order", 0))
+            new_n = kwargs.get("new_n", None)
+            p = _lib.OsdwParams(int(kwargs.get("pre_max_iter", 8)), int(kwargs.get("post_max_iter", 100)),
+                                float(kwargs.get("ms_scaling_factor", 1.0)), int(new_n) if new_n else 0, method, order)
+        elif decoder in ("bpgdg_decoder", "bpgd_decoder", "bp_history_decoder"):
+            p = _gdg_params(kwargs, {"bpgdg_decoder": 0, "bpgd_decoder": 1, "bp_history_decoder": 2}[decoder])
+        else:
+            raise ValueError(f"unknown window decoder {decoder!r}")
         self._keep = []
         descs = (_lib.WindowDesc * self.W)()
         for i, w in enumerate(plan.windows):
@@ -243,7 +331,8 @@ class SlidingWindowDecoder:
         chk = _Csr(plan.chk, plan.priors)
         self._keep.append(chk)
         self.device = int(device)
-        self._h = L.swd_pipeline_create(self.W, C.cast(descs, C.c_void_p), C.byref(chk.desc), C.byref(p), self.device)
+        create = L.swd_pipeline_create if decoder == "osd_window" else L.swd_pipeline_create_gdg
+        self._h = create(self.W, C.cast(descs, C.c_void_p), C.byref(chk.desc), C.byref(p), self.device)
         if not self._h:
             msg = _lib.last_error()
             if "OSD order" in msg or "invalid" in msg:

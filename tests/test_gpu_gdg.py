@@ -1,0 +1,126 @@
+"""GPU parity of the guessing decoders (bpgdg single-thread gdg(), bpgd, plain BP) against the
+reference's recorded runs and the oracle."""
+import numpy as np
+import pytest
+
+from tests import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _cls(tag):
+    import slidingwindowdecoder_amd as S
+    return {"gdg": S.bpgdg_decoder, "gdg_low": S.bpgdg_decoder, "gd": S.bpgd_decoder}[tag]
+
+
+@pytest.mark.parametrize("tag", ["gdg", "gdg_low", "gd"])
+def test_bb72_guessing_batch(tag):
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, tag + "_")
+    kw = fx.params(f, tag + "_params")
+    kw.pop("multi_thread", None)
+    dec = _cls(tag)(mat, channel_probs=priors, **kw)
+    tr = fx.Trace(f, tag + "_", *mat.shape)
+    out = dec.decode_batch(tr.synd)
+    bad = np.flatnonzero((out != tr.out).any(axis=1))
+    assert bad.size == 0, f"{bad.size}/{len(tr)} vectors differ, first {bad[:8]}"
+    assert np.array_equal((dec.last_status & 0x100) != 0, tr.converge != 0)
+
+
+def test_bb72_guessing_single_decode():
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, "gdg_")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread", None)
+    dec = _cls("gdg")(mat, channel_probs=priors, **kw)
+    tr = fx.Trace(f, "gdg_", *mat.shape)
+    for k in range(60):
+        out = dec.decode(tr.synd[k])
+        assert out.dtype == np.int64 and (out == tr.out[k]).all()
+        assert dec.converge == bool(tr.converge[k])
+
+
+def test_bb144_gdg_windows():
+    """Config 3 shape: every window of the recorded single-thread GDG sliding run."""
+    import slidingwindowdecoder_amd as S
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    nconv = 0
+    for wi in range(11):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        dec = S.bpgdg_decoder(mat, channel_probs=priors, **kw)
+        tr = fx.Trace(f, f"gdg_win{wi}_", *mat.shape)
+        out = dec.decode_batch(tr.synd)
+        bad = np.flatnonzero((out != tr.out).any(axis=1))
+        assert bad.size == 0, f"window {wi}: {bad.size} vectors differ, first {bad[:8]}"
+        assert np.array_equal((dec.last_status & 0x100) != 0, tr.converge != 0)
+        nconv += int((dec.last_status & 0xFF == 1).sum())
+    assert nconv > 300  # the decimation search really ran
+
+
+def test_bb144_gdg_pipeline():
+    import slidingwindowdecoder_amd as S
+    from tests.test_gpu_pipeline import load_plan
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    dec = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", **kw)
+    total = dec.decode(det)
+    want = fx.unpack(f["gdg_total"], plan.chk.shape[1])
+    bad = np.flatnonzero((total != want).any(axis=1))
+    assert bad.size == 0, f"{bad.size} shots differ: {bad[:8]}"
+
+
+def test_bb288_weight_two_kat():
+    """Syndrome code.ipynb cell 6 (see tests/test_kat_syndrome_code.py): the device follows the
+    deterministic single-thread search and reproduces its 22 converging syndromes vector for vector."""
+    import slidingwindowdecoder_amd as S
+    from slidingwindowdecoder_amd.codes import bb_code
+    f = fx.load("bb288_hx_wt2_kat.npz")
+    code, _, _ = bb_code(288)
+    pairs = f["pairs"]
+    synd = np.zeros((len(pairs), 144), np.uint8)
+    for k, (i, j) in enumerate(pairs):
+        synd[k, i] = synd[k, j] = 1
+    dec = S.bpgdg_decoder(code.hx, channel_probs=np.ones(288) * 0.01, **fx.params(f, "params"))
+    out = dec.decode_batch(synd)
+    assert np.array_equal(out, fx.unpack(f["single_out"], 288))
+    conv = (dec.last_status & 0x100) != 0
+    got = [[int(i), int(j), int(out[k].sum())] for k, (i, j) in enumerate(pairs) if conv[k]]
+    assert got == f["single"].tolist()
+    assert [0, 72, 14] in got and [1, 73, 14] in got
+
+
+def test_random_codes_vs_oracle():
+    from oracle import oracle as O
+    import slidingwindowdecoder_amd as S
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        m, n = int(rng.integers(8, 21)), int(rng.integers(40, 160))
+        H = (rng.random((m, n)) < 3.0 / m).astype(np.uint8)
+        for c in range(n):
+            if H[:, c].sum() == 0:
+                H[rng.integers(m), c] = 1
+        for r in range(m):
+            if H[r].sum() == 0:
+                H[r, rng.integers(n)] = 1
+        if H.sum(axis=0).max() > 8:
+            continue
+        p = rng.uniform(0.01, 0.08, size=n)
+        kw = dict(channel_probs=p, max_iter=int(rng.integers(4, 9)), ms_scaling_factor=float(rng.choice([1.0, 0.625])),
+                  max_iter_per_step=int(rng.choice([4, 6, 8])), max_step=int(rng.integers(5, 25)),
+                  max_tree_depth=int(rng.integers(1, 4)), max_side_depth=int(rng.integers(4, 12)),
+                  max_side_branch_step=int(rng.integers(3, 12)), gdg_factor=float(rng.choice([1.0, 0.625])),
+                  low_error_mode=bool(trial % 2), new_n=int(rng.integers(2 * m, n + 1)))
+        e = (rng.random((200, n)) < p).astype(np.uint8)
+        synd = (e @ H.T) % 2
+        for cls_d, cls_o in ((S.bpgdg_decoder, O.bpgdg_decoder), (S.bpgd_decoder, O.bpgd_decoder)):
+            dec, ora = cls_d(H, **kw), cls_o(H, **kw)
+            out = dec.decode_batch(synd)
+            for k in range(synd.shape[0]):
+                want = ora.decode(synd[k])
+                assert (out[k] == want).all(), f"trial {trial} shot {k} {cls_d.__name__}"
+                assert bool(dec.last_status[k] & 0x100) == bool(ora.converge)
