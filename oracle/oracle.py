@@ -52,10 +52,20 @@ class _GdgParams(C.Structure):
                 ("gdg_factor", C.c_double), ("new_n", C.c_int32), ("low_error_mode", C.c_int32)]
 
 
+class _Bp4Params(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("ms_scaling_factor", C.c_double), ("osd_method", C.c_int32),
+                ("osd_order", C.c_int32)]
+
+
 def lib():
     global _LIB
     if _LIB is None:
         L = C.CDLL(build())
+        L.swo_bp4_create.restype = C.c_void_p
+        L.swo_bp4_create.argtypes = [C.c_int] * 3 + [C.c_void_p] * 7 + [C.POINTER(_Bp4Params)]
+        L.swo_bp4_free.argtypes = [C.c_void_p]
+        L.swo_bp4_decode.argtypes = [C.c_void_p] * 5 + [C.POINTER(_Result)] + [C.c_void_p] * 3
+        L.swo_bp4_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.swo_graph_create.restype = C.c_void_p
         L.swo_graph_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.swo_graph_free.argtypes = [C.c_void_p]
@@ -238,3 +248,48 @@ class bpgdg_decoder(_GdgBase):
 
 class bpgd_decoder(_GdgBase):
     _mode = 1
+
+
+class bp4_osd:
+    """src/bp4_osd.pyx restated (quaternary BP + one OSD per basis)."""
+
+    def __init__(self, Hx, Hz, **kw):
+        if not (isinstance(Hx, np.ndarray) or sp.issparse(Hx)):
+            raise TypeError("The input matrix is of an invalid type. Please input a np.ndarray or scipy.sparse.spmatrix object.")
+        if Hx.shape[1] != Hz.shape[1]:
+            raise ValueError("Hx, Hz blocklength does not match!")
+        ax, az = sp.csr_matrix(Hx), sp.csr_matrix(Hz)
+        for a in (ax, az):
+            a.eliminate_zeros(); a.sort_indices()
+        self.mx, self.n = ax.shape
+        self.mz = az.shape[0]
+        px, py, pz = (np.ascontiguousarray(kw.get(k), dtype=np.float64) for k in ("channel_probs_x", "channel_probs_y", "channel_probs_z"))
+        if len(px) != self.n:
+            raise ValueError(f"The length of the channel probability vector must be eqaul to the block length n={self.n}.")
+        method, order = parse_osd_method(kw.get("osd_method", "osd_0"), kw.get("osd_order", 0))
+        p = _Bp4Params(int(kw.get("max_iter", 32)), float(kw.get("ms_scaling_factor", 1.0)), method, order)
+        self._keep = [np.ascontiguousarray(x, dtype=np.int32) for x in (ax.indptr, ax.indices, az.indptr, az.indices)] + [px, py, pz]
+        self._h = lib().swo_bp4_create(self.mx, self.mz, self.n, *[k.ctypes.data for k in self._keep], C.byref(p))
+        if not self._h:
+            raise ValueError("For this code, the OSD order should be set in the range 0<=osd_oder<=n-rank.")
+        self._res = _Result()
+        self._lpr = np.zeros((self.n, 3))
+        self._o0x = np.zeros(self.n, np.uint8); self._o0z = np.zeros(self.n, np.uint8)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().swo_bp4_free(self._h)
+            self._h = None
+
+    def decode(self, sx, sz):
+        sx, sz = _synd_u8(sx, self.mx), _synd_u8(sz, self.mz)
+        ox, oz = np.zeros(self.n, np.uint8), np.zeros(self.n, np.uint8)
+        lib().swo_bp4_decode(self._h, sx.ctypes.data, sz.ctypes.data, ox.ctypes.data, oz.ctypes.data, C.byref(self._res),
+                             self._lpr.ctypes.data, self._o0x.ctypes.data, self._o0z.ctypes.data)
+        return np.stack([ox, oz]).astype(np.int64)
+
+    converge = property(lambda self: self._res.converge)
+    bp_iteration = property(lambda self: self._res.bp_iteration)
+    log_prob_ratios = property(lambda self: self._lpr.copy())
+    osd0_decoding_x = property(lambda self: self._o0x.astype(np.int64))
+    osd0_decoding_z = property(lambda self: self._o0z.astype(np.int64))

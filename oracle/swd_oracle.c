@@ -939,3 +939,231 @@ int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* bp4_osd  (src/bp4_osd.pyx)                                                            */
+/* ------------------------------------------------------------------------------------ */
+#include <float.h>
+#ifndef M_LN2
+#define M_LN2 0.693147180559945309417232121458176568 /* math.h value */
+#endif
+
+static double log1pexp_(double x) { /* src/include/bpgd.cpp:399-406 */
+    if (x > -log(DBL_EPSILON)) return x + log1p(exp(-x));
+    return log1p(exp(x));
+}
+static double logaddexp_(double x, double y) { /* src/include/bpgd.cpp:408-416 */
+    double const tmp = x - y;
+    if (x == y) return x + M_LN2;
+    if (tmp > 0) return x + log1pexp_(-tmp);
+    else if (tmp <= 0) return y + log1pexp_(tmp);
+    return tmp;
+}
+
+struct swo_bp4 {
+    tanner hx, hz;
+    swo_bp4_params p;
+    int mx, mz, n, rank_x, rank_z, kx;
+    double *llr_x, *llr_y, *llr_z, *prior_x, *prior_z, *lpr_x, *lpr_y, *lpr_z, *llr_post;
+    signed char *synd_x, *synd_z, *cn_x, *cn_z, *vn, *dec_x, *dec_z, *osd0_x, *osd0_z, *osdw_x, *osdw_z;
+    signed char *scratch, *y, *g, *Htx, *work, *yR;
+    int *cols, *orig_cols, *Ht_cols;
+    lu_t lux, luz;
+    int bp_iteration, converge;
+};
+
+int swo_bp4_ranks(const swo_bp4 *d, int32_t *rx, int32_t *rz) { *rx = d->rank_x; *rz = d->rank_z; return 0; }
+
+swo_bp4 *swo_bp4_create(int mx, int mz, int n, const int32_t *rpx, const int32_t *cix, const int32_t *rpz,
+                        const int32_t *ciz, const double *px, const double *py, const double *pz,
+                        const swo_bp4_params *p) {
+    swo_bp4 *d = xcalloc(1, sizeof(*d));
+    d->p = *p; d->mx = mx; d->mz = mz; d->n = n;
+    if (d->p.osd_method == 0) d->p.osd_order = 0;
+    tanner_init_csr(&d->hx, mx, n, rpx, cix);
+    tanner_init_csr(&d->hz, mz, n, rpz, ciz);
+    d->rank_x = gf2_rank_csr(&d->hx); d->rank_z = gf2_rank_csr(&d->hz);
+    int kmin = (n - d->rank_x) < (n - d->rank_z) ? (n - d->rank_x) : (n - d->rank_z);
+    if (d->p.osd_order > kmin) { tanner_free(&d->hx); tanner_free(&d->hz); free(d); return NULL; } /* bp4_osd.pyx:92-98 */
+    d->kx = n - d->rank_x; /* kz = kx in the reference (bp4_osd.pyx:103-104); both bases use kx (:284) */
+    double **dd[] = {&d->llr_x, &d->llr_y, &d->llr_z, &d->prior_x, &d->prior_z, &d->lpr_x, &d->lpr_y, &d->lpr_z, &d->llr_post};
+    for (unsigned i = 0; i < sizeof(dd) / sizeof(dd[0]); i++) *dd[i] = xcalloc(n, sizeof(double));
+    int mm = mx > mz ? mx : mz;
+    signed char **cn[] = {&d->vn, &d->dec_x, &d->dec_z, &d->osd0_x, &d->osd0_z, &d->osdw_x, &d->osdw_z, &d->y};
+    for (unsigned i = 0; i < sizeof(cn) / sizeof(cn[0]); i++) *cn[i] = xcalloc(n, 1);
+    signed char **cm[] = {&d->synd_x, &d->synd_z, &d->cn_x, &d->cn_z, &d->scratch, &d->g, &d->Htx, &d->work};
+    for (unsigned i = 0; i < sizeof(cm) / sizeof(cm[0]); i++) *cm[i] = xcalloc(mm, 1);
+    d->yR = xcalloc(mm + 1, 1);
+    d->cols = xcalloc(n, sizeof(int)); d->orig_cols = xcalloc(n, sizeof(int)); d->Ht_cols = xcalloc(n + 1, sizeof(int));
+    if (d->p.osd_order > -1) { lu_init(&d->lux, &d->hx, d->rank_x); lu_init(&d->luz, &d->hz, d->rank_z); }
+    for (int v = 0; v < n; v++) { /* bp4_osd.pyx:127-137 */
+        double num = px[v] + py[v] + pz[v];
+        num = 1.0 - num;
+        d->llr_x[v] = log(num / px[v]); d->llr_y[v] = log(num / py[v]); d->llr_z[v] = log(num / pz[v]);
+        double denom = px[v] + py[v];
+        d->prior_x[v] = log((1.0 - denom) / denom);
+        denom = pz[v] + py[v];
+        d->prior_z[v] = log((1.0 - denom) / denom);
+    }
+    return d;
+}
+
+void swo_bp4_free(swo_bp4 *d) {
+    if (!d) return;
+    tanner_free(&d->hx); tanner_free(&d->hz);
+    free(d->llr_x); free(d->llr_y); free(d->llr_z); free(d->prior_x); free(d->prior_z); free(d->lpr_x); free(d->lpr_y);
+    free(d->lpr_z); free(d->llr_post); free(d->vn); free(d->dec_x); free(d->dec_z); free(d->osd0_x); free(d->osd0_z);
+    free(d->osdw_x); free(d->osdw_z); free(d->y); free(d->synd_x); free(d->synd_z); free(d->cn_x); free(d->cn_z);
+    free(d->scratch); free(d->g); free(d->Htx); free(d->work); free(d->yR); free(d->cols); free(d->orig_cols); free(d->Ht_cols);
+    if (d->lux.B) lu_free(&d->lux);
+    if (d->luz.B) lu_free(&d->luz);
+    free(d);
+}
+
+/* cn_update_all (bp4_osd.pyx:483-529): plain min-sum on every check, no VN mask */
+static void bp4_cn_update(tanner *t, const signed char *cn_mask, double alpha) {
+    for (int cn = 0; cn < t->m; cn++) {
+        double temp = 1e308;
+        int sgn = (cn_mask[cn] == 1) ? 1 : 0;
+        for (int e = t->row_ptr[cn]; e < t->row_ptr[cn + 1]; e++) {
+            t->c2b[e] = temp; t->sgn[e] = sgn;
+            if (t->b2c[e] > 50.0) t->b2c[e] = 50.0;
+            else if (t->b2c[e] < -50.0) t->b2c[e] = -50.0;
+            if (fabs(t->b2c[e]) < temp) temp = fabs(t->b2c[e]);
+            if (t->b2c[e] <= 0) sgn = 1 - sgn;
+        }
+        temp = 1e308; sgn = 0;
+        for (int e = t->row_ptr[cn + 1] - 1; e >= t->row_ptr[cn]; e--) {
+            if (temp < t->c2b[e]) t->c2b[e] = temp;
+            t->sgn[e] += sgn;
+            t->c2b[e] *= ((t->sgn[e] % 2 == 0) ? 1.0 : -1.0) * alpha;
+            if (fabs(t->b2c[e]) < temp) temp = fabs(t->b2c[e]);
+            if (t->b2c[e] <= 0) sgn = 1 - sgn;
+        }
+    }
+}
+
+/* vn_update (bp4_osd.pyx:533-589) */
+static void bp4_vn_update(swo_bp4 *d, int vn) {
+    tanner *hx = &d->hx, *hz = &d->hz;
+    double llrx = d->llr_x[vn], llry = d->llr_y[vn], llrz = d->llr_z[vn];
+    double llrx_hx = 0.0;
+    for (int k = hz->col_ptr[vn]; k < hz->col_ptr[vn + 1]; k++) llrx_hx += hz->c2b[hz->c2r[k]];
+    double llrz_hz = 0.0;
+    for (int k = hx->col_ptr[vn]; k < hx->col_ptr[vn + 1]; k++) llrz_hz += hx->c2b[hx->c2r[k]];
+    double llry_all = llrx_hx + llrz_hz + llry;
+    llrx_hx = llrx_hx + llrx;
+    llrz_hz = llrz_hz + llrz;
+    d->lpr_x[vn] = llrx_hx; d->lpr_y[vn] = llry_all; d->lpr_z[vn] = llrz_hz;
+    int idx;
+    if (0 < llrx_hx && 0 < llry_all && 0 < llrz_hz) idx = 0;
+    else if (llrx_hx < llry_all && llrx_hx < llrz_hz) idx = 1;
+    else if (llry_all > llrz_hz) idx = 2;
+    else idx = 3;
+    d->dec_x[vn] = (signed char)(idx % 2);
+    d->dec_z[vn] = (signed char)(idx / 2);
+    double num_hx = log1pexp_(-1. * llrx_hx);
+    for (int k = hx->col_ptr[vn]; k < hx->col_ptr[vn + 1]; k++) {
+        int e = hx->c2r[k];
+        double msg = hx->c2b[e];
+        double a = llrz_hz - msg, b = llry_all - msg;
+        hx->b2c[e] = num_hx - logaddexp_(-1. * a, -1. * b);
+    }
+    double num_hz = log1pexp_(-1. * llrz_hz);
+    for (int k = hz->col_ptr[vn]; k < hz->col_ptr[vn + 1]; k++) {
+        int e = hz->c2r[k];
+        double msg = hz->c2b[e];
+        double a = llrx_hx - msg, b = llry_all - msg;
+        hz->b2c[e] = num_hz - logaddexp_(-1. * a, -1. * b);
+    }
+}
+
+/* osd(basis) (bp4_osd.pyx:261-368) */
+static void bp4_osd_basis(swo_bp4 *d, int is_x) {
+    const int n = d->n;
+    tanner *H = is_x ? &d->hx : &d->hz;
+    lu_t *lu = is_x ? &d->lux : &d->luz;
+    const int rank = is_x ? d->rank_x : d->rank_z, m = H->m;
+    int k = d->kx;
+    if (k > n - rank) k = n - rank; /* the reference would read past the pivot block; identical when rank_x == rank_z */
+    const signed char *synd = is_x ? d->synd_x : d->synd_z;
+    signed char *osd0 = is_x ? d->osd0_z : d->osd0_x, *osdw = is_x ? d->osdw_z : d->osdw_x;
+    const double *prior = is_x ? d->prior_x : d->prior_z;
+    for (int v = 0; v < n; v++)
+        d->llr_post[v] = is_x ? log1pexp_(-1. * d->lpr_x[v]) - logaddexp_(-1. * d->lpr_y[v], -1. * d->lpr_z[v])
+                              : log1pexp_(-1. * d->lpr_z[v]) - logaddexp_(-1. * d->lpr_y[v], -1. * d->lpr_x[v]);
+    index_sort(d->llr_post, d->cols, n);
+    for (int v = 0; v < n; v++) d->orig_cols[v] = d->cols[v];
+    lu_decomp_osd(lu, H, d->cols);
+    lu_solve(lu, d->cols, synd, osd0, d->work, d->yR);
+    double min_pm = 0.0;
+    for (int v = 0; v < n; v++) { if (osd0[v]) min_pm += prior[v]; osdw[v] = osd0[v]; }
+    if (d->p.osd_order == 0) return;
+    int counter = 0;
+    for (int i = 0; i < n; i++) {
+        int cn = d->orig_cols[i], in_pivot = 0;
+        for (int j = 0; j < rank; j++) if (d->cols[j] == cn) { in_pivot = 1; break; }
+        if (!in_pivot) { if (counter < k) d->Ht_cols[counter] = cn; counter++; }
+    }
+    const int w = d->p.osd_order;
+    const int kset = n - rank; /* osd_cs_setup_x/z use n - rank_x / n - rank_z (bp4_osd.pyx:153,176) */
+    long ncand = (d->p.osd_method == 1) ? (1L << w) : (long)kset + (long)w * (w - 1) / 2;
+    signed char *x = xcalloc(k > kset ? k : kset + 1, 1);
+    for (long l = 0; l < ncand; l++) {
+        memset(x, 0, k > kset ? k : kset + 1);
+        if (d->p.osd_method == 1) { long v = l; for (int i = 0; i < kset && v; i++) { x[i] = (signed char)(v % 2); v /= 2; } }
+        else if (l < kset) x[l] = 1;
+        else { long q = l - kset; int i = 0; while (q >= w - 1 - i) { q -= w - 1 - i; i++; } x[i] = 1; x[i + 1 + q] = 1; }
+        for (int c = 0; c < m; c++) d->Htx[c] = 0;
+        for (int j = 0; j < k; j++)
+            if (x[j]) { int v = d->Ht_cols[j]; for (int q = H->col_ptr[v]; q < H->col_ptr[v + 1]; q++) d->Htx[H->row_idx[q]] ^= 1; }
+        for (int c = 0; c < m; c++) d->g[c] = (signed char)(synd[c] ^ d->Htx[c]);
+        lu_solve(lu, d->cols, d->g, d->y, d->work, d->yR);
+        for (int j = 0; j < k; j++) d->y[d->Ht_cols[j]] = x[j];
+        double pm = 0.0;
+        for (int v = 0; v < n; v++) if (d->y[v]) pm += prior[v];
+        if (pm < min_pm) { min_pm = pm; for (int v = 0; v < n; v++) osdw[v] = d->y[v]; }
+    }
+    free(x);
+}
+
+int swo_bp4_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *out_x, uint8_t *out_z,
+                   swo_result *res, double *lpr, uint8_t *osd0_x, uint8_t *osd0_z) {
+    const int n = d->n;
+    for (int c = 0; c < d->mx; c++) d->synd_x[c] = d->cn_x[c] = (signed char)sx[c];
+    for (int c = 0; c < d->mz; c++) d->synd_z[c] = d->cn_z[c] = (signed char)sz[c];
+    d->bp_iteration = 0;
+    for (int v = 0; v < n; v++) { d->vn[v] = -1; d->dec_x[v] = d->dec_z[v] = 0; }
+    for (int v = 0; v < n; v++) { /* bp_init bp4_osd.pyx:425-442 */
+        double llrx = d->llr_x[v], llry = d->llr_y[v], llrz = d->llr_z[v];
+        double msg_x = log1pexp_(-1. * llrx) - logaddexp_(-1. * llry, -1. * llrz);
+        for (int k = d->hx.col_ptr[v]; k < d->hx.col_ptr[v + 1]; k++) d->hx.b2c[d->hx.c2r[k]] = msg_x;
+        double msg_z = log1pexp_(-1. * llrz) - logaddexp_(-1. * llry, -1. * llrz);
+        for (int k = d->hz.col_ptr[v]; k < d->hz.col_ptr[v + 1]; k++) d->hz.b2c[d->hz.c2r[k]] = msg_z;
+    }
+    d->converge = 0;
+    for (int it = 0; it < d->p.max_iter; it++) { /* bp4_decode_llr :444-481 */
+        d->bp_iteration += 1;
+        bp4_cn_update(&d->hx, d->cn_x, d->p.ms_scaling_factor);
+        bp4_cn_update(&d->hz, d->cn_z, d->p.ms_scaling_factor);
+        for (int v = 0; v < n; v++) bp4_vn_update(d, v);
+        if (syndrome_matches(&d->hx, d->dec_z, d->synd_x, d->scratch) &&
+            syndrome_matches(&d->hz, d->dec_x, d->synd_z, d->scratch)) { d->converge = 1; break; }
+    }
+    int exit_class;
+    const signed char *rx = d->dec_x, *rz = d->dec_z;
+    if (d->converge) {
+        for (int v = 0; v < n; v++) { d->osd0_x[v] = d->dec_x[v]; d->osd0_z[v] = d->dec_z[v]; }
+        exit_class = SWO_EXIT_PRE;
+    } else if (d->p.osd_order > -1) {
+        bp4_osd_basis(d, 1);
+        bp4_osd_basis(d, 0);
+        rx = d->osdw_x; rz = d->osdw_z;
+        exit_class = SWO_EXIT_OSD;
+    } else exit_class = SWO_EXIT_NO_OSD;
+    for (int v = 0; v < n; v++) { out_x[v] = (uint8_t)rx[v]; out_z[v] = (uint8_t)rz[v]; }
+    if (lpr) for (int v = 0; v < n; v++) { lpr[3 * v] = d->lpr_x[v]; lpr[3 * v + 1] = d->lpr_y[v]; lpr[3 * v + 2] = d->lpr_z[v]; }
+    if (osd0_x) for (int v = 0; v < n; v++) { osd0_x[v] = (uint8_t)d->osd0_x[v]; osd0_z[v] = (uint8_t)d->osd0_z[v]; }
+    if (res) { res->converge = d->converge; res->bp_iteration = d->bp_iteration; res->exit_class = exit_class; res->reserved = 0; res->min_pm = 0.0; }
+    return 0;
+}

@@ -99,6 +99,25 @@ void swo_gdg_clear_history(swo_gdg *d);
 int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_result *res);
 const double *swo_gdg_history(const swo_gdg *d);
 
+/* ---- bp4_osd (src/bp4_osd.pyx): quaternary min-sum BP on (Hx, Hz) + one OSD per basis ---- */
+typedef struct {
+    int32_t max_iter;
+    double ms_scaling_factor;
+    int32_t osd_method; /* 0 osd_0, 1 osd_e, 2 osd_cs */
+    int32_t osd_order;  /* -1: no OSD */
+} swo_bp4_params;
+
+typedef struct swo_bp4 swo_bp4;
+/* Hx: mx x n CSR, Hz: mz x n CSR; px/py/pz: n Pauli error probabilities */
+swo_bp4 *swo_bp4_create(int mx, int mz, int n, const int32_t *rpx, const int32_t *cix, const int32_t *rpz,
+                        const int32_t *ciz, const double *px, const double *py, const double *pz,
+                        const swo_bp4_params *p);
+void swo_bp4_free(swo_bp4 *d);
+/* out_x[n], out_z[n] = rows 0 and 1 of the array decode() returns; lpr[n*3] nullable = log_prob_ratios */
+int swo_bp4_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *out_x, uint8_t *out_z,
+                   swo_result *res, double *lpr, uint8_t *osd0_x, uint8_t *osd0_z);
+int swo_bp4_ranks(const swo_bp4 *d, int32_t *rank_x, int32_t *rank_z);
+
 #ifdef __cplusplus
 }
 #endif

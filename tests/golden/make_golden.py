@@ -322,10 +322,47 @@ def gen_kat288(ref):
     save("bb288_hx_wt2_kat.npz", pairs=np.array(pairs, np.int32), params=json.dumps(kw), **res)
 
 
+def gen_bp4(ref):
+    """bp4_osd (src/bp4_osd.pyx) on BB codes under depolarizing noise, the setting of Misc.ipynb cell 2
+    (max_iter=100, ms_scaling_factor=0.625, osd_cs order 10) plus osd_e / osd_0 variants."""
+    from slidingwindowdecoder_amd.codes import bb_code
+    arrs = {}
+    sets = [("bb72_cs10", 72, 0.08, dict(max_iter=32, ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10), 300),
+            ("bb144_cs10", 144, 0.10, dict(max_iter=100, ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10), 300),
+            ("bb72_e5", 72, 0.12, dict(max_iter=16, ms_scaling_factor=1.0, osd_method="osd_e", osd_order=5), 200),
+            ("bb144_osd0", 144, 0.12, dict(max_iter=20, ms_scaling_factor=0.8, osd_method="osd_0", osd_order=0), 200)]
+    for tag, N, p, kw, shots in sets:
+        code, _, _ = bb_code(N)
+        n = code.N
+        px = py = pz = p / 3 * np.ones(n)
+        dec = ref.bp4_osd(code.hx.astype(int), code.hz.astype(int), channel_probs_x=px, channel_probs_y=py,
+                          channel_probs_z=pz, **kw)
+        rng = np.random.default_rng(N + shots)
+        sxs, szs, outs, conv, its, lprs, o0 = [], [], [], [], [], [], []
+        for _ in range(shots):
+            noise = rng.uniform(0, 1, n)
+            err_z = np.logical_and(noise > px, noise < px + py + pz)
+            err_x = noise < px + py
+            sx = (err_z @ code.hx.T) % 2
+            sz = (err_x @ code.hz.T) % 2
+            out = dec.decode(sx, sz)
+            sxs.append(sx); szs.append(sz); outs.append(np.asarray(out, np.uint8))
+            conv.append(int(dec.converge)); its.append(int(dec.bp_iteration))
+            lprs.append(np.asarray(dec.log_prob_ratios))
+            o0.append(np.stack([dec.osd0_decoding_x, dec.osd0_decoding_z]).astype(np.uint8))
+        arrs.update({tag + "_N": np.int32(N), tag + "_p": np.float64(p), tag + "_params": json.dumps(kw),
+                     tag + "_sx": pack(np.array(sxs)), tag + "_sz": pack(np.array(szs)),
+                     tag + "_out": pack(np.array(outs)), tag + "_osd0": pack(np.array(o0)),
+                     tag + "_converge": np.array(conv, np.uint8), tag + "_bp_iteration": np.array(its, np.int32),
+                     tag + "_lpr": np.array(lprs[:64])})
+        print(f"  bp4/{tag}: converge {sum(conv)}/{shots}")
+    save("bp4_depolarizing.npz", **arrs)
+
+
 def main():
     ensure_reference()
     import src as ref
-    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288"]
+    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4"]
     if "bb72" in which:
         gen_bb72(ref)
     if "bb144" in which:
@@ -334,6 +371,8 @@ def main():
         gen_bb288(ref)
     if "kat288" in which:
         gen_kat288(ref)
+    if "bp4" in which:
+        gen_bp4(ref)
 
 
 if __name__ == "__main__":
