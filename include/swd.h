@@ -132,6 +132,30 @@ int swd_gdg_decode_batch_dev(swd_gdg *d, int32_t B, const uint8_t *synd, int64_t
                              uint8_t *out, int64_t out_stride, int32_t *stats, double *min_pm,
                              void *stream);
 
+/* ---- quaternary BP + OSD -------------------------------------------------------------------
+ * Replaces bp4_osd(Hx, Hz, channel_probs_x/y/z, max_iter, ms_scaling_factor, osd_method, osd_order)
+ * (/root/reference/src/bp4_osd.pyx:8-140) and its decode(sx, sz) (bp4_osd.pyx:197-221).  The
+ * variable-node update uses exp/log1p, so posterior LLRs agree with the reference to rounding of the
+ * math library (not bit for bit); decisions are equal except on exact ties of those LLRs. */
+typedef struct swd_bp4_params {
+    int32_t max_iter;          /* default 32 */
+    double ms_scaling_factor;
+    int32_t osd_method;        /* 0 osd_0, 1 osd_e, 2 osd_cs */
+    int32_t osd_order;         /* -1 disables OSD */
+} swd_bp4_params;
+typedef struct swd_bp4 swd_bp4;
+swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_desc *hz, const double *px, const double *py,
+                        const double *pz, const swd_bp4_params *p, int device); /* channel_probs of hx/hz ignored */
+void swd_bp4_destroy(swd_bp4 *d);
+int swd_bp4_info(const swd_bp4 *d, int32_t *mx, int32_t *mz, int32_t *n, int32_t *rank_x, int32_t *rank_z);
+/* sx [B*mx], sz [B*mz] -> out [B*2*n] (row 0: X string, row 1: Z string, like the (2, n) array decode()
+ * returns); stats [B*SWD_STAT_WORDS] ([0] exit|converge, [1] bp_iteration); lpr [B*3*n] nullable posterior
+ * LLRs laid out [shot][x|y|z][vn] (property log_prob_ratios transposed); osd0 [B*2*n] nullable. */
+int swd_bp4_decode_batch(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                         int32_t *stats, double *lpr, uint8_t *osd0);
+int swd_bp4_decode_batch_dev(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                             int32_t *stats, double *lpr, uint8_t *osd0, void *stream);
+
 /* ---- sliding-window pipeline ---------------------------------------------------------------
  * Replaces the window loop of the reference harness (/root/reference/osd.py:130-179, identical in
  * guessing.py:135-214 and the notebooks): for every shot, decode window t on the residual

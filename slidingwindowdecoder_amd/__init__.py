@@ -3,7 +3,7 @@
 Host-side problem construction (codes, circuit, windows) is pure numpy/scipy and importable
 anywhere; the decoder classes need libswd_hip.so and a gfx950 GPU and raise otherwise.
 """
-from .decoders import (SlidingWindowDecoder, bp_history_decoder, bpgd_decoder, bpgdg_decoder,  # noqa: F401
-                       osd_window)
+from .decoders import (SlidingWindowDecoder, bp4_osd, bp_history_decoder, bpgd_decoder,  # noqa: F401
+                       bpgdg_decoder, osd_window)
 
-__all__ = ["osd_window", "bpgdg_decoder", "bpgd_decoder", "bp_history_decoder", "SlidingWindowDecoder"]
+__all__ = ["osd_window", "bpgdg_decoder", "bpgd_decoder", "bp_history_decoder", "bp4_osd", "SlidingWindowDecoder"]

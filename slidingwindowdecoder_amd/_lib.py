@@ -38,6 +38,11 @@ class GdgParams(C.Structure):
                 ("mode", C.c_int32)]
 
 
+class Bp4Params(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("ms_scaling_factor", C.c_double), ("osd_method", C.c_int32),
+                ("osd_order", C.c_int32)]
+
+
 # every symbol include/swd.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = [
@@ -55,6 +60,11 @@ SYMBOLS = [
     ("swd_gdg_destroy", None, [_vp]),
     ("swd_gdg_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32]),
     ("swd_gdg_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    ("swd_bp4_create", _vp, [C.POINTER(GraphDesc), C.POINTER(GraphDesc), _vp, _vp, _vp, C.POINTER(Bp4Params), C.c_int]),
+    ("swd_bp4_destroy", None, [_vp]),
+    ("swd_bp4_info", C.c_int, [_vp] + [C.POINTER(_i32)] * 5),
+    ("swd_bp4_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("swd_bp4_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("swd_pipeline_create_gdg", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(GdgParams), C.c_int]),
     ("swd_pipeline_create", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
     ("swd_pipeline_destroy", None, [_vp]),

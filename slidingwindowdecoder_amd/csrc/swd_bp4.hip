@@ -1,0 +1,168 @@
+// C-ABI host side of the quaternary decoder (include/swd.h: swd_bp4_*), replacing the reference's
+// bp4_osd extension type (/root/reference/src/bp4_osd.pyx).
+#include <math.h>
+#include <string.h>
+
+#include "swd_host.h"
+#include "swd_bp4_kernel.h"
+
+namespace swd {
+int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L); // swd_osdw.hip
+
+struct Bp4 {
+    Graph gx, gz;
+    swd_bp4_params p{};
+    int device = 0, nt = 256, dm = 4, n = 0;
+    SwdLdsLayout Lx{}, Lz{};
+    SwdBp4Layout L{};
+    DevBuf llr, sx, sz, out, osd0, stats, lpr;
+    const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
+};
+
+template <int NT, int DM>
+static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+    static int lds_limit[64] = {0};
+    if (d->L.total > lds_limit[d->device & 63]) {
+        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<NT, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
+        lds_limit[d->device & 63] = d->L.total;
+    }
+    hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(a.B), dim3(NT), d->L.total, st, a);
+    SWD_HIP(hipGetLastError());
+    return 0;
+}
+} // namespace swd
+
+using namespace swd;
+
+extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_desc *hz, const double *px, const double *py,
+                                   const double *pz, const swd_bp4_params *p, int device) {
+    if (!hx || !hz || !px || !py || !pz || !p) { set_error("null argument"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: the MI355X decoder has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) { set_error("device %d not usable", device); return nullptr; }
+    if (hx->n != hz->n) { set_error("Hx, Hz blocklength does not match!"); return nullptr; }
+    Bp4 *d = new Bp4();
+    d->device = device; d->p = *p; d->n = hx->n;
+    const int n = hx->n;
+    if (d->p.osd_method == 0) d->p.osd_order = 0;
+    if (d->p.osd_method < 0 || d->p.osd_method > 2) { set_error("ERROR: OSD method '%d' invalid.", d->p.osd_method); delete d; return nullptr; }
+    // OSD path metrics use prior_llr_x = log((1-(px+py))/(px+py)), prior_llr_z = log((1-(pz+py))/(pz+py)) (bp4_osd.pyx:134-137)
+    std::vector<double> qx(n), qz(n);
+    for (int v = 0; v < n; ++v) { qx[v] = px[v] + py[v]; qz[v] = pz[v] + py[v]; }
+    swd_graph_desc dx = *hx, dz = *hz;
+    dx.channel_probs = qx.data(); dz.channel_probs = qz.data();
+    if (d->gx.build(&dx) || d->gz.build(&dz)) { delete d; return nullptr; }
+    const int kmin = std::min(n - d->gx.rank, n - d->gz.rank);
+    if (d->p.osd_order > kmin) { // bp4_osd.pyx:92-98
+        set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", kmin);
+        delete d; return nullptr;
+    }
+    if (d->p.osd_order > 0 && d->gx.rank != d->gz.rank) {
+        set_error("higher-order OSD with rank(Hx) != rank(Hz) is undefined in the reference (kz = n - rank_x) and not supported");
+        delete d; return nullptr;
+    }
+    if (d->p.osd_method == 1 && d->p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); delete d; return nullptr; }
+    const int D = std::max(d->gx.D, d->gz.D);
+    if (D > 8) { set_error("column weight %d exceeds this build's bound 8", D); delete d; return nullptr; }
+    d->dm = D <= 4 ? 4 : 8;
+    d->nt = n <= 3072 ? 256 : 1024;
+    if (d->gx.upload() || d->gz.upload()) { delete d; return nullptr; }
+    d->gx.d.new_n = n; d->gz.d.new_n = n;
+    make_layout_for_osd(d->gx, d->nt, d->Lx);
+    make_layout_for_osd(d->gz, d->nt, d->Lz);
+    auto al = [](int x, int a) { return (x + a - 1) / a * a; };
+    const int msgx_b = al((d->gx.E + 1) * 8, 16), msgz_b = al((d->gz.E + 1) * 8, 16);
+    int scratch = std::max(msgx_b + msgz_b, std::max(d->Lx.off_livemask, d->Lz.off_livemask));
+    SwdBp4Layout &L = d->L;
+    L.off_msgz = msgx_b;
+    int o = al(scratch, 16);
+    const int mx = d->gx.m, mz = d->gz.m;
+    L.off_parx = o; o += mx * 4;
+    L.off_parz = o; o += mz * 4;
+    L.off_jptrx = o; o = al(o + (d->gx.K + 1) * 2, 4);
+    L.off_jptrz = o; o = al(o + (d->gz.K + 1) * 2, 4);
+    L.off_cnx = o; o += mx;
+    L.off_cnz = o; o += mz;
+    L.off_sxo = o; o += mx;
+    L.off_szo = o; o += mz;
+    L.off_decx = o; o += n;
+    L.off_decz = o; o += n;
+    L.off_hard = o; o = al(o + n, 16);
+    L.off_misc = o; o += 640;
+    L.total = al(o, 16);
+    if (L.total > 160 * 1024) { set_error("code needs %d bytes of LDS per shot (> 163840)", L.total); delete d; return nullptr; }
+    // channel LLRs (bp4_osd.pyx:127-133)
+    std::vector<double> llr(3 * (size_t)n);
+    for (int v = 0; v < n; ++v) {
+        double num = px[v] + py[v] + pz[v];
+        num = 1.0 - num;
+        llr[v] = log(num / px[v]); llr[n + v] = log(num / py[v]); llr[2 * n + v] = log(num / pz[v]);
+    }
+    if (d->llr.reserve(llr.size() * 8)) { delete d; return nullptr; }
+    if (hipMemcpy(d->llr.p, llr.data(), llr.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); delete d; return nullptr; }
+    d->d_llr_x = d->llr.as<double>(); d->d_llr_y = d->d_llr_x + n; d->d_llr_z = d->d_llr_y + n;
+    return (swd_bp4 *)d;
+}
+
+extern "C" void swd_bp4_destroy(swd_bp4 *h) {
+    Bp4 *d = (Bp4 *)h;
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    delete d;
+}
+
+extern "C" int swd_bp4_info(const swd_bp4 *h, int32_t *mx, int32_t *mz, int32_t *n, int32_t *rank_x, int32_t *rank_z) {
+    const Bp4 *d = (const Bp4 *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (mx) *mx = d->gx.m;
+    if (mz) *mz = d->gz.m;
+    if (n) *n = d->n;
+    if (rank_x) *rank_x = d->gx.rank;
+    if (rank_z) *rank_z = d->gz.rank;
+    return 0;
+}
+
+extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                                        int32_t *stats, double *lpr, uint8_t *osd0, void *stream) {
+    Bp4 *d = (Bp4 *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (B <= 0) return 0;
+    if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    if (!lpr) {
+        if (d->lpr.reserve((size_t)B * 3 * d->n * 8)) return -1;
+        lpr = d->lpr.as<double>();
+    }
+    SwdBp4Args a{};
+    a.gx = d->gx.d; a.gz = d->gz.d; a.Lx = d->Lx; a.Lz = d->Lz; a.L = d->L;
+    a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
+    a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
+    a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.stats = stats; a.lpr = lpr;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : bp4_launch<256, 8>(d, a, st);
+    return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : bp4_launch<1024, 8>(d, a, st);
+}
+
+extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                                    int32_t *stats, double *lpr, uint8_t *osd0) {
+    Bp4 *d = (Bp4 *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (B <= 0) return 0;
+    SWD_HIP(hipSetDevice(d->device));
+    const size_t n = d->n, mx = d->gx.m, mz = d->gz.m;
+    if (d->sx.reserve(B * mx) || d->sz.reserve(B * mz) || d->out.reserve(B * 2 * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
+        d->lpr.reserve((size_t)B * 3 * n * 8) || d->osd0.reserve(B * 2 * n))
+        return -1;
+    SWD_HIP(hipMemcpy(d->sx.p, sx, B * mx, hipMemcpyHostToDevice));
+    SWD_HIP(hipMemcpy(d->sz.p, sz, B * mz, hipMemcpyHostToDevice));
+    SWD_HIP(hipMemset(d->osd0.p, 0, B * 2 * n));
+    int rc = swd_bp4_decode_batch_dev(h, B, d->sx.as<uint8_t>(), d->sz.as<uint8_t>(), d->out.as<uint8_t>(), d->stats.as<int32_t>(),
+                                      d->lpr.as<double>(), d->osd0.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(out, d->out.p, B * 2 * n, hipMemcpyDeviceToHost));
+    SWD_HIP(hipMemcpy(stats, d->stats.p, (size_t)B * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
+    if (lpr) SWD_HIP(hipMemcpy(lpr, d->lpr.p, (size_t)B * 3 * n * 8, hipMemcpyDeviceToHost));
+    if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * 2 * n, hipMemcpyDeviceToHost));
+    return 0;
+}

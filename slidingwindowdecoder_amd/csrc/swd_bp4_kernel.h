@@ -1,0 +1,224 @@
+// Quaternary min-sum BP + one OSD per basis on the device: bp4_osd.decode
+// (/root/reference/src/bp4_osd.pyx:197-221) for one pair of syndromes per workgroup.
+//   bp_init 425-442, bp4_decode_llr 444-481, cn_update_all 483-529, vn_update 533-589, osd 261-368,
+//   log1pexp / logaddexp  /root/reference/src/include/bpgd.cpp:399-416.
+// Messages of both Tanner graphs (Hx and Hz share the variable nodes) live in LDS; the variable-node
+// update needs exp/log1p, so unlike the binary decoders its results depend on the math library:
+// parity is asserted on the posterior LLRs with a tolerance and on the decisions.
+#pragma once
+#include "swd_osdw_kernel.h"
+
+struct SwdBp4Layout {
+    int32_t off_msgz;   // msgX at 0 (Ex+1 doubles), msgZ here (Ez+1 doubles); both inside the scratch region
+    int32_t off_jptrx, off_jptrz, off_cnx, off_cnz, off_parx, off_parz, off_sxo, off_szo, off_decx, off_decz,
+        off_hard, off_misc, total;
+};
+
+struct SwdBp4Args {
+    SwdGraphDev gx, gz;   // Hx / Hz; their llr arrays hold prior_llr_x / prior_llr_z (OSD path metrics)
+    SwdLdsLayout Lx, Lz;  // OSD scratch layouts (npad, off_idx, off_aux, off_cs, cs_par) per basis
+    SwdBp4Layout L;
+    const double *llr_x, *llr_y, *llr_z; // [n] channel LLRs (bp4_osd.pyx:131-133)
+    int32_t max_iter, osd_method, osd_order, B;
+    double alpha;
+    const uint8_t *sx, *sz;  // [B][mx], [B][mz]
+    uint8_t *out;            // [B][2][n]  rows: X string, Z string
+    uint8_t *osd0;           // nullable [B][2][n]
+    int32_t *stats;          // [B][SWD_STAT_WORDS]
+    double *lpr;             // [B][3][n] posterior LLRs (x, y, z); also the OSD ordering input
+};
+
+namespace swd {
+
+__device__ __forceinline__ double bp4_log1pexp(double x) {
+    if (x > 36.04365338911715) return x + log1p(exp(-x)); // -log(DBL_EPSILON)
+    return log1p(exp(x));
+}
+__device__ __forceinline__ double bp4_logaddexp(double x, double y) {
+    const double tmp = x - y;
+    if (x == y) return x + 0.693147180559945309417232121458176568;
+    if (tmp > 0) return x + bp4_log1pexp(-tmp);
+    else if (tmp <= 0) return y + bp4_log1pexp(tmp);
+    return tmp;
+}
+
+// plain min-sum CN pass over one graph: lanes [lane0, lane0 + g.m) of the block own its checks
+template <int NT>
+__device__ __forceinline__ bool bp4_cn_pass(const SwdGraphDev &g, double *msg, const uint16_t *jptr, const int8_t *cn,
+                                            uint32_t *par, int lane0, int it, double alpha) {
+    bool unsat = false;
+    const int nthreads = NT;
+    for (int l = (int)threadIdx.x - lane0; l < g.m; l += nthreads) {
+        if (l < 0) continue;
+        const int cv = cn[l];
+        if (it > 0 && par[l] != 0u) unsat = true;
+        par[l] = (uint32_t)cv;
+        const int deg = g.row_deg[l];
+        double min1 = 1e308, min2 = 1e308;
+        int arg = -1;
+        uint64_t negm = 0;
+        for (int k = 0; k < deg; ++k) {
+            double x = msg[jptr[k] + l];
+            x = fmin(fmax(x, -50.0), 50.0);
+            const double ax = fabs(x);
+            arg = (ax < min1) ? k : arg;
+            min2 = fmin(min2, fmax(min1, ax));
+            min1 = fmin(min1, ax);
+            negm |= (x <= 0) ? (1ull << k) : 0ull;
+        }
+        const int sg = (cv ^ __popcll(negm)) & 1;
+        for (int k = 0; k < deg; ++k) {
+            const double mag = (k == arg) ? min2 : min1;
+            const int sgn = sg ^ (int)((negm >> k) & 1ull);
+            msg[jptr[k] + l] = mag * (sgn ? -alpha : alpha);
+        }
+    }
+    return unsat;
+}
+
+template <int NT, int DM>
+__global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SwdGraphDev &gx = a.gx, &gz = a.gz;
+    const int tid = threadIdx.x, b = blockIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
+    double *msgx = (double *)smem, *msgz = (double *)(smem + a.L.off_msgz);
+    uint16_t *jpx = (uint16_t *)(smem + a.L.off_jptrx), *jpz = (uint16_t *)(smem + a.L.off_jptrz);
+    int8_t *cnx = (int8_t *)(smem + a.L.off_cnx), *cnz = (int8_t *)(smem + a.L.off_cnz);
+    uint32_t *parx = (uint32_t *)(smem + a.L.off_parx), *parz = (uint32_t *)(smem + a.L.off_parz);
+    uint8_t *sxo = (uint8_t *)(smem + a.L.off_sxo), *szo = (uint8_t *)(smem + a.L.off_szo);
+    uint8_t *decx = (uint8_t *)(smem + a.L.off_decx), *decz = (uint8_t *)(smem + a.L.off_decz);
+    Lds s;
+    s.scratch = smem; s.msg = msgx; s.hard = (uint8_t *)(smem + a.L.off_hard);
+    s.flags = (int *)(smem + a.L.off_misc); s.scal = s.flags + 32; s.dbl = (double *)(s.scal + 32); s.iaux = (int *)(s.dbl + 24);
+    s.fpar = 0;
+    const uint8_t *sx_b = a.sx + (int64_t)b * mx, *sz_b = a.sz + (int64_t)b * mz;
+    double *lpr_b = a.lpr + (int64_t)b * 3 * n;
+
+    // reset + bp_init (bp4_osd.pyx:371-386, 425-442)
+    for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
+    for (int l = tid; l < mz; l += NT) cnz[l] = (int8_t)(sz_b[gz.perm[l]] ? 1 : 0);
+    for (int r = tid; r < mx; r += NT) sxo[r] = sx_b[r] ? 1 : 0;
+    for (int r = tid; r < mz; r += NT) szo[r] = sz_b[r] ? 1 : 0;
+    for (int j = tid; j <= gx.K; j += NT) jpx[j] = gx.jptr[j];
+    for (int j = tid; j <= gz.K; j += NT) jpz[j] = gz.jptr[j];
+    for (int v = tid; v < n; v += NT) {
+        decx[v] = 0; decz[v] = 0;
+        const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
+        const double m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
+        const double m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz); // sic (bp4_osd.pyx:438)
+        const int dx = gx.col_deg[v], dz = gz.col_deg[v];
+        for (int k = 0; k < dx; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
+        for (int k = 0; k < dz; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
+    }
+    __syncthreads();
+
+    // bp4_decode_llr (bp4_osd.pyx:444-481)
+    int conv = 0, iters = 0;
+    const int lane0z = (mx + mz <= NT) ? mx : 0; // Hz checks on the lanes after the Hx ones when both fit
+    for (int it = 0; it < a.max_iter; ++it) {
+        bool unsat = bp4_cn_pass<NT>(gx, msgx, jpx, cnx, parx, 0, it, a.alpha);
+        unsat |= bp4_cn_pass<NT>(gz, msgz, jpz, cnz, parz, lane0z, it, a.alpha);
+        const bool any = block_any<NT>(unsat, s);
+        if (it > 0 && !any) { conv = 1; iters = it; break; }
+        for (int v = tid; v < n; v += NT) { // vn_update (bp4_osd.pyx:533-589)
+            const int dx = gx.col_deg[v], dz = gz.col_deg[v];
+            uint32_t ex[DM], ez[DM];
+            double cx[DM], cz[DM];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                ex[k] = (k < dx) ? gx.vn_edge[k * n + v] : 0u;
+                ez[k] = (k < dz) ? gz.vn_edge[k * n + v] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < DM; ++k) { cx[k] = msgx[swd_edge_slot(ex[k])]; cz[k] = msgz[swd_edge_slot(ez[k])]; }
+            double llrx_hx = 0.0, llrz_hz = 0.0;
+#pragma unroll
+            for (int k = 0; k < DM; ++k) if (k < dz) llrx_hx += cz[k];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) if (k < dx) llrz_hz += cx[k];
+            const double llry_all = llrx_hx + llrz_hz + a.llr_y[v];
+            llrx_hx = llrx_hx + a.llr_x[v];
+            llrz_hz = llrz_hz + a.llr_z[v];
+            lpr_b[v] = llrx_hx; lpr_b[n + v] = llry_all; lpr_b[2 * n + v] = llrz_hz;
+            int idx;
+            if (0 < llrx_hx && 0 < llry_all && 0 < llrz_hz) idx = 0;
+            else if (llrx_hx < llry_all && llrx_hx < llrz_hz) idx = 1;
+            else if (llry_all > llrz_hz) idx = 2;
+            else idx = 3;
+            const int bx = idx & 1, bz = idx >> 1;
+            decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz;
+            const double num_hx = bp4_log1pexp(-1. * llrx_hx);
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                if (k < dx) {
+                    const double aa = llrz_hz - cx[k], bb = llry_all - cx[k];
+                    msgx[swd_edge_slot(ex[k])] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb);
+                    if (bz) atomicXor(&parx[swd_edge_lane(ex[k])], 1u); // Hx * z-string
+                }
+            const double num_hz = bp4_log1pexp(-1. * llrz_hz);
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                if (k < dz) {
+                    const double aa = llrx_hx - cz[k], bb = llry_all - cz[k];
+                    msgz[swd_edge_slot(ez[k])] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb);
+                    if (bx) atomicXor(&parz[swd_edge_lane(ez[k])], 1u); // Hz * x-string
+                }
+        }
+        __syncthreads();
+    }
+    if (!conv) {
+        bool unsat = false;
+        if (a.max_iter > 0) {
+            for (int l = tid; l < mx; l += NT) if (parx[l] != 0u) unsat = true;
+            for (int l = tid; l < mz; l += NT) if (parz[l] != 0u) unsat = true;
+        } else unsat = true;
+        const bool any = block_any<NT>(unsat, s);
+        iters = a.max_iter;
+        conv = any ? 0 : 1;
+    }
+    uint8_t *out_b = a.out + (int64_t)b * 2 * n;
+    int exit_class = SWD_EXIT_PRE, rowadds = 0;
+    if (conv || a.osd_order < 0) {
+        for (int v = tid; v < n; v += NT) { out_b[v] = decx[v]; out_b[n + v] = decz[v]; }
+        if (a.osd0 && conv)
+            for (int v = tid; v < n; v += NT) { a.osd0[(int64_t)b * 2 * n + v] = decx[v]; a.osd0[(int64_t)b * 2 * n + n + v] = decz[v]; }
+        if (!conv) exit_class = SWD_EXIT_NO_OSD;
+    } else {
+        exit_class = SWD_EXIT_OSD;
+        SwdDecodeParams P{};
+        P.osd_method = a.osd_method; P.osd_order = a.osd_order;
+        long long t0, t1;
+        // osd('x'): Hx, synd_x -> Z string; osd('z'): Hz, synd_z -> X string (bp4_osd.pyx:261-296)
+        for (int basis = 0; basis < 2; ++basis) {
+            const SwdGraphDev &g = basis == 0 ? gx : gz;
+            const SwdLdsLayout &L = basis == 0 ? a.Lx : a.Lz;
+            uint64_t *key = (uint64_t *)s.scratch;
+            uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
+            __syncthreads();
+            for (int v = tid; v < L.npad; v += NT) {
+                if (v < n) {
+                    const double lx = lpr_b[v], ly = lpr_b[n + v], lz = lpr_b[2 * n + v];
+                    const double post = basis == 0 ? bp4_log1pexp(-1. * lx) - bp4_logaddexp(-1. * ly, -1. * lz)
+                                                   : bp4_log1pexp(-1. * lz) - bp4_logaddexp(-1. * ly, -1. * lx);
+                    key[v] = f2key(post);
+                    idx[v] = (uint16_t)v;
+                } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+            }
+            __syncthreads();
+            int ra;
+            uint8_t *o0 = a.osd0 ? a.osd0 + (int64_t)b * 2 * n + (basis == 0 ? n : 0) : nullptr;
+            osd_run<NT, DM>(g, L, P, s, basis == 0 ? sxo : szo, o0, ra, t0, t1);
+            rowadds += ra;
+            uint8_t *dst = out_b + (basis == 0 ? n : 0);
+            for (int v = tid; v < n; v += NT) dst[v] = s.hard[v];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        int32_t *st = a.stats + (int64_t)b * SWD_STAT_WORDS;
+        st[0] = exit_class | (conv ? SWD_STATUS_CONVERGE : 0);
+        st[1] = iters; st[2] = iters; st[3] = 0; st[4] = n; st[5] = mx + mz; st[6] = gx.E + gz.E; st[7] = rowadds;
+    }
+}
+
+} // namespace swd

@@ -59,6 +59,10 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
     return 0;
 }
 
+// OSD-only layout of a graph (used by the quaternary decoder): npad / off_idx / off_aux / off_cs / cs_par,
+// off_livemask = bytes of scratch the OSD phase needs
+int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L) { return make_layout(g, g.n, nt, 0, L); }
+
 struct WindowHost {
     std::shared_ptr<Graph> g;
     int new_n = 0, row0 = 0, col0 = 0, commit = 0;

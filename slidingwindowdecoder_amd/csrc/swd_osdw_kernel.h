@@ -853,6 +853,55 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
     return best_pm;
 }
 
+// OSD on the ordered matrix (osd_window.pyx:215-284 / bp4_osd.pyx:297-366): the caller has filled the
+// sort keys (key[v], idx[v] = v, padding ~0 / 0xFFFF) at the start of the scratch region.  Sorts, runs the
+// OSD-0 elimination on wave 0, then the higher-order sweep.  On return s.hard[0..n) holds the OSD
+// solution; the return value is its path metric (sum of g.llr over the solution in column order).
+template <int NT, int DM>
+__device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+                                          const uint8_t *synd, uint8_t *osd0_b, int &rowadds, long long &t_sorted,
+                                          long long &t_elim) {
+    const int tid = threadIdx.x, m = g.m, n = g.n;
+    uint64_t *key = (uint64_t *)s.scratch;
+    uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
+    sort_pairs<NT>(key, idx, L.npad);
+    t_sorted = wall_clock64();
+    uint64_t *Tc = (uint64_t *)(s.scratch + L.off_aux);
+    uint64_t *Sbuf = Tc + m * g.wm;
+    uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
+    uint16_t *piv_row = piv_col + g.rank;
+    uint16_t *list1 = piv_row + g.rank;
+    for (int i = tid; i < m * g.wm; i += NT) { // word-major identity: Tw[w*m + j]
+        const int w = i / m, j = i - w * m;
+        Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
+    }
+    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+    // stage the row lists of the leading sorted columns over the (dead) sort keys
+    uint16_t *crows = (uint16_t *)s.scratch;
+    const int nst = min(n, (L.npad * 8) / (DM * 2));
+    for (int p = tid; p < nst; p += NT) {
+        const int v = idx[p];
+        const int deg = g.col_deg[v];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) crows[p * DM + k] = (k < deg) ? g.vn_row[k * n + v] : (uint16_t)0xFFFF;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int npiv;
+        const int ra = osd0_wave<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
+        if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
+    }
+    __syncthreads();
+    rowadds = s.scal[2];
+    const int npiv = s.scal[3];
+    t_elim = wall_clock64();
+    if (osd0_b)
+        for (int v = tid; v < n; v += NT) osd0_b[v] = s.hard[v];
+    double pm = ordered_pm<NT>(g, s, list1);
+    if (P.osd_order > 0) pm = osd_sweep<NT>(g, L, P, s, idx, Tc, Sbuf, piv_col, piv_row, npiv, pm);
+    return pm;
+}
+
 struct WinResult {
     int exit_class, conv, total_it, pre_it, post_it, live_vn, live_cn, live_e, osd_rowadds;
     double pm;
@@ -1053,41 +1102,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
     }
     __syncthreads();
-    sort_pairs<NT>(key, idx, L.npad);
-    R.t[6] = wall_clock64();
-    uint64_t *Tc = (uint64_t *)(s.scratch + L.off_aux);
-    uint64_t *Sbuf = Tc + m * g.wm;
-    uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
-    uint16_t *piv_row = piv_col + g.rank;
-    uint16_t *list1 = piv_row + g.rank;
-    for (int i = tid; i < m * g.wm; i += NT) { // word-major identity: Tw[w*m + j]
-        const int w = i / m, j = i - w * m;
-        Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
-    }
-    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
-    // stage the row lists of the leading sorted columns over the (dead) sort keys
-    uint16_t *crows = (uint16_t *)s.scratch;
-    const int nst = min(n, (L.npad * 8) / (DM * 2));
-    for (int p = tid; p < nst; p += NT) {
-        const int v = idx[p];
-        const int deg = g.col_deg[v];
-#pragma unroll
-        for (int k = 0; k < DM; ++k) crows[p * DM + k] = (k < deg) ? g.vn_row[k * n + v] : (uint16_t)0xFFFF;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        int npiv;
-        const int ra = osd0_wave<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
-        if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
-    }
-    __syncthreads();
-    R.osd_rowadds = s.scal[2];
-    const int npiv = s.scal[3];
-    R.t[7] = wall_clock64();
-    if (osd0_b)
-        for (int v = tid; v < n; v += NT) osd0_b[v] = s.hard[v];
-    R.pm = ordered_pm<NT>(g, s, list1);
-    if (P.osd_order > 0) R.pm = osd_sweep<NT>(g, L, P, s, idx, Tc, Sbuf, piv_col, piv_row, npiv, R.pm);
+    R.pm = osd_run<NT, DM>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7]);
     R.exit_class = SWD_EXIT_OSD;
 }
 

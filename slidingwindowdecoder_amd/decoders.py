@@ -298,6 +298,99 @@ class bpgd_decoder(bp_history_decoder):
     _mode = 1
 
 
+class bp4_osd:
+    """Quaternary BP + OSD (reference: src/bp4_osd.pyx).  ``decode(sx, sz)`` returns the int64 array of
+    shape (2, n) the reference returns (row 0: X string, row 1: Z string)."""
+
+    def __init__(self, Hx, Hz, **kwargs):
+        L = _lib.lib()
+        if not (isinstance(Hx, np.ndarray) or sp.issparse(Hx)):
+            raise TypeError("The input matrix is of an invalid type. Please input a np.ndarray or "
+                            "scipy.sparse.spmatrix object.")
+        if Hx.shape[1] != Hz.shape[1]:
+            raise ValueError("Hx, Hz blocklength does not match!")
+        n = Hx.shape[1]
+        probs = []
+        for key in ("channel_probs_x", "channel_probs_y", "channel_probs_z"):
+            v = kwargs.get(key)
+            if v is None:
+                raise ValueError(f"{key} is required")
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            if len(v) != n:
+                raise ValueError("The length of the channel probability vector must be eqaul to the "
+                                 f"block length n={n}.")
+            probs.append(v)
+        self._px, self._py, self._pz = probs
+        self._cx, self._cz = _Csr(Hx, self._px), _Csr(Hz, self._pz)
+        self.mx, self.mz, self.n = self._cx.m, self._cz.m, n
+        method, order = _parse_osd_method(kwargs.get("osd_method", "osd_0"), kwargs.get("osd_order", 0))
+        self.device = int(kwargs.get("device", 0))
+        p = _lib.Bp4Params(int(kwargs.get("max_iter", 32)), float(kwargs.get("ms_scaling_factor", 1.0)), method, order)
+        self._h = L.swd_bp4_create(C.byref(self._cx.desc), C.byref(self._cz.desc), self._px.ctypes.data,
+                                   self._py.ctypes.data, self._pz.ctypes.data, C.byref(p), self.device)
+        if not self._h:
+            msg = _lib.last_error()
+            if "OSD order" in msg or "invalid" in msg or "blocklength" in msg:
+                raise ValueError(msg)
+            raise RuntimeError(f"swd_bp4_create failed: {msg}")
+        i = [C.c_int32() for _ in range(5)]
+        L.swd_bp4_info(self._h, *[C.byref(x) for x in i])
+        self.rank_x, self.rank_z = i[3].value, i[4].value
+        self._last = dict(status=0, iters=0)
+        self._lpr = np.zeros((3, n))
+        self._osd0 = np.zeros((2, n), np.int64)
+        self._out = np.zeros((2, n), np.int64)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().swd_bp4_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def decode_batch(self, synd_x, synd_z, return_llr=False):
+        sx, sz = np.asarray(synd_x), np.asarray(synd_z)
+        if sx.ndim != 2 or sx.shape[1] != self.mx or sz.ndim != 2 or sz.shape[1] != self.mz or sx.shape[0] != sz.shape[0]:
+            raise ValueError(f"syndromes must have shapes [B, {self.mx}] and [B, {self.mz}]")
+        sx = np.ascontiguousarray((sx.astype(np.int64) & 0xFF).astype(np.uint8))
+        sz = np.ascontiguousarray((sz.astype(np.int64) & 0xFF).astype(np.uint8))
+        B = sx.shape[0]
+        out = np.zeros((B, 2, self.n), np.uint8)
+        st = np.zeros((B, _lib.STAT_WORDS), np.int32)
+        lpr = np.zeros((B, 3, self.n))
+        osd0 = np.zeros((B, 2, self.n), np.uint8)
+        rc = _lib.lib().swd_bp4_decode_batch(self._h, B, sx.ctypes.data, sz.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                             lpr.ctypes.data, osd0.ctypes.data)
+        if rc:
+            raise RuntimeError(f"swd_bp4_decode_batch failed: {_lib.last_error()}")
+        self.last_stats, self.last_status, self.last_iterations = st, st[:, 0].copy(), st[:, 1].copy()
+        self.last_llr, self.last_osd0 = lpr, osd0
+        return out
+
+    def decode(self, input_vector_x, input_vector_z):
+        sx, sz = np.asarray(input_vector_x), np.asarray(input_vector_z)
+        if sx.shape[0] != self.mx or sz.shape[0] != self.mz:
+            raise ValueError(f"The input to the bp4_osd.decode must be a syndrome (of length={self.mx}).")
+        out = self.decode_batch(sx[None, :], sz[None, :])
+        self._last = dict(status=int(self.last_status[0]), iters=int(self.last_iterations[0]))
+        self._lpr = self.last_llr[0]
+        self._out = out[0].astype(np.int64)
+        if (self._last["status"] & 0xFF) in (EXIT_PRE, EXIT_OSD):
+            self._osd0 = self.last_osd0[0].astype(np.int64)
+        return self._out.copy()
+
+    converge = property(lambda self: 1 if (self._last["status"] & STATUS_CONVERGE) else 0)
+    bp_iteration = property(lambda self: self._last["iters"])
+    osd0_decoding_x = property(lambda self: self._osd0[0].copy())
+    osd0_decoding_z = property(lambda self: self._osd0[1].copy())
+
+    @property
+    def log_prob_ratios(self):
+        return np.ascontiguousarray(self._lpr.T)
+
+
 class SlidingWindowDecoder:
     """The (W,F) sliding-window loop of the reference harness (/root/reference/osd.py:130-179) for
     a whole batch of shots in ONE launch: a workgroup carries a shot through all its windows,
