@@ -1,0 +1,140 @@
+"""Oracle vs. the reference's own C/C++ objects (oracle/_ref/libswd_ref.so, built by `make -C oracle ref`
+from the sources where they lie under /root/reference; the .so travels, the sources do not).
+Covers the parts of the path that exist as C/C++ in the reference: rank, index_sort, the sparse LU +
+solve behind OSD-0, and the BPGD worker class.  Skipped when the library has not been built."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as O
+from tests import fixtures as fx
+
+REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libswd_ref.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def R():
+    L = C.CDLL(REF)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.ref_pcm_new.restype = vp
+    L.ref_pcm_new.argtypes = [i32, i32, vp, vp]
+    L.ref_pcm_free.argtypes = [vp]
+    L.ref_rank.argtypes = [vp]
+    L.ref_index_sort.argtypes = [vp, vp, i32]
+    L.ref_osd0.argtypes = [vp, i32, vp, vp, vp]
+    L.ref_bpgd_new.restype = vp
+    L.ref_bpgd_new.argtypes = [i32, i32, i32, i32, C.c_double]
+    L.ref_bpgd_free.argtypes = [vp]
+    L.ref_bpgd_reset.argtypes = [vp, vp, vp, vp, vp]
+    L.ref_bpgd_min_sum_log.argtypes = [vp]
+    L.ref_bpgd_decimate_vn_reliable.argtypes = [vp, i32, C.c_double]
+    L.ref_bpgd_get_pm.restype = C.c_double
+    L.ref_bpgd_get_pm.argtypes = [vp]
+    L.ref_bpgd_error.argtypes = [vp, vp]
+    return L
+
+
+class Pcm:
+    def __init__(self, R, mat):
+        csr = sp.csr_matrix(mat)
+        csr.sort_indices()
+        self.R, self.m, self.n = R, csr.shape[0], csr.shape[1]
+        rp, ci = csr.indptr.astype(np.int32), csr.indices.astype(np.int32)
+        self.h = R.ref_pcm_new(self.m, self.n, rp.ctypes.data, ci.ctypes.data)
+
+    def __del__(self):
+        self.R.ref_pcm_free(self.h)
+
+
+def window_graphs():
+    f = fx.load("bb72_capacity.npz")
+    yield "bb72", *fx.graph(f, "osd0_")
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    yield "bb144_last", *fx.graph(f, "win10_")
+
+
+def test_rank(R):
+    for _, mat, _ in window_graphs():
+        p = Pcm(R, mat)
+        assert R.ref_rank(p.h) == O.osd_window(mat, channel_probs=np.full(mat.shape[1], 0.01)).rank
+
+
+def test_index_sort_is_stable_ascending(R):
+    rng = np.random.default_rng(5)
+    v = rng.integers(-3, 4, 500).astype(np.float64)  # many ties
+    cols = np.zeros(500, np.int32)
+    R.ref_index_sort(v.ctypes.data, cols.ctypes.data, 500)
+    assert np.array_equal(cols, np.argsort(v, kind="stable"))
+
+
+@pytest.mark.parametrize("name", ["bb72", "bb144_last"])
+def test_osd0_against_reference_lu(R, name):
+    """Non-converging shots: the oracle's OSD-0 solution == the reference's mod2sparse_decomp_osd +
+    LU_forward_backward_solve run on the oracle's final LLR order (osd_window.pyx:201-229)."""
+    mat, priors = next((m, p) for n_, m, p in window_graphs() if n_ == name)
+    m, n = mat.shape
+    dec = O.osd_window(mat, channel_probs=priors, pre_max_iter=4, post_max_iter=6, new_n=n, osd_method="osd_0")
+    p = Pcm(R, mat)
+    rng = np.random.default_rng(11)
+    H = sp.csr_matrix(mat).astype(np.int64)
+    done = 0
+    for _ in range(400):
+        e = (rng.random(n) < np.maximum(priors, 0.02) * 2.5).astype(np.int64)
+        s = (H @ e % 2).astype(np.uint8)
+        dec.clear_history()
+        dec.decode(s)
+        if dec.converge:
+            continue
+        h = dec.log_prob_ratios
+        llr_sum = np.ascontiguousarray(((h[:, 0] + h[:, 1]) + h[:, 2]) + h[:, 3])
+        cols = np.zeros(n, np.int32)
+        R.ref_index_sort(llr_sum.ctypes.data, cols.ctypes.data, n)
+        out = np.zeros(n, np.uint8)
+        R.ref_osd0(p.h, dec.rank, cols.ctypes.data, s.ctypes.data, out.ctypes.data)
+        assert np.array_equal(out, dec.osd0_decoding)
+        done += 1
+        if done >= 40:
+            break
+    assert done >= 10
+
+
+def test_bpgd_worker_class(R):
+    """bpgd_decoder with max_iter=0 is the bare gd() loop on the identity order (zero history):
+    drive the reference's BPGD object through the same steps (bp_guessing_decoder.pyx:517-560)."""
+    f = fx.load("bb72_capacity.npz")
+    mat, priors = fx.graph(f, "gd_")
+    m, n = mat.shape
+    T, steps = 6, 25
+    dec = O.bpgd_decoder(mat, channel_probs=priors, max_iter=0, max_iter_per_step=T, max_step=steps, new_n=n)
+    p = Pcm(R, mat)
+    b = R.ref_bpgd_new(m, n, T, 0, 1.0)
+    llr = np.log((1 - priors) / priors)
+    cols = np.arange(n, dtype=np.int32)
+    H = sp.csr_matrix(mat).astype(np.int64)
+    rng = np.random.default_rng(3)
+    nconv = 0
+    for _ in range(60):
+        e = (rng.random(n) < 0.04).astype(np.int64)
+        s = (H @ e % 2).astype(np.uint8)
+        want = dec.decode(s)
+        conv, pm = False, 10000.0
+        if R.ref_bpgd_reset(b, p.h, cols.ctypes.data, llr.ctypes.data, s.ctypes.data) != -1:
+            for depth in range(steps):
+                if R.ref_bpgd_min_sum_log(b):
+                    conv, pm = True, R.ref_bpgd_get_pm(b)
+                    break
+                if R.ref_bpgd_decimate_vn_reliable(b, depth, 1.0) == -1:
+                    break
+        got = np.zeros(n, np.uint8)
+        R.ref_bpgd_error(b, got.ctypes.data)
+        assert bool(dec.converge) == conv
+        assert np.array_equal(got, want)
+        if conv:
+            assert dec.min_pm == pm
+            nconv += 1
+    assert nconv >= 20
+    R.ref_bpgd_free(b)
