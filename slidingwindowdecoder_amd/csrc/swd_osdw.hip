@@ -32,11 +32,12 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
     if (cs_bytes <= npad * 8) L.off_cs = 0;
     else { L.off_cs = osd_bytes; osd_bytes += align_up(cs_bytes, 16); }
     const int rare_bytes = L.off_aux + n * 2;
-    int scratch = std::max(std::max((E + 1) * 8, osd_bytes), std::max(rare_bytes, n * 2)); // +1: sacrificial slot E
+    // messages + slot E + one far and one zero slot per wave (swd_osdw_kernel.h, VnCache)
+    int scratch = std::max(std::max((E + 1 + 2 * (nt / 64)) * 8, osd_bytes), std::max(rare_bytes, n * 2));
     scratch = align_up(scratch, 16);
     int o = scratch;
     L.off_livemask = o; o += m * 8;
-    L.off_par = o; o += m * 4;
+    L.off_par = o; o += (m + 1) * 4; // par[m]: sink for the dead positions' parity flips
     L.off_lv = o; o = align_up(o + new_n * 2, 4);
     L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
     // live-slot lists: osd_window stages them in the (then dead) scratch region; the guessing decoders

@@ -165,54 +165,65 @@ __device__ __forceinline__ void wave_fence() {
 // ------------------------------------------------------------------------------------------
 // Per-thread register cache of the variable nodes a thread owns during one BP phase: thread t owns
 // entries t, t+NT, ... of the VN list (all VNs in the pre phase, the compacted live list in the post
-// phase).  Edge metadata, priors and live-edge masks are loaded once per phase, so the iteration loop
-// touches only LDS.  DM = exact bound on the column degree of this kernel variant.
+// phase).  Edge metadata and priors are loaded once per phase, so the iteration loop touches only LDS.
+// DM = exact bound on the column degree of this kernel variant.
+//
+// The inner loops are VALU-issue bound (scripts/ubench/valu_indep.hip: ~4.5 cycles per wave
+// instruction and SIMD, whatever the occupancy), so they are written to need no per-edge predicate:
+//   * positions of a VN without a live edge point at the wave's "zero" slot Z_w, which holds +0.0
+//     when it is read (x + 0.0 == x for every x a prefix / suffix sum can take here: they start from
+//     the prior resp. +0.0 and so are never -0.0) and is re-armed after the VN's writes;
+//   * positions of a check without a live edge point at the wave's "far" slot D_w, which holds a
+//     positive value >= 50 when it is read: it clips to 50, never beats a real magnitude (all
+//     <= 50) to first or second minimum of a check with >= 2 live edges, and never counts as
+//     negative; checks with one live edge get their "minimum of nothing" (1e308) patched in after
+//     the loop.  D_w / Z_w are only touched by their own wave, whose LDS operations execute in order.
+// ed = byte offset of the edge's message slot | (index into par[], m for dead positions) << 19.
+constexpr uint32_t kEdAddrMask = 0x7FFF8u;
 template <int VF, int DM>
 struct VnCache {
     double llr[VF];
     uint32_t ed[VF][DM];
-    uint32_t mask[(VF + 3) / 4]; // 8 bits per VN: bit k = edge k exists and its check is live
-    __device__ __forceinline__ uint32_t m8(int i) const { return (mask[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
 };
+
+__device__ __forceinline__ int swd_slot_far(const SwdGraphDev &g) { return g.E + 1 + (int)(threadIdx.x >> 6); }
+template <int NT>
+__device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E + 1 + NT / 64 + (int)(threadIdx.x >> 6); }
 
 template <int NT, int VF, int DM, bool FULL>
 __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCache<VF, DM> &c) {
     const int n = g.n, cnt = FULL ? n : nlive;
-#pragma unroll
-    for (int i = 0; i < (VF + 3) / 4; ++i) c.mask[i] = 0;
+    const uint32_t dead = ((uint32_t)swd_slot_zero<NT>(g) << 3) | ((uint32_t)g.m << 19);
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         const int idx = threadIdx.x + i * NT;
         c.llr[i] = 0.0;
 #pragma unroll
-        for (int k = 0; k < DM; ++k) c.ed[i][k] = 0;
+        for (int k = 0; k < DM; ++k) c.ed[i][k] = dead;
         if (idx < cnt) {
             const int v = FULL ? idx : (int)s.lv[idx];
             const int deg = g.col_deg[v];
             c.llr[i] = g.llr[v];
-            uint32_t mk = 0;
 #pragma unroll
             for (int k = 0; k < DM; ++k) {
                 if (k < deg) {
                     const uint32_t e = g.vn_edge[k * n + v];
-                    c.ed[i][k] = e;
-                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) mk |= 1u << k;
+                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) c.ed[i][k] = (swd_edge_slot(e) << 3) | (swd_edge_lane(e) << 19);
                 }
             }
-            c.mask[i >> 2] |= mk << ((i & 3) * 8);
         }
     }
 }
+
+__device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + (ed & kEdAddrMask)); }
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
 template <int VF, int DM>
 __device__ __forceinline__ void bp_init(Lds &s, const VnCache<VF, DM> &c) {
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
-        const uint32_t mk = c.m8(i);
 #pragma unroll
-        for (int k = 0; k < DM; ++k)
-            if ((mk >> k) & 1u) s.msg[swd_edge_slot(c.ed[i][k])] = c.llr[i];
+        for (int k = 0; k < DM; ++k) swd_msg_at(s, c.ed[i][k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
     }
 }
 
@@ -223,26 +234,26 @@ __device__ __forceinline__ int wave_max(int x) {
 }
 
 // Per-thread register cache of the check a lane owns during one BP phase: the LDS slots of its
-// edges (u16, two per register) in walk order; unused / dead positions hold the sacrificial slot
-// g.E, which is how the inner loops recognise them.  KG = groups of four positions.
+// edges (u16, two per register) in walk order; unused / dead positions hold the wave's far slot.
+// KG = groups of four positions.
 template <int KG>
 struct CnCache {
     uint32_t sl[KG * 2];
-    uint64_t vmask; // bit k: position k carries a live edge
-    int cnt;        // positions to walk (0 for lanes without a live check)
+    int cnt;  // positions to walk (0 for lanes without a live check)
+    int live; // live edges among them
     __device__ __forceinline__ int slot(int k) const { return (int)((sl[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu); }
 };
 
 template <int NT, int KG, bool FULL>
 __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, CnCache<KG> &cc) {
-    const int l = threadIdx.x, m = g.m, dummy = g.E;
+    const int l = threadIdx.x, m = g.m, dummy = swd_slot_far(g);
     const bool act = (l < m) && (s.cn_val[l] >= 0);
-    // list mode walks the compacted live edges, otherwise all original positions (dead ones masked)
+    // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
     const bool bylist = !FULL && uselist;
     const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
     const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : s.livemask[l];
     cc.cnt = cnt;
-    cc.vmask = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) & lmask;
+    cc.live = act ? (int)s.cn_deg[l] : 0;
 #pragma unroll
     for (int q = 0; q < KG * 2; ++q) {
         uint32_t w = 0;
@@ -258,24 +269,34 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
     }
 }
 
+// fp64 min / max without the canonicalising v_max x,x the compiler puts in front of fmin/fmax
+__device__ __forceinline__ double vmin64(double a, double b) { double d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ double vmax64(double a, double b) { double d; asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ double vminabs64(double x, double c) { double d; asm("v_min_f64 %0, |%1|, %2" : "=v"(d) : "v"(x), "v"(c)); return d; }
+// w = 2*w + (x <= 0): shift register of "is negative" bits (osd_window.pyx:404-409 counts <= 0 as negative)
+__device__ __forceinline__ void neg_shift_in(uint32_t &w, double x) {
+    asm("v_cmp_ge_f64 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x) : "vcc");
+}
+
 template <int NT, int VF, int DM, int KG, bool FULL>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
-    const int dummy = g.E;
     const int vcnt = FULL ? n : nlive;
-    const double nalpha = -alpha;
     const bool record_all = P.record_all != 0;
-    uint32_t maskw[(VF + 3) / 4];
-#pragma unroll
-    for (int i = 0; i < (VF + 3) / 4; ++i) maskw[i] = c.mask[i];
     const int l = tid;                       // NT >= m: one check per lane
     const int cv = (l < m) ? (int)s.cn_val[l] : -1;
     const int cnt = cn.cnt;
     const int wmax = wave_max(cnt);
+    const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
+    constexpr int K4 = KG * 4;
+    constexpr int NR = (K4 + 31) / 32;       // sign shift registers
     iters_done = 0;
     if (max_iter <= 0) return 0;
+    s.msg[farslot] = 64.0;
+    s.msg[zeroslot] = 0.0;
+    char *const parb = (char *)s.par;
 #ifdef SWD_BPPROF
     long long tc0, tc1, tc2, tc3;
     long long acc_cn = 0, acc_any = 0, acc_vn = 0, acc_bar = 0;
@@ -286,26 +307,22 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     for (int it = 0; it < max_iter; ++it) {
         bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
         BPT(tc0);
-        // keep the per-edge predicates from being hoisted out of the loop as ~2 SGPRs each
-#pragma unroll
-        for (int i = 0; i < (VF + 3) / 4; ++i) asm volatile("" : "+v"(maskw[i]));
         {
             if (cv >= 0) {
                 if (it > 0 && s.par[l] != 0u) unsat = true;
                 s.par[l] = (uint32_t)cv;
             }
-            double min1 = 1e308, min2 = 1e308;
-            int arg = -1;
-            uint32_t neg_lo = 0, neg_hi = 0; // bit k: clipped b2c of position k is <= 0
-            const uint32_t vm_lo = (uint32_t)cn.vmask, vm_hi = (uint32_t)(cn.vmask >> 32);
             // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
-            // group of four are independent; after the reads everything is min/max/select (hipcc turns
-            // if/else here into exec-mask branches with an exposed LDS round trip each).  The two-minimum
-            // update min2 = min(min2, max(min1, a)); min1 = min(min1, a) equals the reference's
-            // left/right running minima; fmin/fmax ignore NaN like its `<` tests do.
-            // software pipeline of depth one: the reads of group gq+1 are in flight while group gq is
-            // reduced; the scheduling barriers keep the compiler from hoisting every group's reads to
-            // the top (which costs > 70 VGPRs and a wave of occupancy)
+            // group of four are independent.  The two-minimum update
+            //   min2 = min(min2, max(min1, a)); min1 = min(min1, a)
+            // equals the reference's left/right running minima; |clip(x, -50, 50)| = min(|x|, 50).
+            // Software pipeline of depth one: the reads of group gq+1 are in flight while group gq is
+            // reduced; the scheduling barriers keep the compiler from hoisting every group's reads.
+            double min1 = 1e308, min2 = 1e308;
+            int argslot = farslot;
+            uint32_t neg[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) neg[r] = 0;
             double xn[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) xn[u] = s.msg[cn.slot(u)];
@@ -322,30 +339,47 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = gq * 4 + u;
-                        const bool valid = (((k < 32) ? vm_lo : vm_hi) >> (k & 31)) & 1u;
-                        const double x = fmin(fmax(xs[u], -50.0), 50.0);
-                        const double ax = valid ? fabs(x) : 1e308;
-                        arg = (ax < min1) ? k : arg;
-                        min2 = fmin(min2, fmax(min1, ax));
-                        min1 = fmin(min1, ax);
-                        const uint32_t nb = (valid && (x <= 0)) ? (1u << (k & 31)) : 0u;
-                        if (k < 32) neg_lo |= nb; else neg_hi |= nb;
+                        const double ax = vminabs64(xs[u], 50.0);
+                        argslot = (ax < min1) ? cn.slot(k) : argslot;
+                        min2 = vmin64(min2, vmax64(min1, ax));
+                        min1 = vmin64(min1, ax);
+                        neg_shift_in(neg[k >> 5], xs[u]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) neg[(gq * 4 + u) >> 5] <<= 1; // keep position k at bit (31 - k % 32) ...
                 }
             }
-            const int sg = (cv ^ (__popc(neg_lo) + __popc(neg_hi))) & 1;
+            // ... after this alignment of a partly filled last register
+            if (K4 & 31) neg[NR - 1] <<= (32 - (K4 & 31));
+            int npar = cv;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) npar += __popc(neg[r]);
+            const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
+            // the first position holding the minimum gets the second minimum (ties: both equal).
+            // Its own sign is re-read before the slots are overwritten.
+            const double xarg = s.msg[argslot];
+            if (cn.live == 1) min2 = 1e308; // minimum over no other edge
+            const double p1 = min1 * alpha, p2 = min2 * alpha;
+            const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
 #pragma unroll
             for (int gq = 0; gq < KG; ++gq) {
                 if (gq * 4 < wmax) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = gq * 4 + u;
-                        const double mag = (k == arg) ? min2 : min1;
-                        const int sgn = sg ^ (int)((((k < 32) ? neg_lo : neg_hi) >> (k & 31)) & 1u);
-                        s.msg[cn.slot(k)] = mag * (sgn ? nalpha : alpha); // dead positions hit slot g.E
+                        const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
+                        const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
+                        s.msg[cn.slot(k)] = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
                     }
                 }
+            }
+            {
+                const uint32_t sb = (((xarg <= 0) ? 0xFFFFFFFFu : 0u) ^ flip) & 0x80000000u;
+                const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
+                s.msg[argslot] = __longlong_as_double((long long)b2);
+                s.msg[farslot] = 64.0; // re-arm
             }
         }
         BPT(tc1);
@@ -364,36 +398,25 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             const int idx = tid + i * NT;
             if (idx >= vcnt) continue;
             const int v = FULL ? idx : (int)s.lv[idx];
-            const uint32_t mk = (maskw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
             double cc[DM], pre[DM];
-            // dead edges carry slot 0 in the cache: the loads are unconditional (and independent),
-            // their values are dropped by the selects below
 #pragma unroll
-            for (int k = 0; k < DM; ++k) cc[k] = s.msg[swd_edge_slot(c.ed[i][k])];
+            for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, c.ed[i][k]);
             double temp = c.llr[i];
 #pragma unroll
-            for (int k = 0; k < DM; ++k) {
-                const bool lv_ = (mk >> k) & 1u;
-                pre[k] = temp;
-                const double t2 = temp + cc[k];
-                temp = lv_ ? t2 : temp;
-            }
+            for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
             if (record) hist_b[slot_h * n + v] = temp;
             const bool hd = (temp <= 0);
             s.hard[v] = hd ? 1 : 0;
             double suf = 0.0;
 #pragma unroll
             for (int k = DM - 1; k >= 0; --k) {
-                const bool lv_ = (mk >> k) & 1u;
-                const double out = pre[k] + suf;
-                const double s2 = suf + cc[k];
-                suf = lv_ ? s2 : suf;
-                s.msg[lv_ ? (int)swd_edge_slot(c.ed[i][k]) : dummy] = out; // dead edges: sacrificial slot
+                swd_msg_at(s, c.ed[i][k]) = pre[k] + suf;
+                suf = suf + cc[k];
             }
+            s.msg[zeroslot] = 0.0; // re-arm
             if (hd) {
 #pragma unroll
-                for (int k = 0; k < DM; ++k)
-                    if ((mk >> k) & 1u) atomicXor(&s.par[swd_edge_lane(c.ed[i][k])], 1u);
+                for (int k = 0; k < DM; ++k) atomicXor((uint32_t *)(parb + ((c.ed[i][k] >> 17) & 0x1FFCu)), 1u); // dead: par[m]
             }
         }
         BPT(tc3);
