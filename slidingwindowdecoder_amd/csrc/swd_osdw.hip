@@ -31,7 +31,7 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
                          std::max(wm * L.cs_par, 64 + wm) * 8;
     if (cs_bytes <= npad * 8) L.off_cs = 0;
     else { L.off_cs = osd_bytes; osd_bytes += align_up(cs_bytes, 16); }
-    const int rare_bytes = L.off_aux + n * 2;
+    const int rare_bytes = L.off_aux + std::max(n * 2, 3 * 256 * 4); // failed-decimation positions / select histograms
     // messages + slot E + one far and one zero slot per wave (swd_osdw_kernel.h, VnCache)
     int scratch = std::max(std::max((E + 1 + 2 * (nt / 64)) * 8, osd_bytes), std::max(rare_bytes, n * 2));
     scratch = align_up(scratch, 16);

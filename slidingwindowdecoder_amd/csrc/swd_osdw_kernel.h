@@ -457,6 +457,72 @@ __device__ __forceinline__ void sort_pairs(uint64_t *key, uint16_t *idx, int npa
     }
 }
 
+// Marks everything but the `keep` smallest (key, index) pairs: vn_val[v] = 0 for the columns the
+// reference's stable argsort (index_sort, bpgd.cpp:384-389) puts at positions keep.. (osd_window.pyx:
+// 178-183 only uses that tail as a set).  MSB-first radix select on the 64-bit keys, 8 bits per
+// pass; every wave scans the 256-bin histogram itself, so a pass costs one barrier.  Ties on the
+// boundary key go to the smallest indices, which is what a stable sort does.
+// hist: 3 x 256 ints of scratch.  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int keep, int *hist, Lds &s) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint64_t prefix = 0, pmask = 0;
+    int need = keep;
+    bool exact = false; // boundary falls between two bins: no tie to break
+    for (int b = tid; b < 256; b += NT) hist[b] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        int *h = hist + (pass % 3) * 256, *hz = hist + ((pass + 1) % 3) * 256; // hz: last read two passes ago
+        for (int b = tid; b < 256; b += NT) hz[b] = 0;
+        for (int v = tid; v < n; v += NT) {
+            const uint64_t k = key[v];
+            if ((k & pmask) == prefix) atomicAdd(&h[(int)(k >> shift) & 255], 1);
+        }
+        __syncthreads();
+        const int4 c4 = *(const int4 *)(h + 4 * lane);
+        const int tot = c4.x + c4.y + c4.z + c4.w;
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        const unsigned long long hit = __ballot(incl >= need);
+        const int bl = __ffsll((long long)hit) - 1; // first lane whose bins reach the rank
+        int before = __shfl(incl - tot, bl, 64);
+        const int cx = __shfl(c4.x, bl, 64), cy = __shfl(c4.y, bl, 64), cz = __shfl(c4.z, bl, 64), cw = __shfl(c4.w, bl, 64);
+        int bin = 4 * bl, cnt = cx;
+        if (before + cnt < need) { before += cnt; ++bin; cnt = cy; }
+        if (before + cnt < need) { before += cnt; ++bin; cnt = cz; }
+        if (before + cnt < need) { before += cnt; ++bin; cnt = cw; }
+        prefix |= (uint64_t)bin << shift;
+        pmask |= 0xFFull << shift;
+        need -= before;
+        if (cnt == need) { exact = true; break; } // the whole bin is kept
+    }
+    // keep: (k & pmask) < prefix, and of the keys == prefix the first `need` in index order
+    const int ch = (n + NT - 1) / NT;
+    const int v0 = tid * ch, v1 = min(n, v0 + ch);
+    if (exact) {
+        for (int v = tid; v < n; v += NT)
+            if ((key[v] & pmask) > prefix) s.vn_val[v] = 0;
+        __syncthreads();
+        return;
+    }
+    int eq = 0;
+    for (int v = v0; v < v1; ++v) eq += (key[v] == prefix) ? 1 : 0;
+    int tot;
+    int rank = block_exscan<NT>(eq, s, tot);
+    for (int v = v0; v < v1; ++v) {
+        const uint64_t k = key[v];
+        if (k > prefix) s.vn_val[v] = 0;
+        else if (k == prefix) { if (rank >= need) s.vn_val[v] = 0; ++rank; }
+    }
+    __syncthreads();
+}
+
 // sum of llr[v] over hard[v]==1 in ascending v (min_pm, osd_window.pyx:168-169 / 233-235).
 // `list` must hold n u16.  Result valid on every thread.
 template <int NT>
@@ -995,7 +1061,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         R.total_it = R.pre_it;
         return;
     }
-    // ---- order columns by summed LLR history (osd_window.pyx:172-176)
+    // ---- order columns by summed LLR history (osd_window.pyx:172-176); only the set cols[new_n:]
+    // matters unless a decimation fails, so the common path selects instead of sorting
     uint64_t *key = (uint64_t *)s.scratch;
     uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
     __syncthreads();
@@ -1007,11 +1074,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
     }
     __syncthreads();
-    sort_pairs<NT>(key, idx, L.npad);
-    R.t[3] = wall_clock64();
     // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
-    for (int i = g.new_n + tid; i < n; i += NT) s.vn_val[idx[i]] = 0;
-    __syncthreads();
+    if (g.new_n < n) select_smallest<NT>(key, n, g.new_n, (int *)(s.scratch + L.off_aux), s);
+    R.t[3] = wall_clock64();
     bool contra = false;
     for (int l = tid; l < m; l += NT) {
         const int d = g.row_deg[l];
@@ -1032,6 +1097,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     if (any_contra) {
         // "setting vn failed" (osd_window.pyx:179-181): the reference stops at the first decimation
         // that empties an unsatisfied check; only VNs up to that sorted position were zeroed.
+        sort_pairs<NT>(key, idx, L.npad);
         uint16_t *pos = (uint16_t *)(s.scratch + L.off_aux);
         for (int i = tid; i < n; i += NT) pos[idx[i]] = (uint16_t)i;
         if (tid == 0) s.scal[0] = 0x7fffffff;
@@ -1052,7 +1118,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         R.total_it = R.pre_it;
         return;
     }
-    for (int i = g.new_n + tid; i < n; i += NT) s.hard[idx[i]] = 0;
+    for (int v = tid; v < n; v += NT)
+        if (s.vn_val[v] == 0) s.hard[v] = 0;
     __syncthreads();
     // ---- peel (osd_window.pyx:184-186)
     if (tid < 64) {
