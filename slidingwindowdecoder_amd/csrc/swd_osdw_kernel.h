@@ -751,6 +751,154 @@ __device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uin
     return rowadds;
 }
 
+// osd0_wave for m <= 256 (wm <= 4): the transform matrix lives in registers -- lane l owns columns
+// l, l+64, l+128, l+192 of T, four words each -- and LDS only holds a mirror that the column
+// evaluations read.  A step evaluates 16 sorted columns against the mirror and then resolves every
+// pivot among them without touching LDS: after a pivot (row r, reduced column u) the row operation
+// "rows i != r with u[i] = 1 get row r added" is applied to the owned columns of T and to the reduced
+// vectors of the step's later columns (y ^= S if y[r], S = u without bit r), which is exactly what
+// re-evaluating them against the updated T would give.  The mirror is refreshed once per step.
+template <int WS>
+__device__ __forceinline__ void osd_treg_update(uint64_t (&t)[4][4], int bit, const uint64_t (&S)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t msk = ((t[q][WS] >> bit) & 1ull) ? ~0ull : 0ull;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) t[q][x] ^= S[x] & msk;
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // srclane wave-uniform
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, srclane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), srclane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int DM>
+__device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw,
+                             uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b,
+                             const uint16_t *crows, int nst, int *npiv_out) {
+    const int lane = threadIdx.x & 63;
+    const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
+    constexpr int NB = 16;              // columns per step, four lanes (words) each
+    const int c = lane >> 2, w = lane & 3;
+    const bool wact = w < wm;
+    const int wl = wact ? w : 0;
+    uint64_t t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) t[q][x] = (x == q && q * 64 + lane < m) ? (1ull << lane) : 0ull;
+    uint64_t Pw = 0;                    // word w of the pivoted-row mask (replicated per column group)
+    int npiv = 0, rowadds = 0, p = 0;
+#ifdef SWD_BPPROF
+    long long acc_scan = 0, acc_upd = 0, acc_f1 = 0; int nscan = 0;
+#endif
+    while (p < n && npiv < rank) {
+#ifdef SWD_BPPROF
+        long long t0 = clock64(); ++nscan;
+#endif
+        const int pc = p + c;
+        const bool cval = wact && pc < n;
+        int rows[DM];
+        if (p + NB <= nst) { // wave-uniform: whole step inside the staged prefix
+#pragma unroll
+            for (int k = 0; k < DM; ++k) rows[k] = crows[pc * DM + k];
+        } else {             // beyond the staged prefix (rare): straight from the graph
+            const int v = cval ? (int)order[pc] : 0;
+            const int deg = cval ? (int)g.col_deg[v] : 0;
+#pragma unroll
+            for (int k = 0; k < DM; ++k) rows[k] = (k < deg) ? (int)g.vn_row[k * n + v] : 0xFFFF;
+        }
+        uint64_t tw[DM];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) tw[k] = Tw[osd_tidx(rows[k] == 0xFFFF ? 0 : rows[k], wl, m)];
+        uint64_t red = 0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) red ^= (rows[k] == 0xFFFF) ? 0ull : tw[k];
+        if (!cval) red = 0ull;
+        uint64_t cand = red & ~Pw;
+        bool found = false;
+#ifdef SWD_BPPROF
+        long long tA = clock64();
+        acc_scan += tA - t0;
+#endif
+        for (;;) {
+            const unsigned long long bal = __ballot(cand != 0ull);
+            if (bal == 0ull) break;
+            found = true;
+            const int fl = __ffsll((long long)bal) - 1; // first column with a usable 1, its lowest word
+            const int cs = fl >> 2, ws = fl & 3;
+            const int bit = __ffsll((long long)wave_read64(cand, fl)) - 1;
+            const int r = ws * 64 + bit;
+            {   // row additions the reference's LU would apply: unpivoted rows with a 1 in this column
+                uint64_t un = (c == cs) ? cand : 0ull;
+                if (lane == fl) un &= ~(1ull << bit);
+                rowadds += __popcll(un);
+            }
+            const uint64_t redc = (lane == fl) ? (red & ~(1ull << bit)) : red;
+            uint64_t S[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) S[x] = wave_read64(redc, cs * 4 + x);
+            if (w == ws) Pw |= 1ull << bit;
+            if (lane == 0) { piv_col[npiv] = order[p + cs]; piv_row[npiv] = (uint16_t)r; }
+            ++npiv;
+            switch (ws) { // wave-uniform
+            case 0: osd_treg_update<0>(t, bit, S); break;
+            case 1: osd_treg_update<1>(t, bit, S); break;
+            case 2: osd_treg_update<2>(t, bit, S); break;
+            default: osd_treg_update<3>(t, bit, S); break;
+            }
+            if (npiv >= rank) break;
+            // the step's later columns under the same row operation
+            const uint64_t yr = __shfl(red, (lane & ~3) | ws, 64);
+            const uint64_t Sw = (w == 0) ? S[0] : (w == 1) ? S[1] : (w == 2) ? S[2] : S[3];
+            if (c > cs && ((yr >> bit) & 1ull)) red ^= Sw;
+            cand = (c > cs) ? (red & ~Pw) : 0ull;
+        }
+        if (found) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = q * 64 + lane;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (j < m && x < wm) Tw[osd_tidx(j, x, m)] = t[q][x];
+            }
+            wave_fence();
+        }
+        p += NB;
+#ifdef SWD_BPPROF
+        acc_upd += clock64() - tA;
+#endif
+    }
+#ifdef SWD_BPPROF
+    if (lane == 0) { s.scal[20] = nscan; s.scal[21] = (int)(acc_scan >> 4); s.scal[22] = (int)(acc_upd >> 4); s.scal[23] = (int)(acc_f1 >> 4); }
+#endif
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) rowadds += __shfl_xor(rowadds, d, 64);
+    // y = T * s  (s in original row order): XOR of the owned columns the syndrome selects, reduced over the wave
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = q * 64 + lane;
+            if (j < m && synd_b[j]) acc ^= t[q][x];
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+        if (lane == 0 && x < wm) Sbuf[x] = acc;
+    }
+    wave_fence();
+    for (int i = lane; i < npiv; i += 64) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+    }
+    wave_fence();
+    *npiv_out = npiv;
+    return rowadds;
+}
+
 // Higher-order OSD sweep (osd_window.pyx:242-284): after OSD-0, try the osd_cs candidates (every
 // weight-1 pattern on the k = new_n - rank non-pivot columns of the first new_n sorted columns, then
 // the weight-2 patterns on the first `order` of them, osd_cs_setup :134-155) or the 2^order osd_e
@@ -977,7 +1125,8 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
     __syncthreads();
     if (tid < 64) {
         int npiv;
-        const int ra = osd0_wave<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
+        const int ra = (g.wm <= 4) ? osd0_wave_reg<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv)
+                                   : osd0_wave<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
         if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
     }
     __syncthreads();
@@ -1094,6 +1243,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         }
     }
     const bool any_contra = block_any<NT>(contra, s);
+#ifdef SWD_SHPROF
+    long long sh0 = wall_clock64();
+#endif
     if (any_contra) {
         // "setting vn failed" (osd_window.pyx:179-181): the reference stops at the first decimation
         // that empties an unsatisfied check; only VNs up to that sorted position were zeroed.
@@ -1127,6 +1279,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         if (tid == 0) { s.scal[1] = bad ? 1 : 0; s.scal[2] = 0; s.scal[3] = 0; }
     }
     __syncthreads();
+#ifdef SWD_SHPROF
+    long long sh1 = wall_clock64();
+#endif
     if (s.scal[1]) {
         R.exit_class = SWD_EXIT_FAIL_PEEL;
         R.total_it = R.pre_it;
@@ -1161,6 +1316,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         if (lc) { atomicAdd(&s.scal[2], lc); atomicAdd(&s.scal[3], le); }
     }
     __syncthreads();
+#ifdef SWD_SHPROF
+    long long sh2 = wall_clock64();
+#endif
     R.live_vn = nlive; R.live_cn = s.scal[2]; R.live_e = s.scal[3];
     vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
     cn_cache_load<NT, KG, false>(g, s, uselist, cn);
@@ -1168,6 +1326,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     bp_init<VF, DM>(s, vc);
     __syncthreads();
     R.t[4] = wall_clock64();
+#ifdef SWD_SHPROF
+    if (tid == 0) { s.scal[20] = (int)(sh0 - R.t[3]); s.scal[21] = (int)(sh1 - sh0); s.scal[22] = (int)(sh2 - sh1); s.scal[23] = (int)(R.t[4] - sh2); }
+#endif
     R.conv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it, P.alpha);
     R.post_it = it;
     R.t[5] = wall_clock64();
@@ -1273,6 +1434,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
 #ifdef SWD_BPPROF
                 pr[0] = s.scal[24]; pr[5] = s.scal[25]; pr[6] = s.scal[26]; pr[7] = s.scal[27];
                 pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
+#endif
+#ifdef SWD_SHPROF
+                pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
+                if (tid == 0) { s.scal[20] = s.scal[21] = s.scal[22] = s.scal[23] = 0; }
 #endif
             }
         }
