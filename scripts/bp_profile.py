@@ -27,3 +27,8 @@ if osd.any():
     print("OSD shots: steps mean %.0f max %.0f ; cycles: all step evaluations %.0f ; first fence %.0f ; T updates %.0f" % (
         prof[..., 1][osd].mean(), prof[..., 1][osd].max(), 16 * prof[..., 2][osd].mean(), 16 * prof[..., 4][osd].mean(), 16 * prof[..., 3][osd].mean()))
 print("post ticks(100MHz)/iter: %.1f us" % (prof[..., 4][sel].sum() / post[sel].sum() / 100.0))
+w = st[..., 7][sel].astype(np.uint32)
+wm = np.stack([(w >> (8 * i)) & 0xFF for i in range(4)], -1)
+print("post-phase positions walked per wave (mean):", wm.mean(0).round(1).tolist(), " max of waves mean %.1f" % wm.max(1).mean(),
+      " live edges per live check mean %.1f" % (st[..., 6][sel] / np.maximum(st[..., 5][sel], 1)).mean(),
+      " live checks %.0f live vns %.0f" % (st[..., 5][sel].mean(), st[..., 4][sel].mean()))

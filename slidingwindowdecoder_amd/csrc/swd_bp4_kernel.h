@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
     Lds s;
     s.scratch = smem; s.msg = msgx; s.hard = (uint8_t *)(smem + a.L.off_hard);
     s.flags = (int *)(smem + a.L.off_misc); s.scal = s.flags + 32; s.dbl = (double *)(s.scal + 32); s.iaux = (int *)(s.dbl + 24);
-    s.fpar = 0;
+    s.fpar = 0; s.ctid = s.vtid = threadIdx.x;
     const uint8_t *sx_b = a.sx + (int64_t)b * mx, *sz_b = a.sz + (int64_t)b * mz;
     double *lpr_b = a.lpr + (int64_t)b * 3 * n;
 

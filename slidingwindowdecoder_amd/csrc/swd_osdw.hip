@@ -34,6 +34,9 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
     const int rare_bytes = L.off_aux + std::max(n * 2, 3 * 256 * 4); // failed-decimation positions / select histograms
     // messages + slot E + one far and one zero slot per wave (swd_osdw_kernel.h, VnCache)
     int scratch = std::max(std::max((E + 1 + 2 * (nt / 64)) * 8, osd_bytes), std::max(rare_bytes, n * 2));
+    // post-phase check order (degree histogram + order): behind the staged slot lists when those fit
+    L.off_cord = align_up((g.K * m * 2 <= scratch) ? std::max(L.off_aux, g.K * m * 2) : L.off_aux, 16);
+    scratch = std::max(scratch, L.off_cord + 66 * 4 + m * 2);
     scratch = align_up(scratch, 16);
     int o = scratch;
     L.off_livemask = o; o += m * 8;

@@ -24,6 +24,7 @@ struct SwdLdsLayout {
     int32_t off_cs;    // inside scratch: arrays of the higher-order OSD sweep
     int32_t cs_par;    // threads that evaluate OSD candidates concurrently (<= 256)
     int32_t off_gdg;   // guessing decoders: persistent per-shot arrays (outside scratch), -1 if unused
+    int32_t off_cord;  // inside scratch: degree histogram + check order of the post phase (clear of lslot and the keys' tail)
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -99,7 +100,38 @@ struct Lds {
     double *dbl;        // [24]
     int *iaux;          // [32]
     int fpar;
+    // work assignment ids (== threadIdx.x up to a permutation of the waves, see swd_wave_roles): ctid picks
+    // the check a thread serves, vtid its variable nodes
+    int ctid, vtid;
 };
+
+// The CN pass of a wave costs its heaviest check, and checks are dealt to the waves heaviest first, so
+// wave "role 0" is always the slowest.  Two shots share a CU; if both put role 0 on the same SIMD that
+// SIMD is the bottleneck while the others idle.  Roles are therefore taken from the hardware SIMD the
+// wave sits on, shifted by the wave slot the workgroup's first wave got (co-resident workgroups get
+// different slots), and the VN work is dealt in the opposite order.  Any bijection is correct; if the
+// four waves do not sit on four different SIMDs the identity is used.  word: 2 ints of LDS.
+template <int NT>
+__device__ __forceinline__ void swd_wave_roles(Lds &s, uint32_t *word) {
+    const int tid = threadIdx.x;
+    s.ctid = s.vtid = tid;
+    if constexpr (NT == 256) {
+        const int wave = tid >> 6, lane = tid & 63;
+        const uint32_t simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // HW_ID.SIMD_ID
+        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); // HW_ID.WAVE_ID
+        if (tid == 0) { word[0] = 0; word[1] = slot; }
+        __syncthreads();
+        if (lane == 0) atomicOr(&word[0], 1u << simd);
+        __syncthreads();
+        if (word[0] == 0xFu) {
+            const int role = (int)((simd + 2u * (word[1] & 1u)) & 3u);
+            s.ctid = role * 64 + lane;
+            s.vtid = (3 - role) * 64 + lane;
+        }
+        (void)wave;
+        __syncthreads();
+    }
+}
 
 template <int NT>
 __device__ __forceinline__ bool block_any(bool p, Lds &s) {
@@ -196,7 +228,7 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
     const uint32_t dead = ((uint32_t)swd_slot_zero<NT>(g) << 3) | ((uint32_t)g.m << 19);
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
-        const int idx = threadIdx.x + i * NT;
+        const int idx = s.vtid + i * NT;
         c.llr[i] = 0.0;
 #pragma unroll
         for (int k = 0; k < DM; ++k) c.ed[i][k] = dead;
@@ -241,13 +273,16 @@ struct CnCache {
     uint32_t sl[KG * 2];
     int cnt;  // positions to walk (0 for lanes without a live check)
     int live; // live edges among them
+    int l;    // the check (lane numbering of the graph) this thread serves, -1 for none
     __device__ __forceinline__ int slot(int k) const { return (int)((sl[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu); }
 };
 
 template <int NT, int KG, bool FULL>
-__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, CnCache<KG> &cc) {
-    const int l = threadIdx.x, m = g.m, dummy = swd_slot_far(g);
-    const bool act = (l < m) && (s.cn_val[l] >= 0);
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, CnCache<KG> &cc) {
+    const int m = g.m, dummy = swd_slot_far(g);
+    const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
+    const int l = act ? lc : 0;
+    cc.l = act ? lc : -1;
     // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
     const bool bylist = !FULL && uselist;
     const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
@@ -285,8 +320,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
     const bool record_all = P.record_all != 0;
-    const int l = tid;                       // NT >= m: one check per lane
-    const int cv = (l < m) ? (int)s.cn_val[l] : -1;
+    const int l = cn.l >= 0 ? cn.l : 0;      // NT >= m: at most one check per thread
+    const int cv = (cn.l >= 0) ? (int)s.cn_val[l] : -1;
     const int cnt = cn.cnt;
     const int wmax = wave_max(cnt);
     const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
@@ -294,6 +329,9 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     constexpr int NR = (K4 + 31) / 32;       // sign shift registers
     iters_done = 0;
     if (max_iter <= 0) return 0;
+#ifdef SWD_BPPROF
+    if (!FULL && (tid & 63) == 0) ((uint8_t *)&s.scal[28])[tid >> 6] = (uint8_t)wmax;
+#endif
     s.msg[farslot] = 64.0;
     s.msg[zeroslot] = 0.0;
     char *const parb = (char *)s.par;
@@ -360,7 +398,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             // the first position holding the minimum gets the second minimum (ties: both equal).
             // Its own sign is re-read before the slots are overwritten.
             const double xarg = s.msg[argslot];
-            if (cn.live == 1) min2 = 1e308; // minimum over no other edge
+            if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
             const double p1 = min1 * alpha, p2 = min2 * alpha;
             const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
 #pragma unroll
@@ -395,7 +433,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         const bool record = record_all || it >= max_iter - 4;
 #pragma unroll
         for (int i = 0; i < VF; ++i) {
-            const int idx = tid + i * NT;
+            const int idx = s.vtid + i * NT;
             if (idx >= vcnt) continue;
             const int v = FULL ? idx : (int)s.lv[idx];
             double cc[DM], pre[DM];
@@ -1192,7 +1230,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     bp_init<VF, DM>(s, vc);
     CnCache<KG> cn;
-    cn_cache_load<NT, KG, true>(g, s, false, cn);
+    cn_cache_load<NT, KG, true>(g, s, false, s.ctid < m ? s.ctid : -1, cn);
     __syncthreads();
 
     int it = 0;
@@ -1290,6 +1328,11 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // ---- compact the live VNs, re-initialise their messages (osd_window.pyx:187)
     const bool uselist = L.off_lslot >= 0;
     int nlive;
+    // live checks are dealt to the threads in order of decreasing live degree (counting sort): a wave's
+    // CN pass costs its largest degree, and after shortening the degrees are very uneven
+    int *dhist = (int *)(s.scratch + L.off_cord);      // [65]
+    uint16_t *cord = (uint16_t *)(dhist + 66);          // [m]
+    for (int i = tid; i < 65; i += NT) dhist[i] = 0;
     {
         const int ch = (n + NT - 1) / NT;
         const int v0 = tid * ch, v1 = min(n, v0 + ch);
@@ -1303,6 +1346,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
             if (s.cn_val[l] >= 0) {
                 ++lc;
                 le += __popcll(s.livemask[l]);
+                atomicAdd(&dhist[min((int)s.cn_deg[l], 64)], 1);
                 // compact list of the live edge slots of this check (post-phase CN pass)
                 uint64_t mk = uselist ? s.livemask[l] : 0ull;
                 int k = 0;
@@ -1320,8 +1364,23 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     long long sh2 = wall_clock64();
 #endif
     R.live_vn = nlive; R.live_cn = s.scal[2]; R.live_e = s.scal[3];
+    if (tid < 64) { // bin d = 64 - lane: exclusive prefix in order of decreasing degree
+        const int d = 64 - tid;
+        const int c0 = dhist[d];
+        int incl = c0;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int y = __shfl_up(incl, dd, 64);
+            if (tid >= dd) incl += y;
+        }
+        dhist[d] = incl - c0;
+    }
+    __syncthreads();
+    for (int l = tid; l < m; l += NT)
+        if (s.cn_val[l] >= 0) cord[atomicAdd(&dhist[min((int)s.cn_deg[l], 64)], 1)] = (uint16_t)l;
+    __syncthreads();
     vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
-    cn_cache_load<NT, KG, false>(g, s, uselist, cn);
+    cn_cache_load<NT, KG, false>(g, s, uselist, s.ctid < R.live_cn ? (int)cord[s.ctid] : -1, cn);
     __syncthreads(); // every lane has read its slot list before the messages are re-initialised
     bp_init<VF, DM>(s, vc);
     __syncthreads();
@@ -1377,6 +1436,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
     s.fpar = 0;
     uint32_t *acc = (uint32_t *)(smem + a.off_det) - 4; // 16 bytes below sdet are reserved by the host
     if (tid == 0) { acc[0] = 0; acc[1] = 0; }
+    swd_wave_roles<NT>(s, acc + 2);
     __syncthreads();
     for (int wi = 0; wi < a.W; ++wi) {
         const SwdWindowDev &w = a.wins[wi];
@@ -1418,6 +1478,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                 st[0] = R.exit_class | (R.conv ? SWD_STATUS_CONVERGE : 0);
                 st[1] = R.total_it; st[2] = R.pre_it; st[3] = R.post_it;
                 st[4] = R.live_vn; st[5] = R.live_cn; st[6] = R.live_e; st[7] = R.osd_rowadds;
+#ifdef SWD_BPPROF
+                if (R.post_it > 0) st[7] = s.scal[28];
+#endif
             }
             if (a.min_pm) a.min_pm[(int64_t)b * a.W + wi] = R.pm;
             if (a.prof) {
