@@ -57,7 +57,7 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
     L.off_cndeg = o; o += m;
     L.off_cndeg0 = o; o += m;
     L.off_vnval = o; o += n;
-    L.off_hard = o; o = align_up(o + n, 16);
+    L.off_hard = o; o = align_up(o + n + 1, 16); // +1: sink for threads without a VN
     L.off_misc = o; o += 640; // flags[32] scal[32] dbl[24] iaux[32]
     L.total = align_up(o, 16);
     return 0;

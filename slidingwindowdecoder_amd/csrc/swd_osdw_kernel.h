@@ -210,12 +210,14 @@ __device__ __forceinline__ void wave_fence() {
 //     <= 50) to first or second minimum of a check with >= 2 live edges, and never counts as
 //     negative; checks with one live edge get their "minimum of nothing" (1e308) patched in after
 //     the loop.  D_w / Z_w are only touched by their own wave, whose LDS operations execute in order.
-// ed = byte offset of the edge's message slot | (index into par[], m for dead positions) << 19.
-constexpr uint32_t kEdAddrMask = 0x7FFF8u;
+// ed = byte offset of the edge's message slot (a ready LDS address: nothing to recompute or to keep a
+// second copy of per iteration); par = index into par[] of the edge's check, two per word, m for
+// dead positions.
 template <int VF, int DM>
 struct VnCache {
     double llr[VF];
     uint32_t ed[VF][DM];
+    uint32_t par[VF][(DM + 1) / 2];
 };
 
 __device__ __forceinline__ int swd_slot_far(const SwdGraphDev &g) { return g.E + 1 + (int)(threadIdx.x >> 6); }
@@ -225,13 +227,15 @@ __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E 
 template <int NT, int VF, int DM, bool FULL>
 __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCache<VF, DM> &c) {
     const int n = g.n, cnt = FULL ? n : nlive;
-    const uint32_t dead = ((uint32_t)swd_slot_zero<NT>(g) << 3) | ((uint32_t)g.m << 19);
+    const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         const int idx = s.vtid + i * NT;
         c.llr[i] = 0.0;
 #pragma unroll
         for (int k = 0; k < DM; ++k) c.ed[i][k] = dead;
+#pragma unroll
+        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
         if (idx < cnt) {
             const int v = FULL ? idx : (int)s.lv[idx];
             const int deg = g.col_deg[v];
@@ -240,14 +244,18 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
             for (int k = 0; k < DM; ++k) {
                 if (k < deg) {
                     const uint32_t e = g.vn_edge[k * n + v];
-                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) c.ed[i][k] = (swd_edge_slot(e) << 3) | (swd_edge_lane(e) << 19);
+                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
+                        c.ed[i][k] = swd_edge_slot(e) << 3;
+                        c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
+                                                   : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
+                    }
                 }
             }
         }
     }
 }
 
-__device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + (ed & kEdAddrMask)); }
+__device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
 template <int VF, int DM>
@@ -270,11 +278,11 @@ __device__ __forceinline__ int wave_max(int x) {
 // KG = groups of four positions.
 template <int KG>
 struct CnCache {
-    uint32_t sl[KG * 2];
+    uint16_t sl[KG * 4];
     int cnt;  // positions to walk (0 for lanes without a live check)
     int live; // live edges among them
     int l;    // the check (lane numbering of the graph) this thread serves, -1 for none
-    __device__ __forceinline__ int slot(int k) const { return (int)((sl[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu); }
+    __device__ __forceinline__ int slot(int k) const { return (int)sl[k]; }
 };
 
 template <int NT, int KG, bool FULL>
@@ -290,17 +298,11 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
     cc.cnt = cnt;
     cc.live = act ? (int)s.cn_deg[l] : 0;
 #pragma unroll
-    for (int q = 0; q < KG * 2; ++q) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 2 * q + h;
-            int sv = dummy;
-            if (k < cnt && ((lmask >> (k & 63)) & 1ull))
-                sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
-            w |= (uint32_t)sv << (16 * h);
-        }
-        cc.sl[q] = w;
+    for (int k = 0; k < KG * 4; ++k) {
+        int sv = dummy;
+        if (k < cnt && ((lmask >> (k & 63)) & 1ull))
+            sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
+        cc.sl[k] = (uint16_t)sv;
     }
 }
 
@@ -329,6 +331,9 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     constexpr int NR = (K4 + 31) / 32;       // sign shift registers
     iters_done = 0;
     if (max_iter <= 0) return 0;
+    // VNs this wave walks (wave-uniform): entries vtid + i*NT < vcnt for some lane
+    const int wbase = s.vtid & ~63;
+    const int nch = __builtin_amdgcn_readfirstlane((vcnt > wbase) ? min(VF, (vcnt - wbase + NT - 1) / NT) : 0);
 #ifdef SWD_BPPROF
     if (!FULL && (tid & 63) == 0) ((uint8_t *)&s.scal[28])[tid >> 6] = (uint8_t)wmax;
 #endif
@@ -431,30 +436,49 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 
         const int slot_h = it & 3;
         const bool record = record_all || it >= max_iter - 4;
+        // VN pass (osd_window.pyx:442-471), software-pipelined over the thread's VNs: the messages of the
+        // next VN are read before this one's are written (no two VNs share an edge; the zero slot is
+        // re-armed after every VN's writes, i.e. before the reads two VNs ahead are issued)
+        double cnx[DM];
+        if (nch > 0) {
+#pragma unroll
+            for (int k = 0; k < DM; ++k) cnx[k] = swd_msg_at(s, c.ed[0][k]);
+        }
 #pragma unroll
         for (int i = 0; i < VF; ++i) {
-            const int idx = s.vtid + i * NT;
-            if (idx >= vcnt) continue;
-            const int v = FULL ? idx : (int)s.lv[idx];
-            double cc[DM], pre[DM];
+            if (i < nch) { // wave-uniform
+                const int idx = s.vtid + i * NT;
+                const bool valid = idx < vcnt; // threads past the end carry all-dead positions and a zero prior
+                const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
+                double cc[DM], pre[DM];
 #pragma unroll
-            for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, c.ed[i][k]);
-            double temp = c.llr[i];
+                for (int k = 0; k < DM; ++k) cc[k] = cnx[k];
+                if (i + 1 < VF && i + 1 < nch) {
 #pragma unroll
-            for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
-            if (record) hist_b[slot_h * n + v] = temp;
-            const bool hd = (temp <= 0);
-            s.hard[v] = hd ? 1 : 0;
-            double suf = 0.0;
+                    for (int k = 0; k < DM; ++k) cnx[k] = swd_msg_at(s, c.ed[i + 1 < VF ? i + 1 : i][k]);
+                }
+                double temp = c.llr[i];
 #pragma unroll
-            for (int k = DM - 1; k >= 0; --k) {
-                swd_msg_at(s, c.ed[i][k]) = pre[k] + suf;
-                suf = suf + cc[k];
-            }
-            s.msg[zeroslot] = 0.0; // re-arm
-            if (hd) {
+                for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
+                if (record && valid) hist_b[slot_h * n + v] = temp;
+                const bool hd = valid && (temp <= 0);
+                s.hard[v] = hd ? 1 : 0; // hard[n] is a spare byte
+                double suf = 0.0;
 #pragma unroll
-                for (int k = 0; k < DM; ++k) atomicXor((uint32_t *)(parb + ((c.ed[i][k] >> 17) & 0x1FFCu)), 1u); // dead: par[m]
+                for (int k = DM - 1; k >= 0; --k) {
+                    swd_msg_at(s, c.ed[i][k]) = pre[k] + suf;
+                    suf = suf + cc[k];
+                }
+                s.msg[zeroslot] = 0.0; // re-arm
+                if (hd) {
+#pragma unroll
+                    for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
+                        uint32_t pw = c.par[i][k2];
+                        asm volatile("" : "+v"(pw)); // keep the address arithmetic here instead of in 2*DM*VF hoisted registers
+                        atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u); // dead: par[m]
+                        if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
+                    }
+                }
             }
         }
         BPT(tc3);
