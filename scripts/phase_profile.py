@@ -4,6 +4,8 @@ import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from slidingwindowdecoder_amd import _lib
+if os.environ.get("SWD_LIB"): _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["SWD_LIB"])
 from slidingwindowdecoder_amd import SlidingWindowDecoder
 from slidingwindowdecoder_amd.windows import sample_dem
 shots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

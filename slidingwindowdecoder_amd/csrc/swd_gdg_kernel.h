@@ -102,7 +102,7 @@ __device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, co
         }
     __syncthreads();
     vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
-    cn_cache_load<NT, KG, false>(g, s, true, s.ctid < g.m ? s.ctid : -1, cn);
+    cn_cache_load<NT, KG, false>(g, s, true, s.ctid < g.m ? s.ctid : -1, 0, 1, cn);
     __syncthreads();
     return nlive;
 }
@@ -328,7 +328,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     CnCache<KG> cn;
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     bp_init<VF, DM>(s, vc);
-    cn_cache_load<NT, KG, true>(g, s, false, s.ctid < g.m ? s.ctid : -1, cn);
+    cn_cache_load<NT, KG, true>(g, s, false, s.ctid < g.m ? s.ctid : -1, 0, 1, cn);
     __syncthreads();
     int it = 0;
     R.conv = 0; R.pm = 0.0; R.pre_it = R.post_it = 0;

@@ -81,7 +81,7 @@ struct Variant {
     int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);      // osd_window kernels
     int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing-decoder kernels
 };
-static const Variant *select_variant(int mmax, int nmax, int dm, int kmax);
+static const Variant *select_variant(int mmax, int nmax, int dm, int kmax, int kind);
 
 // A decode plan: 1..W windows + (for W > 1 or commit > 0) the global check matrix in CSC form.
 struct Plan {
@@ -160,7 +160,7 @@ struct Plan {
         int kmax = 0;
         mmax = 0;
         for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
-        variant = select_variant(mmax, nmax, dm, kmax);
+        variant = select_variant(mmax, nmax, dm, kmax, kind);
         if (!variant) {
             set_error("no kernel variant for m=%d n=%d column weight %d row weight %d", mmax, nmax, dm, kmax);
             return -1;
@@ -216,8 +216,6 @@ struct Plan {
 
 
 template <int NT, int VF, int DM, int KG, int KIND>
-static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st);
-template <int NT, int VF, int DM, int KG, int KIND>
 static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
     static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
     if (d->lds_total > lds_limit[d->device & 63]) {
@@ -230,19 +228,23 @@ static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
 }
 
 static const Variant kVariants[] = {
+#ifndef SWD_HEADLINE_ONLY // development builds: -DSWD_HEADLINE_ONLY compiles only the [[144,12,12]] kernel
     {64, 4, 4, 2, launch_nt<64, 4, 4, 2, 0>, launch_nt<64, 4, 4, 2, 1>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
     {64, 4, 8, 16, launch_nt<64, 4, 8, 16, 0>, launch_nt<64, 4, 8, 16, 1>},
     {256, 2, 8, 16, launch_nt<256, 2, 8, 16, 0>, launch_nt<256, 2, 8, 16, 1>},
     {256, 4, 8, 16, launch_nt<256, 4, 8, 16, 0>, launch_nt<256, 4, 8, 16, 1>},
+#endif
     {256, 7, 6, 9, launch_nt<256, 7, 6, 9, 0>, launch_nt<256, 7, 6, 9, 1>},      // [[144,12,12]] circuit-level windows
+#ifndef SWD_HEADLINE_ONLY
     {256, 7, 8, 16, launch_nt<256, 7, 8, 16, 0>, launch_nt<256, 7, 8, 16, 1>},
     {1024, 5, 6, 9, launch_nt<1024, 5, 6, 9, 0>, launch_nt<1024, 5, 6, 9, 1>},    // [[288,12,18]] circuit-level windows
     {1024, 8, 8, 16, launch_nt<1024, 8, 8, 16, 0>, launch_nt<1024, 8, 8, 16, 1>},
+#endif
 };
 
-static const Variant *select_variant(int mmax, int nmax, int dm, int kmax) {
+static const Variant *select_variant(int mmax, int nmax, int dm, int kmax, int kind) {
     for (const Variant &v : kVariants)
-        if (v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm && 4 * v.kg >= kmax) return &v;
+        if ((kind == 0 ? v.launch != nullptr : v.launch_gdg != nullptr) && v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm && 4 * v.kg >= kmax) return &v;
     return nullptr;
 }
 

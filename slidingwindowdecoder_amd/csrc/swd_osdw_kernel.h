@@ -282,28 +282,46 @@ struct CnCache {
     int cnt;  // positions to walk (0 for lanes without a live check)
     int live; // live edges among them
     int l;    // the check (lane numbering of the graph) this thread serves, -1 for none
+    int sub;  // which of the check's grp threads this is (it walks positions sub, sub + grp, ...)
+    int grp;  // 1, 2 or 4 adjacent threads (lanes of one quad) share the check
     __device__ __forceinline__ int slot(int k) const { return (int)sl[k]; }
 };
 
+// grp = 1, 2 or 4 threads share a check (adjacent lanes of a quad): thread `sub` walks positions sub, sub + grp, ...
 template <int NT, int KG, bool FULL>
-__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, CnCache<KG> &cc) {
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCache<KG> &cc) {
     const int m = g.m, dummy = swd_slot_far(g);
     const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
     const int l = act ? lc : 0;
     cc.l = act ? lc : -1;
+    cc.sub = sub;
+    cc.grp = grp;
     // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
     const bool bylist = !FULL && uselist;
     const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
     const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : s.livemask[l];
-    cc.cnt = cnt;
+    cc.cnt = (cnt > sub) ? (cnt - sub + grp - 1) / grp : 0;
     cc.live = act ? (int)s.cn_deg[l] : 0;
 #pragma unroll
-    for (int k = 0; k < KG * 4; ++k) {
+    for (int kk = 0; kk < KG * 4; ++kk) {
+        const int k = kk * grp + sub;
         int sv = dummy;
         if (k < cnt && ((lmask >> (k & 63)) & 1ull))
             sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
-        cc.sl[k] = (uint16_t)sv;
+        cc.sl[kk] = (uint16_t)sv;
     }
+}
+
+// value of the lane `lane ^ X` (X = 1 or 2) of the same quad
+template <int X>
+__device__ __forceinline__ int quad_xor(int v) {
+    return __builtin_amdgcn_mov_dpp(v, X == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true);
+}
+template <int X>
+__device__ __forceinline__ double quad_xor(double v) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)quad_xor<X>((int)(uint32_t)b), hi = (uint32_t)quad_xor<X>((int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 // fp64 min / max without the canonicalising v_max x,x the compiler puts in front of fmin/fmax
@@ -351,7 +369,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
         BPT(tc0);
         {
-            if (cv >= 0) {
+            if (cv >= 0 && cn.sub == 0) {
                 if (it > 0 && s.par[l] != 0u) unsat = true;
                 s.par[l] = (uint32_t)cv;
             }
@@ -396,9 +414,34 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             }
             // ... after this alignment of a partly filled last register
             if (K4 & 31) neg[NR - 1] <<= (32 - (K4 & 31));
-            int npar = cv;
+            int npar = (cn.sub == 0) ? cv : 0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) npar += __popc(neg[r]);
+            if constexpr (!FULL) {
+                // merge the partial results of the check's threads (butterfly inside the quad).  On a tie
+                // of the minima the second minimum equals the first, so which side's position is kept
+                // as "first minimum" does not change any value written below.
+                {
+                    const double o1 = quad_xor<1>(min1), o2 = quad_xor<1>(min2);
+                    const int oa = quad_xor<1>(argslot), op = quad_xor<1>(npar);
+                    if (cn.grp >= 2) {
+                        npar += op;
+                        argslot = (o1 < min1) ? oa : argslot;
+                        min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
+                        min1 = vmin64(min1, o1);
+                    }
+                }
+                {
+                    const double o1 = quad_xor<2>(min1), o2 = quad_xor<2>(min2);
+                    const int oa = quad_xor<2>(argslot), op = quad_xor<2>(npar);
+                    if (cn.grp == 4) {
+                        npar += op;
+                        argslot = (o1 < min1) ? oa : argslot;
+                        min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
+                        min1 = vmin64(min1, o1);
+                    }
+                }
+            }
             const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
             // the first position holding the minimum gets the second minimum (ties: both equal).
             // Its own sign is re-read before the slots are overwritten.
@@ -436,33 +479,23 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 
         const int slot_h = it & 3;
         const bool record = record_all || it >= max_iter - 4;
-        // VN pass (osd_window.pyx:442-471), software-pipelined over the thread's VNs: the messages of the
-        // next VN are read before this one's are written (no two VNs share an edge; the zero slot is
-        // re-armed after every VN's writes, i.e. before the reads two VNs ahead are issued)
-        double cnx[DM];
-        if (nch > 0) {
-#pragma unroll
-            for (int k = 0; k < DM; ++k) cnx[k] = swd_msg_at(s, c.ed[0][k]);
-        }
+        // VN pass (osd_window.pyx:442-471).  (Reading the next VN's messages before this one's are written
+        // was tried and is slower.)
 #pragma unroll
         for (int i = 0; i < VF; ++i) {
             if (i < nch) { // wave-uniform
                 const int idx = s.vtid + i * NT;
-                const bool valid = idx < vcnt; // threads past the end carry all-dead positions and a zero prior
+                const bool valid = idx < vcnt;
                 const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
                 double cc[DM], pre[DM];
 #pragma unroll
-                for (int k = 0; k < DM; ++k) cc[k] = cnx[k];
-                if (i + 1 < VF && i + 1 < nch) {
-#pragma unroll
-                    for (int k = 0; k < DM; ++k) cnx[k] = swd_msg_at(s, c.ed[i + 1 < VF ? i + 1 : i][k]);
-                }
+                for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, c.ed[i][k]);
                 double temp = c.llr[i];
 #pragma unroll
                 for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
                 if (record && valid) hist_b[slot_h * n + v] = temp;
                 const bool hd = valid && (temp <= 0);
-                s.hard[v] = hd ? 1 : 0; // hard[n] is a spare byte
+                s.hard[v] = hd ? 1 : 0;
                 double suf = 0.0;
 #pragma unroll
                 for (int k = DM - 1; k >= 0; --k) {
@@ -474,8 +507,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #pragma unroll
                     for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
                         uint32_t pw = c.par[i][k2];
-                        asm volatile("" : "+v"(pw)); // keep the address arithmetic here instead of in 2*DM*VF hoisted registers
-                        atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u); // dead: par[m]
+                        asm volatile("" : "+v"(pw));
+                        atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u);
                         if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
                     }
                 }
@@ -1254,7 +1287,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     bp_init<VF, DM>(s, vc);
     CnCache<KG> cn;
-    cn_cache_load<NT, KG, true>(g, s, false, s.ctid < m ? s.ctid : -1, cn);
+    cn_cache_load<NT, KG, true>(g, s, false, s.ctid < m ? s.ctid : -1, 0, 1, cn);
     __syncthreads();
 
     int it = 0;
@@ -1391,6 +1424,26 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     if (tid < 64) { // bin d = 64 - lane: exclusive prefix in order of decreasing degree
         const int d = 64 - tid;
         const int c0 = dhist[d];
+        // Heavy checks are shared by 2 or 4 adjacent threads so that no thread walks more than T
+        // positions: smallest T for which one thread per check of degree <= T, two up to 2T and four up
+        // to 4T fit the workgroup.  Sorted by decreasing degree the quads come first, then the pairs.
+        int T = 64, nq = 0, np = 0;
+        if (uselist) {
+            const int cand[8] = {3, 4, 6, 8, 12, 16, 24, 32};
+#pragma unroll 1
+            for (int ci = 0; ci < 8; ++ci) {
+                const int Tc = cand[ci];
+                int need = c0 * (d <= Tc ? 1 : (d <= 2 * Tc ? 2 : 4));
+                int q = (d > 2 * Tc) ? c0 : 0, pr = (d > Tc && d <= 2 * Tc) ? c0 : 0;
+#pragma unroll
+                for (int dd = 32; dd > 0; dd >>= 1) {
+                    need += __shfl_xor(need, dd, 64); q += __shfl_xor(q, dd, 64); pr += __shfl_xor(pr, dd, 64);
+                }
+                const bool toobig = __ballot(c0 > 0 && d > 4 * Tc) != 0ull;
+                if (!toobig && need <= NT && Tc <= KG * 4) { T = Tc; nq = q; np = pr; break; }
+            }
+        }
+        if (tid == 0) { s.iaux[0] = T; s.iaux[1] = nq; s.iaux[2] = np; }
         int incl = c0;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
@@ -1403,8 +1456,15 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     for (int l = tid; l < m; l += NT)
         if (s.cn_val[l] >= 0) cord[atomicAdd(&dhist[min((int)s.cn_deg[l], 64)], 1)] = (uint16_t)l;
     __syncthreads();
+    int cidx, csub, cgrp;
+    {
+        const int nq = s.iaux[1], np = s.iaux[2], ct = s.ctid;
+        if (ct < 4 * nq) { cidx = ct >> 2; csub = ct & 3; cgrp = 4; }
+        else if (ct < 4 * nq + 2 * np) { const int t2 = ct - 4 * nq; cidx = nq + (t2 >> 1); csub = t2 & 1; cgrp = 2; }
+        else { cidx = nq + np + (ct - 4 * nq - 2 * np); csub = 0; cgrp = 1; }
+    }
     vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
-    cn_cache_load<NT, KG, false>(g, s, uselist, s.ctid < R.live_cn ? (int)cord[s.ctid] : -1, cn);
+    cn_cache_load<NT, KG, false>(g, s, uselist, cidx < R.live_cn ? (int)cord[cidx] : -1, csub, cgrp, cn);
     __syncthreads(); // every lane has read its slot list before the messages are re-initialised
     bp_init<VF, DM>(s, vc);
     __syncthreads();
