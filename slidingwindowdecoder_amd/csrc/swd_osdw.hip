@@ -36,7 +36,9 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
     int scratch = std::max(std::max((E + 1 + 2 * (nt / 64)) * 8, osd_bytes), std::max(rare_bytes, n * 2));
     // post-phase check order (degree histogram + order): behind the staged slot lists when those fit
     L.off_cord = align_up((g.K * m * 2 <= scratch) ? std::max(L.off_aux, g.K * m * 2) : L.off_aux, 16);
-    scratch = std::max(scratch, L.off_cord + 66 * 4 + m * 2);
+    L.off_rc = align_up(std::max(L.off_cord + 66 * 4 + m * 2, L.off_aux + 3 * 256 * 4), 16); // clear of the select histograms
+    L.off_bak = align_up(L.off_rc + E * 2, 16);
+    scratch = std::max(scratch, L.off_bak + 10 * m + 2 * n + 8);
     scratch = align_up(scratch, 16);
     int o = scratch;
     L.off_livemask = o; o += m * 8;

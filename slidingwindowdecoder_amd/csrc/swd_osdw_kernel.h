@@ -25,6 +25,8 @@ struct SwdLdsLayout {
     int32_t cs_par;    // threads that evaluate OSD candidates concurrently (<= 256)
     int32_t off_gdg;   // guessing decoders: persistent per-shot arrays (outside scratch), -1 if unused
     int32_t off_cord;  // inside scratch: degree histogram + check order of the post phase (clear of lslot and the keys' tail)
+    int32_t off_rc;    // inside scratch: u16 row_col[E] staged for the shortening step
+    int32_t off_bak;   // inside scratch: state backup of the parallel peel (10 m + 2 n bytes)
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -1317,6 +1319,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
             idx[v] = (uint16_t)v;
         } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
     }
+    // columns of the edges, by slot: the shortening step walks them several times
+    uint16_t *rc = (uint16_t *)(s.scratch + L.off_rc);
+    for (int e = tid; e < g.E; e += NT) rc[e] = g.row_col[e];
     __syncthreads();
     // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
     if (g.new_n < n) select_smallest<NT>(key, n, g.new_n, (int *)(s.scratch + L.off_aux), s);
@@ -1327,7 +1332,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         uint64_t mk = 0;
         int cntl = 0;
         for (int j = 0; j < d; ++j) {
-            const int v = g.row_col[s.jptr[j] + l];
+            const int v = rc[s.jptr[j] + l];
             if (s.vn_val[v] < 0) { mk |= 1ull << j; ++cntl; }
         }
         s.livemask[l] = mk;
@@ -1368,10 +1373,60 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     for (int v = tid; v < n; v += NT)
         if (s.vn_val[v] == 0) s.hard[v] = 0;
     __syncthreads();
-    // ---- peel (osd_window.pyx:184-186)
-    if (tid < 64) {
-        const bool bad = peel_wave(g, s);
-        if (tid == 0) { s.scal[1] = bad ? 1 : 0; s.scal[2] = 0; s.scal[3] = 0; }
+    // ---- peel (osd_window.pyx:184-186).  Degree-1 checks force their last VN; the closure of these
+    // forced values does not depend on the order they are applied in, and a contradiction shows up
+    // in every order.  So all degree-1 checks fire at once, round by round; only when a contradiction
+    // appears is the saved state restored and the reference's sweep order replayed by one wave (the
+    // partial result the reference leaves behind depends on that order).
+    {
+        char *bak = s.scratch + L.off_bak;
+        for (int i = tid; i < n; i += NT) { bak[i] = (char)s.vn_val[i]; bak[n + i] = (char)s.hard[i]; }
+        for (int i = tid; i < m; i += NT) {
+            bak[2 * n + i] = (char)s.cn_val[i]; bak[2 * n + m + i] = (char)s.cn_deg[i];
+            ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i] = s.livemask[i];
+        }
+        bool bad = false;
+        for (;;) {
+            bool fired = false;
+            for (int l = tid; l < m; l += NT) {
+                if (s.cn_val[l] >= 0 && s.cn_deg[l] == 1) {
+                    const int j = __ffsll((long long)s.livemask[l]) - 1;
+                    const int v = rc[s.jptr[j] + l];
+                    const int8_t val = s.cn_val[l];
+                    s.vn_val[v] = val; s.hard[v] = (uint8_t)val;
+                    fired = true;
+                }
+            }
+            if (!block_any<NT>(fired, s)) break;
+            for (int l = tid; l < m; l += NT) {
+                int cv = s.cn_val[l];
+                if (cv < 0) continue;
+                uint64_t mk = s.livemask[l], left = mk;
+                int deg = s.cn_deg[l];
+                while (left) {
+                    const int j = __ffsll((long long)left) - 1;
+                    left &= left - 1;
+                    const int vv = s.vn_val[rc[s.jptr[j] + l]];
+                    if (vv >= 0) { mk &= ~(1ull << j); --deg; cv ^= vv; }
+                }
+                if (deg == 0) { if (cv != 0) bad = true; cv = -1; }
+                s.livemask[l] = mk; s.cn_deg[l] = (uint8_t)deg; s.cn_val[l] = (int8_t)cv;
+            }
+            if (block_any<NT>(bad, s)) { bad = true; break; }
+        }
+        if (bad) {
+            for (int i = tid; i < n; i += NT) { s.vn_val[i] = (int8_t)bak[i]; s.hard[i] = (uint8_t)bak[n + i]; }
+            for (int i = tid; i < m; i += NT) {
+                s.cn_val[i] = (int8_t)bak[2 * n + i]; s.cn_deg[i] = (uint8_t)bak[2 * n + m + i];
+                s.livemask[i] = ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i];
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const bool b2 = peel_wave(g, s);
+                if (tid == 0) s.scal[1] = b2 ? 1 : 0;
+            }
+        } else if (tid == 0) s.scal[1] = 0;
+        if (tid == 0) { s.scal[2] = 0; s.scal[3] = 0; }
     }
     __syncthreads();
 #ifdef SWD_SHPROF
