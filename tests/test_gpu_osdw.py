@@ -159,6 +159,38 @@ def test_random_small_codes_vs_oracle():
         assert np.array_equal(dec.last_status & 0xFF, res["exit_class"])
 
 
+def test_failed_decimation_and_peel_exits_vs_oracle():
+    """Random (mostly inconsistent) syndromes on small ragged codes with a short new_n: the "setting vn
+    failed" and "peeling failed" exits (osd_window.pyx:179-186) leave an order-dependent partial result
+    behind; the device replays the reference's order for them."""
+    rng = np.random.default_rng(23)
+    O = _oracle()
+    seen = set()
+    for trial in range(12):
+        m, n = int(rng.integers(10, 25)), int(rng.integers(60, 220))
+        H = (rng.random((m, n)) < 2.5 / m).astype(np.uint8)
+        for c in range(n):
+            if H[:, c].sum() == 0:
+                H[rng.integers(m), c] = 1
+        for r in range(m):
+            if H[r].sum() == 0:
+                H[r, rng.integers(n)] = 1
+        if H.sum(axis=0).max() > 8 or H.sum(axis=1).max() > 60:
+            continue
+        p = rng.uniform(0.01, 0.08, size=n)
+        kw = dict(channel_probs=p, pre_max_iter=int(rng.integers(1, 5)), post_max_iter=int(rng.integers(1, 20)),
+                  ms_scaling_factor=1.0, osd_method="osd_0", osd_order=0, new_n=int(rng.integers(m, 2 * m)))
+        dec, ora = _dev_cls()(H, **kw), O.osd_window(H, **kw)
+        synd = (rng.random((400, m)) < 0.35).astype(np.uint8)
+        out = dec.decode_batch(synd)
+        want, res = ora.decode_batch(synd)
+        assert (out == want).all(), f"trial {trial}"
+        assert np.array_equal(dec.last_iterations, res["bp_iteration"])
+        assert np.array_equal(dec.last_status & 0xFF, res["exit_class"])
+        seen |= set(np.unique(res["exit_class"]).tolist())
+    assert {3, 4} <= seen, seen
+
+
 def test_constructor_and_decode_errors():
     f = fx.load("bb72_capacity.npz")
     mat, priors = fx.graph(f, "c1_")
