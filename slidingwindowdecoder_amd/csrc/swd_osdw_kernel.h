@@ -855,13 +855,32 @@ __device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uin
 // "rows i != r with u[i] = 1 get row r added" is applied to the owned columns of T and to the reduced
 // vectors of the step's later columns (y ^= S if y[r], S = u without bit r), which is exactly what
 // re-evaluating them against the updated T would give.  The mirror is refreshed once per step.
+// word WS of the calling lane's quad (lane = column * 4 + word)
 template <int WS>
-__device__ __forceinline__ void osd_treg_update(uint64_t (&t)[4][4], int bit, const uint64_t (&S)[4]) {
+__device__ __forceinline__ uint64_t quad_word(uint64_t v) {
+    constexpr int ctrl = WS | (WS << 2) | (WS << 4) | (WS << 6); // quad_perm broadcast of lane WS
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, ctrl, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), ctrl, 0xF, 0xF, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int WS>
+__device__ __forceinline__ void osd_treg_update(uint64_t (&t)[4][4], int bit, const uint64_t (&S)[4], uint64_t &red, uint64_t Sw, bool later) {
+    // the step's later columns under the same row operation: y ^= S if y[r]
+    if (later && ((quad_word<WS>(red) >> bit) & 1ull)) red ^= Sw;
+    // 32-bit halves: the selector is one sign-extended bit of the pivot row's word, S is wave-uniform
+    uint32_t Sl[4], Sh[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { Sl[x] = (uint32_t)S[x]; Sh[x] = (uint32_t)(S[x] >> 32); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint64_t msk = ((t[q][WS] >> bit) & 1ull) ? ~0ull : 0ull;
+        const uint32_t word = (bit < 32) ? (uint32_t)t[q][WS] : (uint32_t)(t[q][WS] >> 32); // wave-uniform choice
+        const uint32_t msk = (uint32_t)__builtin_amdgcn_sbfe((int)word, (uint32_t)(bit & 31), 1u);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) t[q][x] ^= S[x] & msk;
+        for (int x = 0; x < 4; ++x) {
+            const uint32_t lo = (uint32_t)t[q][x] ^ (Sl[x] & msk), hi = (uint32_t)(t[q][x] >> 32) ^ (Sh[x] & msk);
+            t[q][x] = ((uint64_t)hi << 32) | lo;
+        }
     }
 }
 
@@ -938,19 +957,16 @@ __device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const
 #pragma unroll
             for (int x = 0; x < 4; ++x) S[x] = wave_read64(redc, cs * 4 + x);
             if (w == ws) Pw |= 1ull << bit;
-            if (lane == 0) { piv_col[npiv] = order[p + cs]; piv_row[npiv] = (uint16_t)r; }
+            if (lane == 0) { piv_col[npiv] = (uint16_t)(p + cs); piv_row[npiv] = (uint16_t)r; } // position, translated below
             ++npiv;
+            const uint64_t Sw = (w == 0) ? S[0] : (w == 1) ? S[1] : (w == 2) ? S[2] : S[3];
             switch (ws) { // wave-uniform
-            case 0: osd_treg_update<0>(t, bit, S); break;
-            case 1: osd_treg_update<1>(t, bit, S); break;
-            case 2: osd_treg_update<2>(t, bit, S); break;
-            default: osd_treg_update<3>(t, bit, S); break;
+            case 0: osd_treg_update<0>(t, bit, S, red, Sw, c > cs); break;
+            case 1: osd_treg_update<1>(t, bit, S, red, Sw, c > cs); break;
+            case 2: osd_treg_update<2>(t, bit, S, red, Sw, c > cs); break;
+            default: osd_treg_update<3>(t, bit, S, red, Sw, c > cs); break;
             }
             if (npiv >= rank) break;
-            // the step's later columns under the same row operation
-            const uint64_t yr = __shfl(red, (lane & ~3) | ws, 64);
-            const uint64_t Sw = (w == 0) ? S[0] : (w == 1) ? S[1] : (w == 2) ? S[2] : S[3];
-            if (c > cs && ((yr >> bit) & 1ull)) red ^= Sw;
             cand = (c > cs) ? (red & ~Pw) : 0ull;
         }
         if (found) {
@@ -989,7 +1005,9 @@ __device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const
     wave_fence();
     for (int i = lane; i < npiv; i += 64) {
         const int r = piv_row[i];
-        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+        const uint16_t col = order[piv_col[i]];
+        piv_col[i] = col;
+        s.hard[col] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
     }
     wave_fence();
     *npiv_out = npiv;
