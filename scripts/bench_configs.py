@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configurations on one MI355X (bench.py measures configs[1]):
+
+  config 3  [[144,12,12]] circuit-level p=0.003, (W,F)=(3,1), bpgdg_decoder windows (guessing.py:160-173)
+  config 4  [[288,12,18]] circuit-level p=0.003, (W,F)=(4,1), osd_window windows
+  bp4       [[144,12,12]] depolarizing code-capacity noise, bp4_osd (Misc.ipynb cell 2 setting)
+  order10   configs[1] with the notebooks' default OSD-CS order 10
+
+One JSON line per configuration: windows (or decodes) per second from HIP-event kernel time."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from slidingwindowdecoder_amd import SlidingWindowDecoder, bp4_osd
+from slidingwindowdecoder_amd.windows import sample_dem
+from slidingwindowdecoder_amd.codes import bb_code
+
+which = sys.argv[1:] or ["3", "4", "bp4", "order10"]
+
+
+def run_pipeline(name, plan, shots, reps, **kw):
+    dec = SlidingWindowDecoder(plan, **kw)
+    det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=7)
+    d = torch.from_numpy(np.ascontiguousarray(det)).cuda()
+    stats = torch.empty((shots, dec.W, 8), dtype=torch.int32, device="cuda")
+    dec.decode_device(d, stats=stats); torch.cuda.synchronize()
+    dec.set_timing(True)
+    for _ in range(reps):
+        dec.decode_device(d, stats=stats)
+    torch.cuda.synchronize()
+    ms, n = dec.get_timing()
+    st = stats.cpu().numpy()
+    conv = ((st[..., 0] & 0x100) != 0).mean()
+    print(json.dumps({"config": name, "shots": shots, "windows_per_shot": dec.W, "ms_per_launch": ms / n,
+                      "windows_per_s": shots * dec.W / (ms / n / 1e3), "threads": dec.threads, "lds_bytes": dec.lds_bytes,
+                      "converged_fraction": float(conv), "exit_classes": np.bincount((st[..., 0] & 0xFF).ravel(), minlength=6).tolist()}), flush=True)
+
+
+if "3" in which:
+    run_pipeline("configs[2]: [[144,12,12]] p=0.003 (3,1) bpgdg_decoder(max_iter=8, T=6, R=25, D=3, S=10)", bench.build_problem(), 2048, 3,
+                 decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+                 max_tree_branch_step=10, max_side_branch_step=10)
+if "4" in which:
+    run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 1024, 3,
+                 **dict(bench.DECODER_KW, osd_order=0))
+if "order10" in which:
+    run_pipeline("configs[1] with osd_cs order 10", bench.build_problem(), 4096, 3, **dict(bench.DECODER_KW, osd_order=10))
+if "bp4" in which:
+    code, _, _ = bb_code(144)
+    n = code.hx.shape[1]
+    p = 0.02
+    pr = np.full(n, p / 3)
+    dec = bp4_osd(code.hx, code.hz, channel_probs_x=pr, channel_probs_y=pr, channel_probs_z=pr, max_iter=100,
+                  ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10)
+    rng = np.random.default_rng(5)
+    B = 16384
+    pauli = rng.choice(4, size=(B, n), p=[1 - p, p / 3, p / 3, p / 3])  # 0 I, 1 X, 2 Y, 3 Z
+    ex, ez = ((pauli == 1) | (pauli == 2)).astype(np.uint8), ((pauli == 3) | (pauli == 2)).astype(np.uint8)
+    sx = (ez @ code.hx.T % 2).astype(np.uint8); sz = (ex @ code.hz.T % 2).astype(np.uint8)
+    dec.decode_batch(sx[:256], sz[:256])
+    t0 = time.perf_counter(); out = dec.decode_batch(sx, sz); dt = time.perf_counter() - t0
+    print(json.dumps({"config": "bp4_osd [[144,12,12]] depolarizing p=0.02, max_iter=100, osd_cs 10 (host buffers, PCIe included)",
+                      "decodes": B, "decodes_per_s": B / dt, "converged_fraction": float(((dec.last_status & 0x100) != 0).mean())}), flush=True)

@@ -6,4 +6,11 @@ anywhere; the decoder classes need libswd_hip.so and a gfx950 GPU and raise othe
 from .decoders import (SlidingWindowDecoder, bp4_osd, bp_history_decoder, bpgd_decoder,  # noqa: F401
                        bpgdg_decoder, osd_window)
 
-__all__ = ["osd_window", "bpgdg_decoder", "bpgd_decoder", "bp_history_decoder", "bp4_osd", "SlidingWindowDecoder"]
+# The reference's classes imitate the `ldpc` v1 names (error text of osd_window.pyx:197, BASELINE north star):
+# bp_decoder / bposd_decoder are the same objects under those spellings.  (The third-party ldpc.BpOsdDecoder of
+# the harness's shorten=False branch is a different algorithm with no pinned version: not provided.)
+bp_decoder = bp_history_decoder
+bposd_decoder = osd_window
+
+__all__ = ["osd_window", "bpgdg_decoder", "bpgd_decoder", "bp_history_decoder", "bp4_osd", "SlidingWindowDecoder",
+           "bp_decoder", "bposd_decoder"]
