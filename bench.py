@@ -7,7 +7,7 @@ shortened window matrix (osd_window semantics), batch = 4096 shots per GPU.
 
 One "step" = one pass of the whole hot path over one batch of synthetic shots: a single launch of
 the sliding-window pipeline kernel that decodes shots x 11 windows with commit and residual-syndrome
-update.  Detector data is sampled from the DEM on the host BEFORE the timed region and is resident
+update.  Detector data is sampled from the DEM on the device BEFORE the timed region and is resident
 in HBM when timing starts.  Shots are sharded over ranks (weak scaling, no data-path collective);
 one RCCL all_gather of the per-shot decisions (observable flips + flagged bit) closes the job.
 
@@ -139,19 +139,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from slidingwindowdecoder_amd import SlidingWindowDecoder
-    from slidingwindowdecoder_amd.windows import sample_dem
+    from slidingwindowdecoder_amd import DemSampler, SlidingWindowDecoder
     plan = build_problem()
     W = len(plan.windows)
     kw = dict(DECODER_KW, osd_order=args.osd_order)
     dec = SlidingWindowDecoder(plan, device=local_rank, **kw)
 
     nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    # synthetic shots sampled from the DEM on the device (Philox stream, shot numbers disjoint over ranks)
+    sampler = DemSampler(plan.chk, plan.obs, plan.priors, device=local_rank)
     dets, obs_true = [], []
     for i in range(nb):
-        det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, args.shots, seed=20240318 + 1000 * rank + i)
-        dets.append(torch.from_numpy(np.ascontiguousarray(det)).to(dev))
-        obs_true.append((obs.astype(np.uint32) << np.arange(obs.shape[1], dtype=np.uint32)).sum(axis=1).astype(np.int64))
+        det, flips = sampler.sample_device(args.shots, seed=20240318, first_shot=(rank * nb + i) * args.shots)
+        dets.append(det)
+        obs_true.append(flips.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
     total = torch.empty((args.shots, plan.chk.shape[1]), dtype=torch.uint8, device=dev)
     stats = torch.empty((args.shots, W, 8), dtype=torch.int32, device=dev)
     shot = torch.empty((args.shots, 2), dtype=torch.int32, device=dev)

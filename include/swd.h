@@ -156,6 +156,25 @@ int swd_bp4_decode_batch(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t
 int swd_bp4_decode_batch_dev(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
                              int32_t *stats, double *lpr, uint8_t *osd0, void *stream);
 
+/* ---- DEM sampler -----------------------------------------------------------------------------
+ * Replaces `dem.compile_sampler().sample(shots)` of the reference harness (/root/reference/osd.py:124-125,
+ * guessing.py:129-130; Stim is not available here): per shot, faults e ~ Bernoulli(priors) over the
+ * columns of the detector error model, det = chk e, observable flips = obs e over GF(2).
+ * chk: num_det x num_col CSR with channel_probs = priors; obs: (<= 32) x num_col CSR or NULL.
+ * Stream: Philox4x32-10 keyed by `seed`, counter (shot, column / 4); fault iff x < round(p 2^32); shot b of
+ * a call is shot number first_shot + b, so a result does not depend on batching or on the rank. */
+typedef struct swd_sampler swd_sampler;
+swd_sampler *swd_sampler_create(const swd_graph_desc *chk, const swd_graph_desc *obs, int device);
+void swd_sampler_destroy(swd_sampler *s);
+int swd_sampler_info(const swd_sampler *s, int32_t *num_det, int32_t *num_col, int32_t *num_obs);
+/* det [B*num_det] u8; obs_flips [B] bit masks, nullable; faults [B*num_col] u8, nullable.  Host pointers. */
+int swd_sampler_sample(swd_sampler *s, int32_t B, uint64_t seed, uint64_t first_shot, uint8_t *det,
+                       uint32_t *obs_flips, uint8_t *faults);
+/* device pointers (strides in bytes per shot, 0 = dense), asynchronous on `stream` */
+int swd_sampler_sample_dev(swd_sampler *s, int32_t B, uint64_t seed, uint64_t first_shot, uint8_t *det,
+                           int64_t det_stride, uint32_t *obs_flips, uint8_t *faults, int64_t faults_stride,
+                           void *stream);
+
 /* ---- sliding-window pipeline ---------------------------------------------------------------
  * Replaces the window loop of the reference harness (/root/reference/osd.py:130-179, identical in
  * guessing.py:135-214 and the notebooks): for every shot, decode window t on the residual

@@ -76,6 +76,11 @@ SYMBOLS = [
     ("swd_pipeline_get_profile", C.c_int, [_vp, _i32, _vp]),
     ("swd_pipeline_set_timing", C.c_int, [_vp, _i32]),
     ("swd_pipeline_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
+    ("swd_sampler_create", _vp, [C.POINTER(GraphDesc), C.POINTER(GraphDesc), C.c_int]),
+    ("swd_sampler_destroy", None, [_vp]),
+    ("swd_sampler_info", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    ("swd_sampler_sample", C.c_int, [_vp, _i32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    ("swd_sampler_sample_dev", C.c_int, [_vp, _i32, C.c_uint64, C.c_uint64, _vp, _i64, _vp, _vp, _i64, _vp]),
 ]
 
 STAT_WORDS = 8

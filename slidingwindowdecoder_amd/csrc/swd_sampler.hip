@@ -1,0 +1,160 @@
+// On-device DEM sampler: for every shot, faults e ~ Bernoulli(priors) over the columns of the detector
+// error model, det = chk e, obs = obs e over GF(2) -- what `dem.compile_sampler().sample(shots)` hands
+// to the reference's harness (/root/reference/osd.py:124-125, guessing.py:129-130).  Stim's generator
+// cannot be reproduced, so the stream is the build's own: Philox4x32-10 keyed by the seed, counter =
+// (shot, column / 4): the four outputs decide columns 4c..4c+3, fault iff x < round(p * 2^32).  The
+// result is a pure function of (seed, shot index, column), independent of batch size and of the GPU a
+// shot lands on; tests/philox_ref.py restates it in numpy.
+#include <string.h>
+
+#include "swd_host.h"
+
+using namespace swd;
+
+namespace {
+
+struct Sampler {
+    int device = 0, num_det = 0, num_col = 0, num_obs = 0;
+    DevBuf buf;                       // thr[num_col] u32 | colptr[num_col+1] u32 | rows[E] u16 | obs_mask[num_col] u32
+    const uint32_t *d_thr = nullptr, *d_colptr = nullptr, *d_obs = nullptr;
+    const uint16_t *d_rows = nullptr;
+    DevBuf det, obs, faults;          // staging for the host-pointer entry point
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one workgroup per shot; detector parities accumulate as bits in LDS
+__global__ void __launch_bounds__(256) sample_kernel(int num_det, int num_col, const uint32_t *thr, const uint32_t *colptr,
+                                                     const uint16_t *rows, const uint32_t *obs_mask, uint64_t seed,
+                                                     uint64_t first_shot, uint8_t *det, int64_t det_stride, uint32_t *obs_out,
+                                                     uint8_t *faults, int64_t faults_stride) {
+    extern __shared__ uint32_t bits[]; // [ceil(num_det / 32)] + 1 word of observable flips
+    const int tid = threadIdx.x, nw = (num_det + 31) / 32;
+    const uint64_t shot = first_shot + blockIdx.x;
+    for (int i = tid; i <= nw; i += 256) bits[i] = 0;
+    __syncthreads();
+    const int ngroups = (num_col + 3) / 4;
+    for (int gidx = tid; gidx < ngroups; gidx += 256) {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)shot, (uint32_t)(shot >> 32), (uint32_t)gidx, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = 4 * gidx + u;
+            if (c >= num_col) break;
+            const bool f = x[u] < thr[c];
+            if (faults) faults[(int64_t)blockIdx.x * faults_stride + c] = f ? 1 : 0;
+            if (f) {
+                for (uint32_t e = colptr[c]; e < colptr[c + 1]; ++e) atomicXor(&bits[rows[e] >> 5], 1u << (rows[e] & 31));
+                if (obs_mask && obs_mask[c]) atomicXor(&bits[nw], obs_mask[c]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < num_det; r += 256) det[(int64_t)blockIdx.x * det_stride + r] = (uint8_t)((bits[r >> 5] >> (r & 31)) & 1u);
+    if (tid == 0 && obs_out) obs_out[blockIdx.x] = bits[nw];
+}
+
+} // namespace
+
+extern "C" swd_sampler *swd_sampler_create(const swd_graph_desc *chk, const swd_graph_desc *obs, int device) {
+    if (!chk || !chk->row_ptr || !chk->col_idx || !chk->channel_probs) { set_error("null argument"); return nullptr; }
+    if (chk->m <= 0 || chk->n <= 0 || chk->m > 65535) { set_error("detector matrix %d x %d out of range", chk->m, chk->n); return nullptr; }
+    if (obs && (obs->m > 32 || obs->n != chk->n)) { set_error("observable matrix must be (<= 32) x %d", chk->n); return nullptr; }
+    Sampler *s = new Sampler();
+    s->device = device; s->num_det = chk->m; s->num_col = chk->n; s->num_obs = obs ? obs->m : 0;
+    const int n = chk->n, E = chk->row_ptr[chk->m];
+    std::vector<uint32_t> thr(n), colptr(n + 1, 0), omask(n, 0);
+    std::vector<uint16_t> rows(std::max(E, 1));
+    for (int c = 0; c < n; ++c) {
+        const double p = chk->channel_probs[c];
+        if (!(p >= 0.0 && p <= 1.0)) { set_error("prior %d = %g is not a probability", c, p); delete s; return nullptr; }
+        const double t = p * 4294967296.0 + 0.5;
+        thr[c] = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    }
+    for (int e = 0; e < E; ++e) {
+        if (chk->col_idx[e] < 0 || chk->col_idx[e] >= n) { set_error("detector matrix: column out of range"); delete s; return nullptr; }
+        colptr[chk->col_idx[e] + 1]++;
+    }
+    for (int c = 0; c < n; ++c) colptr[c + 1] += colptr[c];
+    {
+        std::vector<uint32_t> fill(colptr.begin(), colptr.end() - 1);
+        for (int r = 0; r < chk->m; ++r)
+            for (int e = chk->row_ptr[r]; e < chk->row_ptr[r + 1]; ++e) rows[fill[chk->col_idx[e]]++] = (uint16_t)r;
+    }
+    if (obs)
+        for (int k = 0; k < obs->m; ++k)
+            for (int e = obs->row_ptr[k]; e < obs->row_ptr[k + 1]; ++e) {
+                if (obs->col_idx[e] < 0 || obs->col_idx[e] >= n) { set_error("observable matrix: column out of range"); delete s; return nullptr; }
+                omask[obs->col_idx[e]] ^= 1u << k;
+            }
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_thr = 0, o_cp = al(o_thr + n * 4), o_rows = al(o_cp + (n + 1) * 4), o_obs = al(o_rows + rows.size() * 2),
+                 total = al(o_obs + n * 4);
+    std::vector<char> h(total, 0);
+    memcpy(&h[o_thr], thr.data(), n * 4); memcpy(&h[o_cp], colptr.data(), (n + 1) * 4);
+    memcpy(&h[o_rows], rows.data(), rows.size() * 2); memcpy(&h[o_obs], omask.data(), n * 4);
+    if (hipSetDevice(device) != hipSuccess || s->buf.reserve(total) ||
+        hipMemcpy(s->buf.p, h.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("sampler: device allocation failed on device %d", device);
+        delete s;
+        return nullptr;
+    }
+    char *b = (char *)s->buf.p;
+    s->d_thr = (const uint32_t *)(b + o_thr); s->d_colptr = (const uint32_t *)(b + o_cp);
+    s->d_rows = (const uint16_t *)(b + o_rows); s->d_obs = obs ? (const uint32_t *)(b + o_obs) : nullptr;
+    return (swd_sampler *)s;
+}
+
+extern "C" void swd_sampler_destroy(swd_sampler *h) { delete (Sampler *)h; }
+
+extern "C" int swd_sampler_sample_dev(swd_sampler *h, int32_t B, uint64_t seed, uint64_t first_shot, uint8_t *det,
+                                      int64_t det_stride, uint32_t *obs_flips, uint8_t *faults, int64_t faults_stride,
+                                      void *stream) {
+    Sampler *s = (Sampler *)h;
+    if (!s || !det) { set_error("null argument"); return -1; }
+    if (B <= 0) return 0;
+    SWD_HIP(hipSetDevice(s->device));
+    const size_t lds = ((size_t)(s->num_det + 31) / 32 + 1) * 4;
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, s->num_det, s->num_col, s->d_thr, s->d_colptr,
+                       s->d_rows, s->d_obs, seed, first_shot, det, det_stride ? det_stride : s->num_det, obs_flips, faults,
+                       faults_stride ? faults_stride : s->num_col);
+    SWD_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int swd_sampler_sample(swd_sampler *h, int32_t B, uint64_t seed, uint64_t first_shot, uint8_t *det,
+                                  uint32_t *obs_flips, uint8_t *faults) {
+    Sampler *s = (Sampler *)h;
+    if (!s || !det) { set_error("null argument"); return -1; }
+    if (B <= 0) return 0;
+    SWD_HIP(hipSetDevice(s->device));
+    if (s->det.reserve((size_t)B * s->num_det) || s->obs.reserve((size_t)B * 4)) return -1;
+    if (faults && s->faults.reserve((size_t)B * s->num_col)) return -1;
+    if (swd_sampler_sample_dev(h, B, seed, first_shot, s->det.as<uint8_t>(), 0, s->obs.as<uint32_t>(),
+                               faults ? s->faults.as<uint8_t>() : nullptr, 0, nullptr)) return -1;
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(det, s->det.p, (size_t)B * s->num_det, hipMemcpyDeviceToHost));
+    if (obs_flips) SWD_HIP(hipMemcpy(obs_flips, s->obs.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (faults) SWD_HIP(hipMemcpy(faults, s->faults.p, (size_t)B * s->num_col, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int swd_sampler_info(const swd_sampler *h, int32_t *num_det, int32_t *num_col, int32_t *num_obs) {
+    const Sampler *s = (const Sampler *)h;
+    if (!s) { set_error("null sampler"); return -1; }
+    if (num_det) *num_det = s->num_det;
+    if (num_col) *num_col = s->num_col;
+    if (num_obs) *num_obs = s->num_obs;
+    return 0;
+}

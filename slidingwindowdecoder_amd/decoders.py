@@ -510,3 +510,59 @@ class SlidingWindowDecoder:
         ms, k = C.c_double(), C.c_int64()
         _lib.lib().swd_pipeline_get_timing(self._h, C.byref(ms), C.byref(k))
         return ms.value, k.value
+
+
+class DemSampler:
+    """Samples shots of a detector error model on the device: ``det, obs = sampler.sample(shots)`` is what
+    ``dem.compile_sampler().sample(shots)`` gives the reference harness (/root/reference/osd.py:124-125).
+    Faults are Bernoulli(priors) per column from a Philox4x32-10 stream that is a pure function of
+    (seed, shot number, column): batches and ranks can be cut anywhere (``first_shot``)."""
+
+    def __init__(self, chk, obs, priors, device=0):
+        L = _lib.lib()
+        self._chk = _Csr(chk, priors)
+        self.num_det, self.num_col = self._chk.m, self._chk.n
+        self.num_obs = 0
+        od = None
+        if obs is not None:
+            a = sp.csr_matrix(obs)
+            a.sort_indices()
+            self._orp, self._oci = np.ascontiguousarray(a.indptr, np.int32), np.ascontiguousarray(a.indices, np.int32)
+            if a.shape[1] != self.num_col:
+                raise ValueError(f"obs has {a.shape[1]} columns, chk has {self.num_col}")
+            if a.shape[0] > 32:
+                raise ValueError("at most 32 observables")
+            self.num_obs = int(a.shape[0])
+            od = _lib.GraphDesc(a.shape[0], a.shape[1], int(self._orp[-1]), self._orp.ctypes.data, self._oci.ctypes.data, None)
+        self.device = int(device)
+        self._h = L.swd_sampler_create(C.byref(self._chk.desc), C.byref(od) if od is not None else None, self.device)
+        if not self._h:
+            raise RuntimeError(f"swd_sampler_create failed: {_lib.last_error()}")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().swd_sampler_destroy(self._h)
+            self._h = None
+
+    def sample(self, shots, seed=20240318, first_shot=0, return_faults=False):
+        """-> det uint8 [shots, num_det], obs uint8 [shots, num_obs] (, faults uint8 [shots, num_col])."""
+        det = np.zeros((shots, self.num_det), np.uint8)
+        flips = np.zeros(shots, np.uint32)
+        faults = np.zeros((shots, self.num_col), np.uint8) if return_faults else None
+        if _lib.lib().swd_sampler_sample(self._h, shots, int(seed), int(first_shot), det.ctypes.data, flips.ctypes.data,
+                                         faults.ctypes.data if return_faults else None):
+            raise RuntimeError(f"swd_sampler_sample failed: {_lib.last_error()}")
+        obs = ((flips[:, None] >> np.arange(self.num_obs, dtype=np.uint32)) & 1).astype(np.uint8)
+        return (det, obs, faults) if return_faults else (det, obs)
+
+    def sample_device(self, shots, seed=20240318, first_shot=0):
+        """-> torch tensors on the device: det uint8 [shots, num_det], observable-flip bit masks int32 [shots]."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        det = torch.empty((shots, self.num_det), dtype=torch.uint8, device=dev)
+        flips = torch.empty((shots,), dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if _lib.lib().swd_sampler_sample_dev(self._h, shots, int(seed), int(first_shot), det.data_ptr(), 0, flips.data_ptr(),
+                                             None, 0, st):
+            raise RuntimeError(f"swd_sampler_sample_dev failed: {_lib.last_error()}")
+        return det, flips
