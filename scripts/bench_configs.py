@@ -3,6 +3,7 @@
 
   config 3  [[144,12,12]] circuit-level p=0.003, (W,F)=(3,1), bpgdg_decoder windows (guessing.py:160-173)
   config 4  [[288,12,18]] circuit-level p=0.003, (W,F)=(4,1), osd_window windows
+  config 5  SHYPS r=3 circuit-level p=0.001, 12 rounds, (3,1), osd_window windows (stim-free DEM, shyps.py)
   bp4       [[144,12,12]] depolarizing code-capacity noise, bp4_osd (Misc.ipynb cell 2 setting)
   order10   configs[1] with the notebooks' default OSD-CS order 10
 
@@ -15,7 +16,7 @@ from slidingwindowdecoder_amd import SlidingWindowDecoder, bp4_osd
 from slidingwindowdecoder_amd.windows import sample_dem
 from slidingwindowdecoder_amd.codes import bb_code
 
-which = sys.argv[1:] or ["3", "4", "bp4", "order10"]
+which = sys.argv[1:] or ["3", "4", "5", "bp4", "order10"]
 
 
 def run_pipeline(name, plan, shots, reps, **kw):
@@ -43,6 +44,13 @@ if "3" in which:
 if "4" in which:
     run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 1024, 3,
                  **dict(bench.DECODER_KW, osd_order=0))
+if "5" in which:
+    from slidingwindowdecoder_amd import shyps
+    from slidingwindowdecoder_amd.windows import plan_windows
+    dem = shyps.shyps_dem(3, 0.001, 12)
+    run_pipeline("configs[4] circuit: SHYPS r=3 p=0.001, 12 rounds, (3,1) windows 63x476, osd_window(pre=8, post=200, osd_cs 0) "
+                 "(binary BP+OSD like SHYPS.ipynb; BP4 has no circuit-level reference)",
+                 plan_windows(dem.chk, dem.obs, dem.priors, 21, 3, 1, method=1), 8192, 3, **dict(bench.DECODER_KW, osd_order=0))
 if "order10" in which:
     run_pipeline("configs[1] with osd_cs order 10", bench.build_problem(), 4096, 3, **dict(bench.DECODER_KW, osd_order=10))
 if "bp4" in which:

@@ -32,7 +32,7 @@ import numpy as np
 import scipy.sparse as sp
 
 # op codes
-R, RX, H, CX, M, MR, MRX, XERR, DEP1, DEP2, DETECTOR, OBSERVABLE = range(12)
+R, RX, H, CX, M, MR, MRX, XERR, DEP1, DEP2, DETECTOR, OBSERVABLE, MX = range(13)
 
 
 def bb_memory_ops(code, A_list, B_list, p: float, num_repeat: int):
@@ -188,6 +188,7 @@ def dem_from_ops(ops) -> DEM:
             sens[o[1]] ^= meas_mask.get(o[2], 0)
         elif kind in (R, RX, MRX, H):
             sens[o[1]] = 0
+        # MX: an X flip commutes with the X-basis measurement -- neither its outcome nor the state after it changes
     # forward-circuit order of first appearance
     order.reverse()
 

@@ -235,6 +235,7 @@ static const Variant kVariants[] = {
     {64, 4, 8, 16, launch_nt<64, 4, 8, 16, 0>, launch_nt<64, 4, 8, 16, 1>},
     {256, 2, 8, 16, launch_nt<256, 2, 8, 16, 0>, launch_nt<256, 2, 8, 16, 1>},
     {256, 4, 8, 16, launch_nt<256, 4, 8, 16, 0>, launch_nt<256, 4, 8, 16, 1>},
+    {256, 2, 10, 12, launch_nt<256, 2, 10, 12, 0>, launch_nt<256, 2, 10, 12, 1>},  // SHYPS r=3 circuit-level windows (63 x 476, column weight <= 9)
 #endif
     {256, 7, 6, 9, launch_nt<256, 7, 6, 9, 0>, launch_nt<256, 7, 6, 9, 1>},      // [[144,12,12]] circuit-level windows
 #ifndef SWD_HEADLINE_ONLY

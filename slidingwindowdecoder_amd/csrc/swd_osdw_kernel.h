@@ -13,7 +13,7 @@
 #include "swd.h"
 #include "swd_graph.h"
 
-#define SWD_DMAX 8 // largest column degree any kernel variant of this build supports
+#define SWD_DMAX 10 // largest column degree any kernel variant of this build supports
 
 struct SwdLdsLayout {
     int32_t off_livemask, off_par, off_lv, off_jptr, off_lslot, off_cnval, off_cndeg, off_cndeg0, off_vnval, off_hard,

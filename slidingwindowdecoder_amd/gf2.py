@@ -93,3 +93,23 @@ def nullspace(mat: np.ndarray) -> np.ndarray:
         if v == 0:
             kernel.append(c)
     return ints_to_rows(kernel, n)
+
+
+def left_inverse(mat: np.ndarray) -> np.ndarray:
+    """P with P @ mat = I over GF(2) for a full-column-rank n x k matrix (any such P; the reference's
+    utils.inverse serves the same purpose, /root/reference/src/utils.py:476-514)."""
+    a = (np.asarray(mat) % 2).astype(np.uint8)
+    n, k = a.shape
+    aug = np.concatenate([a, np.identity(n, dtype=np.uint8)], axis=1)
+    row = 0
+    for col in range(k):
+        piv = next((i for i in range(row, n) if aug[i, col]), None)
+        if piv is None:
+            raise ValueError("matrix does not have full column rank")
+        if piv != row:
+            aug[[row, piv]] = aug[[piv, row]]
+        for i in range(n):
+            if i != row and aug[i, col]:
+                aug[i] ^= aug[row]
+        row += 1
+    return aug[:k, k:].astype(np.int64)
