@@ -32,3 +32,21 @@ pre = st[..., 2]; post = st[..., 3]
 print("pre iters/window mean %.2f ; post iters mean %.2f ; us per pre-iter %.2f ; us per post-iter %.2f" % (
     pre.mean(), post.mean(), prof[..., 1].sum() / max(pre.sum(), 1), prof[..., 4].sum() / max(post.sum(), 1)))
 print("classes", np.bincount(cls.ravel(), minlength=6).tolist())
+# per-shot latency distribution and what a greedy dispatch of the shots onto the 512 workgroup slots gives
+tot_shot = prof.sum(axis=(1, 2))
+print("per-shot device time (us): mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
+    tot_shot.mean(), *np.percentile(tot_shot, [50, 90, 99]), tot_shot.max()))
+import heapq
+slots = [0.0] * 512
+heapq.heapify(slots)
+for t in tot_shot:
+    heapq.heappush(slots, heapq.heappop(slots) + t)
+print("greedy makespan over 512 slots: %.2f ms (sum/512 = %.2f ms)" % (max(slots) / 1e3, tot_shot.sum() / 512 / 1e3))
+wt = det.sum(axis=1)
+print("correlation(detector weight, shot time) = %.3f" % np.corrcoef(wt, tot_shot)[0, 1])
+for name, order_ in (("heaviest syndrome first", np.argsort(-wt, kind="stable")), ("oracle: longest first", np.argsort(-tot_shot))):
+    slots = [0.0] * 512
+    heapq.heapify(slots)
+    for t in tot_shot[order_]:
+        heapq.heappush(slots, heapq.heappop(slots) + t)
+    print("greedy makespan, %s: %.2f ms" % (name, max(slots) / 1e3))

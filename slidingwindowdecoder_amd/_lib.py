@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswd_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("SWD_LIB", "libswd_hip.so"))  # SWD_LIB: a development build next to it
 _lib = None
 
 

@@ -103,7 +103,7 @@ struct Plan {
     const uint16_t *d_rows = nullptr;
     // host-pointer staging
     DevBuf synd, out, stats, pm, hist, osd0, total;
-    DevBuf prof;
+    DevBuf prof, sched, state;
     bool profiling = false;
     bool timing = false;
     double t_total_ms = 0;
@@ -218,13 +218,34 @@ struct Plan {
 
 
 template <int NT, int VF, int DM, int KG, int KIND>
-static int launch_nt(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
+static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
+    SwdPipeArgs a = a0;
     static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
     if (d->lds_total > lds_limit[d->device & 63]) {
         SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
     }
-    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND>), dim3(a.B), dim3(NT), d->lds_total, st, a);
+    // persistent grid: as many workgroups as fit the device at once (they draw work units until none is left)
+    static int slots[64] = {0};
+    static int slots_lds[64] = {0};
+    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->lds_total) {
+        int per_cu = 0, cus = 0;
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND>, NT, (size_t)d->lds_total));
+        SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
+        slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
+        slots_lds[d->device & 63] = d->lds_total;
+    }
+    const long long units = (long long)a.B * a.W;
+    const unsigned grid = (unsigned)std::min<long long>(units, slots[d->device & 63]);
+    if (a.slot_scratch) { // per-workgroup scratch (sliding-window plans): history ring and, for the guessing decoders, snapshots
+        if (d->hist.reserve((size_t)grid * a.hist_stride * sizeof(double))) return -1;
+        a.hist = d->hist.as<double>();
+        if (d->kind != 0) {
+            if (d->snap.reserve((size_t)grid * d->snap_stride + 8)) return -1;
+            a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
+        }
+    }
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND>), dim3(grid), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
@@ -251,7 +272,13 @@ static const Variant *select_variant(int mmax, int nmax, int dm, int kmax, int k
     return nullptr;
 }
 
-static int launch(Plan *d, const SwdPipeArgs &a, hipStream_t st) {
+static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
+    // work-unit scheduling state: ticket counter + per-shot progress (zeroed per launch), hand-over buffer
+    SwdPipeArgs a = a0;
+    a.state_stride = 16 + align_up(d->num_det, 16);
+    if (d->sched.reserve((size_t)(a.B + 2) * 4) || d->state.reserve((size_t)a.B * a.state_stride)) return -1; // + ticket, + error flag
+    a.sched = d->sched.as<uint32_t>(); a.state = d->state.as<uint8_t>();
+    SWD_HIP(hipMemsetAsync(a.sched, 0, (size_t)(a.B + 2) * 4, st));
     if (d->timing) {
         if (!d->ev0) { SWD_HIP(hipEventCreate(&d->ev0)); SWD_HIP(hipEventCreate(&d->ev1)); }
         SWD_HIP(hipEventRecord(d->ev0, st));
@@ -478,9 +505,10 @@ extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t
     if (B <= 0) return 0;
     if (!det || !total) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
-    if (d->hist.reserve((size_t)B * 4 * d->nmax * sizeof(double))) return -1;
     SwdPipeArgs a{};
     a.wins = d->d_wins.as<SwdWindowDev>(); a.W = (int)d->wins.size(); a.B = B;
+    a.slot_scratch = a.W > 1 ? 1 : 0;
+    if (!a.slot_scratch && d->hist.reserve((size_t)B * 4 * d->nmax * sizeof(double))) return -1;
     fill_params(d, a.P, false, false);
     a.det = det; a.det_stride = det_stride ? det_stride : d->num_det; a.num_det = d->num_det; a.off_det = d->off_det;
     a.total = total; a.total_stride = total_stride ? total_stride : d->num_col;
@@ -489,7 +517,7 @@ extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t
     a.hist = d->hist.as<double>(); a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
     a.obs_mask = d->d_obs.p ? d->d_obs.as<uint32_t>() : nullptr;
     a.shot_result = shot_result;
-    if (d->kind != 0) {
+    if (d->kind != 0 && !a.slot_scratch) {
         if (d->snap.reserve((size_t)B * d->snap_stride + 8)) return -1;
         a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
     }
@@ -516,6 +544,11 @@ extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *de
                                      d->pm.as<double>(), d->shot.as<int32_t>(), nullptr);
     if (rc) return rc;
     SWD_HIP(hipDeviceSynchronize());
+    {
+        uint32_t err = 0;
+        SWD_HIP(hipMemcpy(&err, d->sched.as<uint32_t>() + 1 + B, 4, hipMemcpyDeviceToHost));
+        if (err) { set_error("internal: a window waited more than 10 s for its predecessor (scheduling bug)"); return -1; }
+    }
     SWD_HIP(hipMemcpy(total, d->total.p, (size_t)B * d->num_col, hipMemcpyDeviceToHost));
     if (shot_result) SWD_HIP(hipMemcpy(shot_result, d->shot.p, (size_t)B * 8, hipMemcpyDeviceToHost));
     if (stats) SWD_HIP(hipMemcpy(stats, d->stats.p, B * W * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));

@@ -80,6 +80,11 @@ struct SwdPipeArgs {
     const uint32_t *obs_mask; // nullable [num_col]: bit k set if fault flips observable k (obs matrix)
     int32_t *shot_result;     // nullable [B][2]: predicted observable flips, residual syndrome != 0
     int64_t *prof;            // nullable [B][W][8]: 100 MHz ticks per phase (diagnostics only)
+    // work-unit scheduling (one workgroup = one window of one shot, see pipeline_kernel)
+    uint32_t *sched;          // [1 + B]: ticket counter, then per shot the number of windows finished
+    uint8_t *state;           // [B][state_stride]: residual syndrome + accumulators handed to the next window
+    int64_t state_stride;
+    int32_t slot_scratch;     // hist / snap are private to the workgroup (indexed by blockIdx.x), not to the shot
 };
 
 namespace swd {
@@ -1584,18 +1589,64 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 template <int NT, int VF, int DM, int KG, int KIND>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    uint8_t *sdet = (uint8_t *)(smem + a.off_det);
-    const uint8_t *det_b = a.det + (int64_t)b * a.det_stride;
-    for (int r = tid; r < a.num_det; r += NT) sdet[r] = det_b[r] ? 1 : 0;
-    double *hist_b = a.hist + (int64_t)b * a.hist_stride;
-    Lds s;
-    s.fpar = 0;
+    const int tid = threadIdx.x;
+    // One workgroup decodes ONE window of one shot.  Units are handed out by an atomic ticket in
+    // window-major order (all shots' window 0, then window 1, ...): a shot's windows are sequential
+    // (commit -> residual syndrome), and shot times are heavy-tailed (a shot with several OSD windows
+    // takes 5x the mean), so whole shots per workgroup left a quarter of the launch to stragglers;
+    // level by level every shot advances together and the tail is one window long.  Unit t depends on
+    // unit t - B, whose ticket was drawn earlier by a workgroup that is already running, so the wait
+    // below cannot deadlock whatever order the hardware dispatches workgroups in.
     uint32_t *acc = (uint32_t *)(smem + a.off_det) - 4; // 16 bytes below sdet are reserved by the host
-    if (tid == 0) { acc[0] = 0; acc[1] = 0; }
+    // The grid is only as large as the device can hold at once; every workgroup keeps drawing tickets
+    // (starting a fresh workgroup per unit left a fifth of the slots empty at any time).
+    const uint32_t nunits = (uint32_t)a.B * (uint32_t)a.W;
+    Lds s;
     swd_wave_roles<NT>(s, acc + 2);
+    for (;;) {
+    const long long t_unit0 = wall_clock64();
     __syncthreads();
-    for (int wi = 0; wi < a.W; ++wi) {
+    if (tid == 0) acc[2] = atomicAdd(a.sched, 1u);
+    __syncthreads();
+    const uint32_t ticket = acc[2];
+    if (ticket >= nunits) break;
+    const int wi = (int)(ticket / (uint32_t)a.B), b = (int)(ticket % (uint32_t)a.B);
+    __syncthreads();
+    uint8_t *sdet = (uint8_t *)(smem + a.off_det);
+    uint8_t *state_b = a.state + (int64_t)b * a.state_stride;
+    if (wi == 0) {
+        const uint8_t *det_b = a.det + (int64_t)b * a.det_stride;
+        for (int r = tid; r < a.num_det; r += NT) sdet[r] = det_b[r] ? 1 : 0;
+        if (tid == 0) { acc[0] = 0; acc[1] = 0; }
+    } else {
+        // Hand-over without cache maintenance: the state words and the progress counter are written and read
+        // with agent-scope atomic accesses (coherent per access across the XCDs' L2s); a release / acquire
+        // FENCE at agent scope would write back / invalidate a whole L2 per window and costs more than the
+        // window's own tail.  Order: data stores complete (workgroup fence = wait for their acknowledgement),
+        // then the counter; the reader sees the counter, then loads the data the same way.
+        if (tid == 0) {
+            const long long t_wait0 = wall_clock64();
+            while (__hip_atomic_load(&a.sched[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)wi) {
+                __builtin_amdgcn_s_sleep(8);
+                // cannot happen by construction (the awaited ticket is older and running); a bound keeps a bug
+                // from hanging the device: flag the launch and go on (wall_clock64 ticks at 100 MHz -> 10 s)
+                if (wall_clock64() - t_wait0 > 1000000000ll) { atomicOr(&a.sched[1 + a.B], 1u); break; }
+            }
+        }
+        __syncthreads();
+        const uint32_t *st32 = (const uint32_t *)state_b;
+        uint32_t *sdet32 = (uint32_t *)sdet;
+        for (int r = tid; r < (a.num_det + 3) / 4; r += NT)
+            sdet32[r] = __hip_atomic_load(&st32[4 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) { acc[0] = __hip_atomic_load(&st32[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[1] = 0; }
+    }
+    // Scratch that one window writes and reads back lives with the workgroup, not with the shot: consecutive
+    // windows of a shot run on different XCDs, whose L2s do not see each other's ordinary stores.
+    const int sidx = a.slot_scratch ? (int)blockIdx.x : b;
+    double *hist_b = a.hist + (int64_t)sidx * a.hist_stride;
+    s.fpar = 0;
+    __syncthreads();
+    {
         const SwdWindowDev &w = a.wins[wi];
         const SwdGraphDev &g = w.g;
         const SwdLdsLayout &L = w.L;
@@ -1607,7 +1658,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
         if constexpr (KIND == 0)
             decode_window<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
         else
-            decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.snap + (int64_t)b * a.snap_stride, R);
+            decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.snap + (int64_t)sidx * a.snap_stride, R);
         __syncthreads();
         if (a.total) {
             uint8_t *tot_b = a.total + (int64_t)b * a.total_stride + w.col0;
@@ -1651,6 +1702,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                     prev = cur;
                 }
                 pr[7] = tend - prev;
+                pr[0] += R.t[0] - t_unit0; // ticket, wait for the previous window, state load
+#ifdef SWD_TSPROF
+                pr[5] = t_unit0; pr[6] = tend; // absolute ticks of the unit (diagnostic build)
+#endif
 #ifdef SWD_BPPROF
                 pr[0] = s.scal[24]; pr[5] = s.scal[25]; pr[6] = s.scal[26]; pr[7] = s.scal[27];
                 pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
@@ -1662,8 +1717,20 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
             }
         }
         __syncthreads();
+        if (wi + 1 < a.W) {
+            // hand the shot to its next window: state, then an agent-scope release of the window count
+            uint32_t *st32 = (uint32_t *)state_b;
+            const uint32_t *sdet32 = (const uint32_t *)sdet;
+            for (int r = tid; r < (a.num_det + 3) / 4; r += NT)
+                __hip_atomic_store(&st32[4 + r], sdet32[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(&st32[0], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state stores are acknowledged ...
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();                                  // ... by every wave, before the counter moves
+            if (tid == 0) __hip_atomic_store(&a.sched[1 + b], (uint32_t)(wi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (a.shot_result) {
+    if (a.shot_result && wi == a.W - 1) {
         // osd.py:184-187: flagged = residual syndrome of the whole run non-zero; observable flips
         // predicted by the committed faults (compared with the sampled ones by the caller)
         bool nz = false;
@@ -1671,6 +1738,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
         const bool any = block_any<NT>(nz, s);
         if (tid == 0) { a.shot_result[2 * b] = (int32_t)acc[0]; a.shot_result[2 * b + 1] = any ? 1 : 0; }
     }
+    } // next unit
 }
 
 } // namespace swd

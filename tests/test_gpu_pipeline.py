@@ -86,6 +86,8 @@ def test_bb288_pipeline_vs_oracle_host_loop():
     plan = load_plan(f, 4)
     kw = dict(fx.params(f, "osd10_params"), osd_order=0)
     det = fx.unpack(f["det"], plan.chk.shape[0])
-    total = SlidingWindowDecoder(plan, **kw).decode(det)
+    dec = SlidingWindowDecoder(plan, **kw)
+    total = dec.decode(det)
     want, _ = sliding_window_decode_host(plan, det, lambda w: O.osd_window(w.mat, channel_probs=w.prior, **kw))
-    assert np.array_equal(total, want)
+    bad = np.flatnonzero((total != want).any(axis=1))
+    assert bad.size == 0, f"shots {bad.tolist()} differ; exit classes {(dec.last_stats[bad, :, 0] & 0xFF).tolist()}, iterations {dec.last_stats[bad, :, 1].tolist()}"
