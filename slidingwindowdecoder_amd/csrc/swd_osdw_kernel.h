@@ -1217,11 +1217,11 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
 template <int NT, int DM>
 __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                           const uint8_t *synd, uint8_t *osd0_b, int &rowadds, long long &t_sorted,
-                                          long long &t_elim) {
+                                          long long &t_elim, bool presorted = false) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     uint64_t *key = (uint64_t *)s.scratch;
     uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
-    sort_pairs<NT>(key, idx, L.npad);
+    if (!presorted) sort_pairs<NT>(key, idx, L.npad);
     t_sorted = wall_clock64();
     uint64_t *Tc = (uint64_t *)(s.scratch + L.off_aux);
     uint64_t *Sbuf = Tc + m * g.wm;
@@ -1560,21 +1560,69 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         return;
     }
     if (P.osd_order < 0) { R.exit_class = SWD_EXIT_NO_OSD; return; }
-    // ---- OSD (osd_window.pyx:201-284): keys -1000 / +1000 / history sum
+    // ---- OSD (osd_window.pyx:201-284): keys -1000 / +1000 / history sum, stable ascending order.
+    // The decided-0 columns (most of the window after shortening) all carry +1000 and therefore form one
+    // block in index order; only the rest (decided-1 and live columns, <= new_n) needs sorting:
+    //   order = [rest with key < 1000, sorted] ++ [decided-0 by index] ++ [rest with key > 1000, sorted].
+    // A live column whose sum is exactly 1000.0 would interleave with the block by index: then the full sort runs.
     __syncthreads();
-    for (int v = tid; v < L.npad; v += NT) {
-        if (v < n) {
-            double sum;
+    bool presorted = false;
+    {
+        const uint64_t k1000 = f2key(1000.0);
+        uint16_t *zlist = (uint16_t *)(s.scratch + L.off_aux); // [n], free until the transform matrix is set up
+        const int ch = (n + NT - 1) / NT;
+        const int v0 = tid * ch, v1 = min(n, v0 + ch);
+        int cnt = 0; // rest count | zero count << 16
+        for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] == 0) ? 0x10000 : 1;
+        int tot;
+        const int pos = block_exscan<NT>(cnt, s, tot);
+        int ps = pos & 0xFFFF, pz = pos >> 16, nlt = 0;
+        bool eq = false;
+        for (int v = v0; v < v1; ++v) {
             const int vv = s.vn_val[v];
-            if (vv == 1) sum = -1000.0;
-            else if (vv == 0) sum = 1000.0;
-            else sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
-            key[v] = f2key(sum);
-            idx[v] = (uint16_t)v;
-        } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+            if (vv == 0) { zlist[pz++] = (uint16_t)v; continue; }
+            const uint64_t k = f2key(vv == 1 ? -1000.0 : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v]);
+            key[ps] = k; idx[ps] = (uint16_t)v; ++ps;
+            nlt += (k < k1000) ? 1 : 0;
+            eq |= (k == k1000);
+        }
+        const int totS = tot & 0xFFFF, totZ = tot >> 16;
+        int npadS = 2;
+        while (npadS < totS) npadS <<= 1;
+        for (int i = totS + tid; i < npadS; i += NT) { key[i] = ~0ull; idx[i] = 0xFFFF; }
+        if (tid == 0) s.iaux[3] = 0;
+        const bool any_eq = block_any<NT>(eq, s);
+        if (!any_eq) {
+            if (nlt) atomicAdd(&s.iaux[3], nlt);
+            sort_pairs<NT>(key, idx, npadS);
+            const int c_lt = s.iaux[3];
+            // the (rare) tail of the rest with keys > 1000 moves behind the decided-0 block
+            uint16_t tail[VF];
+#pragma unroll
+            for (int k = 0; k < VF; ++k) { const int i = c_lt + tid + k * NT; tail[k] = (i < totS) ? idx[i] : (uint16_t)0; }
+            __syncthreads();
+            for (int i = tid; i < totZ; i += NT) idx[c_lt + i] = zlist[i];
+#pragma unroll
+            for (int k = 0; k < VF; ++k) { const int i = c_lt + tid + k * NT; if (i < totS) idx[totZ + i] = tail[k]; }
+            __syncthreads();
+            presorted = true;
+        }
     }
-    __syncthreads();
-    R.pm = osd_run<NT, DM>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7]);
+    if (!presorted) {
+        for (int v = tid; v < L.npad; v += NT) {
+            if (v < n) {
+                double sum;
+                const int vv = s.vn_val[v];
+                if (vv == 1) sum = -1000.0;
+                else if (vv == 0) sum = 1000.0;
+                else sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+                key[v] = f2key(sum);
+                idx[v] = (uint16_t)v;
+            } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+        }
+        __syncthreads();
+    }
+    R.pm = osd_run<NT, DM>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted);
     R.exit_class = SWD_EXIT_OSD;
 }
 
