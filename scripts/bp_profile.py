@@ -4,7 +4,7 @@ import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slidingwindowdecoder_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libswd_hip_bpprof.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("SWD_LIB", "libswd_hip_bpprof.so"))
 import bench
 from slidingwindowdecoder_amd import SlidingWindowDecoder
 from slidingwindowdecoder_amd.windows import sample_dem
