@@ -340,6 +340,68 @@ __device__ __forceinline__ void neg_shift_in(uint32_t &w, double x) {
     asm("v_cmp_ge_f64 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x) : "vcc");
 }
 
+// Deals the live checks to the threads for a shortened-graph BP phase: by decreasing live degree (counting
+// sort; a wave's CN pass costs its largest degree and after decimation the degrees are very uneven), and
+// checks heavier than T are shared by 2 or 4 adjacent threads so that no thread walks more than T positions
+// (T = smallest value for which one thread per check of degree <= T, two up to 2T and four up to 4T fit the
+// workgroup; sorted by decreasing degree the quads come first, then the pairs, so quads / pairs stay aligned).
+// dhist: 66 ints, cord: m u16 of LDS.  counted: dhist already holds the degree histogram of the live checks.
+// (The guessing decoders rebuild their caches every few iterations; there the sort costs more than it saves.)
+// Out: the check this thread serves (-1 for none), its rank among the check's threads and their number.
+template <int NT, int KG>
+__device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhist, uint16_t *cord, bool split, bool counted,
+                                          int nlive_cn, int &lc, int &sub, int &grp) {
+    const int tid = threadIdx.x, m = g.m;
+    if (!counted) {
+        for (int i = tid; i < 65; i += NT) dhist[i] = 0;
+        __syncthreads();
+        for (int l = tid; l < m; l += NT)
+            if (s.cn_val[l] >= 0) atomicAdd(&dhist[max(1, min((int)s.cn_deg[l], 64))], 1); // edgeless live checks still own a parity word
+        __syncthreads();
+    }
+    if (tid < 64) { // bin d = 64 - lane: exclusive prefix in order of decreasing degree
+        const int d = 64 - tid;
+        const int c0 = dhist[d];
+        int T = 64, nq = 0, np = 0, nl = c0;
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) nl += __shfl_xor(nl, dd, 64);
+        if (split) {
+            const int cand[8] = {3, 4, 6, 8, 12, 16, 24, 32};
+#pragma unroll 1
+            for (int ci = 0; ci < 8; ++ci) {
+                const int Tc = cand[ci];
+                int need = c0 * (d <= Tc ? 1 : (d <= 2 * Tc ? 2 : 4));
+                int q = (d > 2 * Tc) ? c0 : 0, pr = (d > Tc && d <= 2 * Tc) ? c0 : 0;
+#pragma unroll
+                for (int dd = 32; dd > 0; dd >>= 1) {
+                    need += __shfl_xor(need, dd, 64); q += __shfl_xor(q, dd, 64); pr += __shfl_xor(pr, dd, 64);
+                }
+                const bool toobig = __ballot(c0 > 0 && d > 4 * Tc) != 0ull;
+                if (!toobig && need <= NT && Tc <= KG * 4) { T = Tc; nq = q; np = pr; break; }
+            }
+        }
+        if (tid == 0) { s.iaux[0] = T; s.iaux[1] = nq; s.iaux[2] = np; s.iaux[3] = nl; }
+        int incl = c0;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int y = __shfl_up(incl, dd, 64);
+            if (tid >= dd) incl += y;
+        }
+        dhist[d] = incl - c0;
+    }
+    __syncthreads();
+    for (int l = tid; l < m; l += NT)
+        if (s.cn_val[l] >= 0) cord[atomicAdd(&dhist[max(1, min((int)s.cn_deg[l], 64))], 1)] = (uint16_t)l;
+    __syncthreads();
+    const int nq = s.iaux[1], np = s.iaux[2], ct = s.ctid;
+    const int nl = (nlive_cn >= 0) ? nlive_cn : s.iaux[3];
+    int cidx;
+    if (ct < 4 * nq) { cidx = ct >> 2; sub = ct & 3; grp = 4; }
+    else if (ct < 4 * nq + 2 * np) { const int t2 = ct - 4 * nq; cidx = nq + (t2 >> 1); sub = t2 & 1; grp = 2; }
+    else { cidx = nq + np + (ct - 4 * nq - 2 * np); sub = 0; grp = 1; }
+    lc = (cidx < nl) ? (int)cord[cidx] : -1;
+}
+
 template <int NT, int VF, int DM, int KG, bool FULL>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
@@ -1499,50 +1561,10 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     long long sh2 = wall_clock64();
 #endif
     R.live_vn = nlive; R.live_cn = s.scal[2]; R.live_e = s.scal[3];
-    if (tid < 64) { // bin d = 64 - lane: exclusive prefix in order of decreasing degree
-        const int d = 64 - tid;
-        const int c0 = dhist[d];
-        // Heavy checks are shared by 2 or 4 adjacent threads so that no thread walks more than T
-        // positions: smallest T for which one thread per check of degree <= T, two up to 2T and four up
-        // to 4T fit the workgroup.  Sorted by decreasing degree the quads come first, then the pairs.
-        int T = 64, nq = 0, np = 0;
-        if (uselist) {
-            const int cand[8] = {3, 4, 6, 8, 12, 16, 24, 32};
-#pragma unroll 1
-            for (int ci = 0; ci < 8; ++ci) {
-                const int Tc = cand[ci];
-                int need = c0 * (d <= Tc ? 1 : (d <= 2 * Tc ? 2 : 4));
-                int q = (d > 2 * Tc) ? c0 : 0, pr = (d > Tc && d <= 2 * Tc) ? c0 : 0;
-#pragma unroll
-                for (int dd = 32; dd > 0; dd >>= 1) {
-                    need += __shfl_xor(need, dd, 64); q += __shfl_xor(q, dd, 64); pr += __shfl_xor(pr, dd, 64);
-                }
-                const bool toobig = __ballot(c0 > 0 && d > 4 * Tc) != 0ull;
-                if (!toobig && need <= NT && Tc <= KG * 4) { T = Tc; nq = q; np = pr; break; }
-            }
-        }
-        if (tid == 0) { s.iaux[0] = T; s.iaux[1] = nq; s.iaux[2] = np; }
-        int incl = c0;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const int y = __shfl_up(incl, dd, 64);
-            if (tid >= dd) incl += y;
-        }
-        dhist[d] = incl - c0;
-    }
-    __syncthreads();
-    for (int l = tid; l < m; l += NT)
-        if (s.cn_val[l] >= 0) cord[atomicAdd(&dhist[min((int)s.cn_deg[l], 64)], 1)] = (uint16_t)l;
-    __syncthreads();
-    int cidx, csub, cgrp;
-    {
-        const int nq = s.iaux[1], np = s.iaux[2], ct = s.ctid;
-        if (ct < 4 * nq) { cidx = ct >> 2; csub = ct & 3; cgrp = 4; }
-        else if (ct < 4 * nq + 2 * np) { const int t2 = ct - 4 * nq; cidx = nq + (t2 >> 1); csub = t2 & 1; cgrp = 2; }
-        else { cidx = nq + np + (ct - 4 * nq - 2 * np); csub = 0; cgrp = 1; }
-    }
+    int clc, csub, cgrp;
+    cn_assign<NT, KG>(g, s, dhist, cord, uselist, true, R.live_cn, clc, csub, cgrp);
     vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
-    cn_cache_load<NT, KG, false>(g, s, uselist, cidx < R.live_cn ? (int)cord[cidx] : -1, csub, cgrp, cn);
+    cn_cache_load<NT, KG, false>(g, s, uselist, clc, csub, cgrp, cn);
     __syncthreads(); // every lane has read its slot list before the messages are re-initialised
     bp_init<VF, DM>(s, vc);
     __syncthreads();
