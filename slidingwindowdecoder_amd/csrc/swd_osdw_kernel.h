@@ -789,11 +789,15 @@ __device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
 // (0xFFFF pad), staged in LDS by the whole workgroup for p < nst.
 __device__ __forceinline__ int osd_tidx(int row, int w, int m) { return w * m + row; }
 
-template <int DM>
-__device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw,
-                         uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b,
-                         const uint16_t *crows, int nst, int *npiv_out) {
-    const int lane = threadIdx.x & 63;
+template <int NT, int DM>
+__device__ __forceinline__ int osd0_block(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw,
+                          uint64_t *Sbuf, uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b,
+                          const uint16_t *crows, int nst, int *npiv_out) {
+    // General m (here: m > 256): wave 0 evaluates 64/WG sorted columns per step against T in LDS and picks the
+    // pivot; the row operation on T (m columns x wm words) is shared by ALL threads of the workgroup -- with
+    // one wave it was 13.6k cycles per pivot for the [[288,12,18]] windows (m = 576, wm = 9).  Two barriers
+    // per step; the step outcome travels through ctl[] (found | done << 1, pivot row).  Every thread calls.
+    const int tid = threadIdx.x, lane = tid & 63;
     const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
     int WG = 1;
     while (WG < wm) WG <<= 1;
@@ -801,117 +805,91 @@ __device__ __forceinline__ int osd0_wave(const SwdGraphDev &g, Lds &s, const uin
     const int c = lane / WG, w = lane % WG;
     const bool wact = w < wm;
     const int wl = wact ? w : 0;
-    uint64_t Pw = 0;                    // word w of the pivoted-row mask (replicated per column group)
+    int *ctl = s.iaux + 8;
+    uint64_t Pw = 0;                    // word w of the pivoted-row mask (replicated per column group), wave 0
     int npiv = 0, rowadds = 0, p = 0;
-#ifdef SWD_BPPROF
-    long long acc_scan = 0, acc_upd = 0, acc_f1 = 0; int nscan = 0;
-#endif
-    while (p < n && npiv < rank) {
-#ifdef SWD_BPPROF
-        long long t0 = clock64(); ++nscan;
-#endif
-        const int pc = p + c;
-        const bool cval = wact && pc < n;
-        int rows[DM];
-        if (p + NB <= nst) { // wave-uniform: whole step inside the staged prefix
+    for (;;) {
+        if (tid < 64) {
+            int found = 0;
+            if (p < n && npiv < rank) {
+                const int pc = p + c;
+                const bool cval = wact && pc < n;
+                int rows[DM];
+                if (p + NB <= nst) { // wave-uniform: whole step inside the staged prefix
 #pragma unroll
-            for (int k = 0; k < DM; ++k) rows[k] = crows[pc * DM + k];
-        } else {             // beyond the staged prefix (rare): straight from the graph
-            const int v = cval ? (int)order[pc] : 0;
-            const int deg = cval ? (int)g.col_deg[v] : 0;
+                    for (int k = 0; k < DM; ++k) rows[k] = crows[pc * DM + k];
+                } else {             // beyond the staged prefix (rare): straight from the graph
+                    const int v = cval ? (int)order[pc] : 0;
+                    const int deg = cval ? (int)g.col_deg[v] : 0;
 #pragma unroll
-            for (int k = 0; k < DM; ++k) rows[k] = (k < deg) ? (int)g.vn_row[k * n + v] : 0xFFFF;
+                    for (int k = 0; k < DM; ++k) rows[k] = (k < deg) ? (int)g.vn_row[k * n + v] : 0xFFFF;
+                }
+                uint64_t tw[DM];
+#pragma unroll
+                for (int k = 0; k < DM; ++k) tw[k] = Tw[osd_tidx(rows[k] == 0xFFFF ? 0 : rows[k], wl, m)];
+                uint64_t red = 0;
+#pragma unroll
+                for (int k = 0; k < DM; ++k) red ^= (rows[k] == 0xFFFF) ? 0ull : tw[k];
+                const uint64_t cand = cval ? (red & ~Pw) : 0ull;
+                const unsigned long long bal = __ballot(cand != 0ull);
+                if (bal == 0ull) {
+                    p += NB;
+                } else {
+                    const int fl = __ffsll((long long)bal) - 1; // first column with a usable 1, its lowest word
+                    const int cs = fl / WG, ws = fl % WG;
+                    const uint64_t cw = __shfl(cand, fl, 64);
+                    const int bit = __ffsll((long long)cw) - 1;
+                    const int r = ws * 64 + bit;
+                    {   // row additions the reference's LU would apply: unpivoted rows with a 1 in this column
+                        uint64_t un = (c == cs) ? cand : 0ull;
+                        if (lane == fl) un &= ~(1ull << bit);
+                        rowadds += __popcll(un);
+                    }
+                    if (c == cs && wact) Sbuf[w] = (w == ws) ? (red & ~(1ull << bit)) : red;
+                    if (w == ws) Pw |= 1ull << bit;
+                    if (lane == 0) { piv_col[npiv] = order[p + cs]; piv_row[npiv] = (uint16_t)r; ctl[1] = r; }
+                    ++npiv;
+                    p += cs + 1;
+                    found = 1;
+                }
+            }
+            if (lane == 0) ctl[0] = found | ((p < n && npiv < rank) ? 0 : 2);
         }
-        uint64_t tw[DM];
-#pragma unroll
-        for (int k = 0; k < DM; ++k) tw[k] = Tw[osd_tidx(rows[k] == 0xFFFF ? 0 : rows[k], wl, m)];
-        uint64_t red = 0;
-#pragma unroll
-        for (int k = 0; k < DM; ++k) red ^= (rows[k] == 0xFFFF) ? 0ull : tw[k];
-        const uint64_t cand = cval ? (red & ~Pw) : 0ull;
-        const unsigned long long bal = __ballot(cand != 0ull);
-        if (bal == 0ull) {
-#ifdef SWD_BPPROF
-            acc_scan += clock64() - t0;
-#endif
-            p += NB;
-            continue;
-        }
-        const int fl = __ffsll((long long)bal) - 1; // first column of the step with a usable 1, its lowest word
-        const int cs = fl / WG, ws = fl % WG;
-        const uint64_t cw = __shfl(cand, fl, 64);
-        const int bit = __ffsll((long long)cw) - 1;
-        const int r = ws * 64 + bit;
-        {   // row additions the reference's LU would apply: unpivoted rows with a 1 in this column
-            // (statistics only: per-lane partial sums, reduced once after the loop)
-            uint64_t un = (c == cs) ? cand : 0ull;
-            if (lane == fl) un &= ~(1ull << bit);
-            rowadds += __popcll(un);
-        }
-        if (c == cs && wact) Sbuf[w] = (w == ws) ? (red & ~(1ull << bit)) : red;
-        if (w == ws) Pw |= 1ull << bit;
-        if (lane == 0) { piv_col[npiv] = order[p + cs]; piv_row[npiv] = (uint16_t)r; }
-        ++npiv;
-#ifdef SWD_BPPROF
-        long long tA = clock64();
-#endif
-        wave_fence();
-#ifdef SWD_BPPROF
-        long long tB = clock64();
-        acc_scan += tA - t0; acc_f1 += tB - tA;
-#endif
-        // T[:, j] ^= S for every column j of T with T[r][j] = 1: four columns per lane per round,
-        // reads first, select-XOR, unconditional write-back (no serial read-modify-write chains)
-        const uint64_t rb = 1ull << (r & 63);
-        for (int j0 = 0; j0 < m; j0 += 256) {
-            bool hit[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hit[q] = (Tw[osd_tidx(min(j0 + q * 64 + lane, m - 1), ws, m)] & rb) != 0ull;
-            for (int x0 = 0; x0 < wm; x0 += 4) {
-                uint64_t sv[4], tv[4][4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) sv[x] = Sbuf[min(x0 + x, wm - 1)];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        tv[q][x] = Tw[osd_tidx(min(j0 + q * 64 + lane, m - 1), min(x0 + x, wm - 1), m)];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = j0 + q * 64 + lane;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (j < m && x0 + x < wm) Tw[osd_tidx(j, x0 + x, m)] = tv[q][x] ^ (hit[q] ? sv[x] : 0ull);
+        __syncthreads();
+        const int c0 = ctl[0];
+        if (c0 & 1) { // T[:, j] ^= S for every column j of T with T[r][j] = 1
+            const int r = ctl[1];
+            const int ws = r >> 6;
+            const uint64_t rb = 1ull << (r & 63);
+            for (int j = tid; j < m; j += NT) {
+                if (Tw[osd_tidx(j, ws, m)] & rb) {
+                    for (int x = 0; x < wm; ++x) Tw[osd_tidx(j, x, m)] ^= Sbuf[x];
                 }
             }
         }
+        __syncthreads();
+        if (c0 & 2) break;
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) rowadds += __shfl_xor(rowadds, d, 64);
+        // y = T * s  (s in original row order): lanes over the columns of T, then a wave XOR-reduction
+        for (int x = 0; x < wm; ++x) {
+            uint64_t acc = 0;
+            for (int j = lane; j < m; j += 64)
+                if (synd_b[j]) acc ^= Tw[osd_tidx(j, x, m)];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+            if (lane == 0) Sbuf[x] = acc;
+        }
         wave_fence();
-        p += cs + 1;
-#ifdef SWD_BPPROF
-        acc_upd += clock64() - tB;
-#endif
+        for (int i = lane; i < npiv; i += 64) {
+            const int r = piv_row[i];
+            s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+        }
+        wave_fence();
+        *npiv_out = npiv;
     }
-#ifdef SWD_BPPROF
-    if (lane == 0) { s.scal[20] = nscan; s.scal[21] = (int)(acc_scan >> 4); s.scal[22] = (int)(acc_upd >> 4); s.scal[23] = (int)(acc_f1 >> 4); }
-#endif
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) rowadds += __shfl_xor(rowadds, d, 64);
-    // y = T * s  (s in original row order): lanes over the columns of T, then a wave XOR-reduction
-    for (int x = 0; x < wm; ++x) {
-        uint64_t acc = 0;
-        for (int j = lane; j < m; j += 64)
-            if (synd_b[j]) acc ^= Tw[osd_tidx(j, x, m)];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
-        if (lane == 0) Sbuf[x] = acc;
-    }
-    wave_fence();
-    for (int i = lane; i < npiv; i += 64) {
-        const int r = piv_row[i];
-        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
-    }
-    wave_fence();
-    *npiv_out = npiv;
     return rowadds;
 }
 
@@ -1305,10 +1283,15 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
         for (int k = 0; k < DM; ++k) crows[p * DM + k] = (k < deg) ? g.vn_row[k * n + v] : (uint16_t)0xFFFF;
     }
     __syncthreads();
-    if (tid < 64) {
-        int npiv;
-        const int ra = (g.wm <= 4) ? osd0_wave_reg<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv)
-                                   : osd0_wave<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
+    if (g.wm <= 4) {
+        if (tid < 64) {
+            int npiv;
+            const int ra = osd0_wave_reg<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
+            if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
+        }
+    } else {
+        int npiv = 0;
+        const int ra = osd0_block<NT, DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
         if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
     }
     __syncthreads();
