@@ -80,10 +80,13 @@ struct Plan;
 // A plan uses the first variant with NT >= m, NT*VF >= n, DM >= D, 4*KG >= K over all its windows.
 struct Variant {
     int nt, vf, dm, kg;
+    int sf; // full-graph phase shares heavy checks among threads (needs the host-built map): 4 * kg may be < K
     int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);      // osd_window kernels
     int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing-decoder kernels
 };
-static const Variant *select_variant(int mmax, int nmax, int dm, int kmax, int kind);
+static const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
+static bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);
+
 
 // A decode plan: 1..W windows + (for W > 1 or commit > 0) the global check matrix in CSC form.
 struct Plan {
@@ -97,7 +100,7 @@ struct Plan {
     int device = 0, nt = 256, vf = 7, dm = 8;
     const Variant *variant = nullptr;
     int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
-    DevBuf d_wins, d_chk, d_obs;
+    DevBuf d_wins, d_chk, d_obs, d_cnmap;
     DevBuf shot;
     const uint32_t *d_colptr = nullptr;
     const uint16_t *d_rows = nullptr;
@@ -162,7 +165,7 @@ struct Plan {
         int kmax = 0;
         mmax = 0;
         for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
-        variant = select_variant(mmax, nmax, dm, kmax, kind);
+        variant = select_variant(wins, mmax, nmax, dm, kmax, kind);
         if (!variant) {
             set_error("no kernel variant for m=%d n=%d column weight %d row weight %d", mmax, nmax, dm, kmax);
             return -1;
@@ -182,7 +185,14 @@ struct Plan {
             return -1;
         }
         std::vector<SwdWindowDev> hw(wins.size());
+        if (variant->sf) {
+            std::vector<uint32_t> all, one;
+            for (auto &w : wins) { split_map(*w.g, nt, 4 * variant->kg, &one); all.insert(all.end(), one.begin(), one.end()); }
+            if (d_cnmap.reserve(all.size() * 4)) return -1;
+            SWD_HIP(hipMemcpy(d_cnmap.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+        }
         for (size_t i = 0; i < wins.size(); ++i) {
+            hw[i].cn_map = variant->sf ? d_cnmap.as<uint32_t>() + i * (size_t)nt : nullptr;
             hw[i].g = wins[i].g->d;
             hw[i].g.new_n = wins[i].new_n;
             hw[i].L = wins[i].L;
@@ -217,12 +227,12 @@ struct Plan {
 };
 
 
-template <int NT, int VF, int DM, int KG, int KIND>
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
 static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     SwdPipeArgs a = a0;
     static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
     if (d->lds_total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
     }
     // persistent grid: as many workgroups as fit the device at once (they draw work units until none is left)
@@ -230,7 +240,7 @@ static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     static int slots_lds[64] = {0};
     if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->lds_total) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND>, NT, (size_t)d->lds_total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF>, NT, (size_t)d->lds_total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
         slots_lds[d->device & 63] = d->lds_total;
@@ -245,30 +255,73 @@ static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
             a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
         }
     }
-    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND>), dim3(grid), dim3(NT), d->lds_total, st, a);
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF>), dim3(grid), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
 
+// Static check-to-thread map of the full-graph BP phase for variants that share heavy checks among threads
+// (same rule as cn_assign on the device: smallest T <= cap such that one thread per check of degree <= T,
+// two up to 2T, four up to 4T fit nt threads; lanes are already sorted by decreasing degree).
+static bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map) {
+    static const int cand[8] = {3, 4, 6, 8, 12, 16, 24, 32};
+    for (int ci = 0; ci < 8; ++ci) {
+        const int T = cand[ci];
+        if (T > cap) break;
+        long need = 0;
+        bool ok = true;
+        for (int l = 0; l < g.m; ++l) {
+            const int d = g.row_deg[l];
+            if (d > 4 * T) { ok = false; break; }
+            need += d <= T ? 1 : (d <= 2 * T ? 2 : 4);
+        }
+        if (!ok || need > nt) continue;
+        if (map) {
+            map->assign(nt, 0xFFFFu);
+            int t = 0;
+            for (int pass = 4; pass >= 1; pass >>= 1) // quads first, then pairs, then singles (degrees are sorted)
+                for (int l = 0; l < g.m; ++l) {
+                    const int d = g.row_deg[l];
+                    const int grp = d <= T ? 1 : (d <= 2 * T ? 2 : 4);
+                    if (grp != pass) continue;
+                    for (int r = 0; r < grp; ++r) (*map)[t++] = (uint32_t)l | ((uint32_t)r << 16) | ((uint32_t)grp << 18);
+                }
+        }
+        return true;
+    }
+    return false;
+}
+
 static const Variant kVariants[] = {
 #ifndef SWD_HEADLINE_ONLY // development builds: -DSWD_HEADLINE_ONLY compiles only the [[144,12,12]] kernel
-    {64, 4, 4, 2, launch_nt<64, 4, 4, 2, 0>, launch_nt<64, 4, 4, 2, 1>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
-    {64, 4, 8, 16, launch_nt<64, 4, 8, 16, 0>, launch_nt<64, 4, 8, 16, 1>},
-    {256, 2, 8, 16, launch_nt<256, 2, 8, 16, 0>, launch_nt<256, 2, 8, 16, 1>},
-    {256, 4, 8, 16, launch_nt<256, 4, 8, 16, 0>, launch_nt<256, 4, 8, 16, 1>},
-    {256, 2, 10, 12, launch_nt<256, 2, 10, 12, 0>, launch_nt<256, 2, 10, 12, 1>},  // SHYPS r=3 circuit-level windows (63 x 476, column weight <= 9)
+    {64, 4, 4, 2, 0, launch_nt<64, 4, 4, 2, 0>, launch_nt<64, 4, 4, 2, 1>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
+    {64, 4, 8, 16, 0, launch_nt<64, 4, 8, 16, 0>, launch_nt<64, 4, 8, 16, 1>},
+    {256, 2, 8, 16, 0, launch_nt<256, 2, 8, 16, 0>, launch_nt<256, 2, 8, 16, 1>},
+    {256, 4, 8, 16, 0, launch_nt<256, 4, 8, 16, 0>, launch_nt<256, 4, 8, 16, 1>},
+    {256, 2, 10, 12, 0, launch_nt<256, 2, 10, 12, 0>, launch_nt<256, 2, 10, 12, 1>},  // SHYPS r=3 circuit-level windows (63 x 476, column weight <= 9)
 #endif
-    {256, 7, 6, 9, launch_nt<256, 7, 6, 9, 0>, launch_nt<256, 7, 6, 9, 1>},      // [[144,12,12]] circuit-level windows
+    {256, 7, 6, 9, 0, launch_nt<256, 7, 6, 9, 0>, launch_nt<256, 7, 6, 9, 1>},      // [[144,12,12]] circuit-level windows
 #ifndef SWD_HEADLINE_ONLY
-    {256, 7, 8, 16, launch_nt<256, 7, 8, 16, 0>, launch_nt<256, 7, 8, 16, 1>},
-    {1024, 5, 6, 9, launch_nt<1024, 5, 6, 9, 0>, launch_nt<1024, 5, 6, 9, 1>},    // [[288,12,18]] circuit-level windows
-    {1024, 8, 8, 16, launch_nt<1024, 8, 8, 16, 0>, launch_nt<1024, 8, 8, 16, 1>},
+    {256, 7, 8, 16, 0, launch_nt<256, 7, 8, 16, 0>, launch_nt<256, 7, 8, 16, 1>},
+    {1024, 5, 6, 6, 1, launch_nt<1024, 5, 6, 6, 0, true>, nullptr},                   // [[288,12,18]] circuit-level windows, osd_window
+    {1024, 5, 6, 9, 0, launch_nt<1024, 5, 6, 9, 0>, launch_nt<1024, 5, 6, 9, 1>},    // [[288,12,18]] circuit-level windows
+    {1024, 8, 8, 16, 0, launch_nt<1024, 8, 8, 16, 0>, launch_nt<1024, 8, 8, 16, 1>},
 #endif
 };
 
-static const Variant *select_variant(int mmax, int nmax, int dm, int kmax, int kind) {
-    for (const Variant &v : kVariants)
-        if ((kind == 0 ? v.launch != nullptr : v.launch_gdg != nullptr) && v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm && 4 * v.kg >= kmax) return &v;
+static const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind) {
+    for (const Variant &v : kVariants) {
+        if (!(kind == 0 ? v.launch != nullptr : v.launch_gdg != nullptr)) continue;
+        if (!(v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm)) continue;
+        if (!v.sf) { if (4 * v.kg >= kmax) return &v; continue; }
+        bool ok = true;
+        for (auto &w : wins) {
+            SwdLdsLayout L{};
+            make_layout(*w.g, w.new_n, v.nt, kind, L);
+            if (L.off_lslot < 0 || !split_map(*w.g, v.nt, 4 * v.kg, nullptr)) { ok = false; break; } // the post phase must walk lists
+        }
+        if (ok) return &v;
+    }
     return nullptr;
 }
 

@@ -52,6 +52,7 @@ struct SwdWindowDev {
     int32_t col0;   // first global fault column (anchors[t].col)
     int32_t commit; // leading columns committed after decoding (osd.py:140,170-173)
     int32_t pad;
+    const uint32_t *cn_map; // nullable [NT]: static check-to-thread map of the full-graph phase (check | rank << 16 | threads << 18, 0xFFFF = none)
 };
 
 
@@ -402,7 +403,7 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
     lc = (cidx < nl) ? (int)cord[cidx] : -1;
 }
 
-template <int NT, int VF, int DM, int KG, bool FULL>
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false) {
@@ -486,7 +487,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             int npar = (cn.sub == 0) ? cv : 0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) npar += __popc(neg[r]);
-            if constexpr (!FULL) {
+            if constexpr (!FULL || SF) {
                 // merge the partial results of the check's threads (butterfly inside the quad).  On a tie
                 // of the minima the second minimum equals the first, so which side's position is kept
                 // as "first minimum" does not change any value written below.
@@ -1332,9 +1333,9 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 
 // osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
 // order).  On return s.hard[0..n) is the vector decode() returns.
-template <int NT, int VF, int DM, int KG>
+template <int NT, int VF, int DM, int KG, bool SF>
 __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
-                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, WinResult &R) {
+                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, WinResult &R, const uint32_t *cn_map) {
     const int tid = threadIdx.x;
     const int m = g.m, n = g.n;
 #pragma unroll
@@ -1357,7 +1358,12 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     bp_init<VF, DM>(s, vc);
     CnCache<KG> cn;
-    cn_cache_load<NT, KG, true>(g, s, false, s.ctid < m ? s.ctid : -1, 0, 1, cn);
+    if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)
+        const uint32_t e = cn_map[s.ctid];
+        cn_cache_load<NT, KG, true>(g, s, false, (e & 0xFFFFu) == 0xFFFFu ? -1 : (int)(e & 0xFFFFu), (int)((e >> 16) & 3u), (int)(e >> 18), cn);
+    } else {
+        cn_cache_load<NT, KG, true>(g, s, false, s.ctid < m ? s.ctid : -1, 0, 1, cn);
+    }
     __syncthreads();
 
     int it = 0;
@@ -1366,7 +1372,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     uint16_t *list0 = (uint16_t *)s.scratch;
     R.t[1] = wall_clock64();
 
-    R.conv = bp_run<NT, VF, DM, KG, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha);
+    R.conv = bp_run<NT, VF, DM, KG, true, SF>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha);
     R.pre_it = it;
     R.t[2] = wall_clock64();
     if (R.conv) {
@@ -1639,7 +1645,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 // residual syndrome (osd.py:178, done sparsely on the shot's LDS copy), next window.  Windows
 // of one shot are sequentially dependent, shots are independent, so there is no inter-workgroup
 // traffic at all.  W = 1 with commit = 0 is the plain batched osd_window.decode.
-template <int NT, int VF, int DM, int KG, int KIND>
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1709,7 +1715,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
         if (tid == 0) { s.scal[24] = s.scal[25] = s.scal[26] = s.scal[27] = 0; s.scal[20] = s.scal[21] = s.scal[22] = 0; }
 #endif
         if constexpr (KIND == 0)
-            decode_window<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R);
+            decode_window<NT, VF, DM, KG, SF>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R, w.cn_map);
         else
             decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.snap + (int64_t)sidx * a.snap_stride, R);
         __syncthreads();
