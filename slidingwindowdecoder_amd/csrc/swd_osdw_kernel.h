@@ -812,7 +812,7 @@ __device__ __forceinline__ int osd0_block(const SwdGraphDev &g, Lds &s, const ui
     for (;;) {
         if (tid < 64) {
             int found = 0;
-            if (p < n && npiv < rank) {
+            while (!found && p < n && npiv < rank) { // T only changes at a pivot: runs of dependent columns need no barrier
                 const int pc = p + c;
                 const bool cval = wact && pc < n;
                 int rows[DM];
