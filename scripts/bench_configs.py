@@ -38,7 +38,7 @@ def run_pipeline(name, plan, shots, reps, **kw):
 
 
 if "3" in which:
-    run_pipeline("configs[2]: [[144,12,12]] p=0.003 (3,1) bpgdg_decoder(max_iter=8, T=6, R=25, D=3, S=10)", bench.build_problem(), 2048, 3,
+    run_pipeline("configs[2]: [[144,12,12]] p=0.003 (3,1) bpgdg_decoder(max_iter=8, T=6, R=25, D=3, S=10)", bench.build_problem(), int(os.environ.get("SWD_GDG_SHOTS", "16384")), 2,
                  decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
                  max_tree_branch_step=10, max_side_branch_step=10)
 if "4" in which:

@@ -9,6 +9,8 @@
 #include <map>
 #include <memory>
 
+#include <stdlib.h>
+
 #include "swd_host.h"
 #include "swd_osdw_kernel.h"
 
@@ -244,6 +246,7 @@ static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
         slots_lds[d->device & 63] = d->lds_total;
+        if (getenv("SWD_DEBUG")) fprintf(stderr, "[swd] pipeline_kernel<%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs, %d B LDS\n", NT, VF, DM, KG, KIND, per_cu, cus, d->lds_total);
     }
     const long long units = (long long)a.B * a.W;
     const unsigned grid = (unsigned)std::min<long long>(units, slots[d->device & 63]);
