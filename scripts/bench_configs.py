@@ -42,7 +42,7 @@ if "3" in which:
                  decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
                  max_tree_branch_step=10, max_side_branch_step=10)
 if "4" in which:
-    run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 1024, 3,
+    run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 4096, 2,
                  **dict(bench.DECODER_KW, osd_order=0))
 if "5" in which:
     from slidingwindowdecoder_amd import shyps
