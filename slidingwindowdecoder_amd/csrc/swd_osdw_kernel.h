@@ -447,26 +447,19 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             // group of four are independent.  The two-minimum update
             //   min2 = min(min2, max(min1, a)); min1 = min(min1, a)
             // equals the reference's left/right running minima; |clip(x, -50, 50)| = min(|x|, 50).
-            // Software pipeline of depth one: the reads of group gq+1 are in flight while group gq is
-            // reduced; the scheduling barriers keep the compiler from hoisting every group's reads.
+            // (A hand-made software pipeline over the groups was faster with the default machine scheduler and
+            // is slower with iterative-ilp, which overlaps the reads of the next group by itself.)
             double min1 = 1e308, min2 = 1e308;
             int argslot = farslot;
             uint32_t neg[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) neg[r] = 0;
-            double xn[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xn[u] = s.msg[cn.slot(u)];
 #pragma unroll
             for (int gq = 0; gq < KG; ++gq) {
                 if (gq * 4 < wmax) { // wave-uniform
                     double xs[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xs[u] = xn[u];
-                    if (gq + 1 < KG) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) xn[u] = s.msg[cn.slot(min(gq + 1, KG - 1) * 4 + u)];
-                    }
+                    for (int u = 0; u < 4; ++u) xs[u] = s.msg[cn.slot(gq * 4 + u)];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = gq * 4 + u;
@@ -476,7 +469,6 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                         min1 = vmin64(min1, ax);
                         neg_shift_in(neg[k >> 5], xs[u]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 } else {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) neg[(gq * 4 + u) >> 5] <<= 1; // keep position k at bit (31 - k % 32) ...
