@@ -3,5 +3,5 @@
 set -e
 cd "$(dirname "$0")/../slidingwindowdecoder_amd/csrc"
 mkdir -p build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -structurizecfg-skip-uniform-regions=1 -I../../include -I. -DSWD_HEADLINE_ONLY "$@" -c swd_osdw.hip -o build/swd_osdw_dev.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -structurizecfg-skip-uniform-regions=1 -mllvm -amdgpu-atomic-optimizer-strategy=None -I../../include -I. -DSWD_HEADLINE_ONLY "$@" -c swd_osdw.hip -o build/swd_osdw_dev.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libswd_hip_dev.so build/swd_graph.o build/swd_osdw_dev.o build/swd_bp4.o build/swd_sampler.o

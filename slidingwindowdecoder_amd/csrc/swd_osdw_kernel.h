@@ -557,7 +557,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
                 if (record && valid) hist_b[slot_h * n + v] = temp;
                 const bool hd = valid && (temp <= 0);
-                s.hard[v] = hd ? 1 : 0;
+                ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
                 double suf = 0.0;
 #pragma unroll
                 for (int k = DM - 1; k >= 0; --k) {
