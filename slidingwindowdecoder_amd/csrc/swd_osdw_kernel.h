@@ -1348,6 +1348,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
     VnCache<VF, DM> vc;
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
+    // the check state and jptr written above are read below by OTHER threads (a check is served by the thread
+    // whose ctid equals its lane number, which need not be the thread that initialised it)
+    __syncthreads();
     bp_init<VF, DM>(s, vc);
     CnCache<KG> cn;
     if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised device-vs-oracle comparison (not collected by pytest; run by hand on a GPU box):
+    python tests/fuzz_vs_oracle.py [trials] [seed]
+Random ragged matrices, priors, iteration counts, scaling factors, OSD methods/orders, shortening lengths;
+syndromes from sampled errors and from random bits (inconsistent).  Everything must agree bit for bit."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from slidingwindowdecoder_amd import osd_window  # noqa: E402
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for t in range(trials):
+    m = int(rng.integers(6, 120))
+    n = int(rng.integers(m + 4, min(6 * m, 700)))
+    dens = rng.uniform(1.5, 4.0) / m
+    H = (rng.random((m, n)) < dens).astype(np.uint8)
+    for c in range(n):
+        if H[:, c].sum() == 0:
+            H[rng.integers(m), c] = 1
+    for r in range(m):
+        if H[r].sum() == 0:
+            H[r, rng.integers(n)] = 1
+    if H.sum(axis=0).max() > 8 or H.sum(axis=1).max() > 60:
+        continue
+    p = rng.uniform(0.002, 0.1, size=n)
+    if rng.random() < 0.3:
+        p[:] = rng.uniform(0.005, 0.05)  # equal priors: many exact ties in the orderings
+    method = ["osd_0", "osd_cs", "osd_e"][int(rng.integers(3))]
+    order = 0 if method == "osd_0" else int(rng.integers(0, 6))
+    kw = dict(channel_probs=p, pre_max_iter=int(rng.integers(1, 10)), post_max_iter=int(rng.integers(1, 60)),
+              ms_scaling_factor=float(rng.choice([1.0, 0.9, 0.75, 0.625])), osd_method=method, osd_order=order,
+              new_n=int(rng.integers(m, n + 1)))
+    try:
+        ora = O.osd_window(H, **kw)
+    except ValueError:
+        continue
+    dev = osd_window(H, **kw)
+    B = 256
+    e = (rng.random((B, n)) < p * rng.uniform(0.5, 3.0)).astype(np.uint8)
+    synd = (e @ H.T) % 2
+    synd[B // 2:] = (rng.random((B - B // 2, m)) < 0.3).astype(np.uint8)  # inconsistent half
+    out = dev.decode_batch(synd)
+    want, res = ora.decode_batch(synd)
+    ok = (out == want).all() and np.array_equal(dev.last_iterations, res["bp_iteration"]) and \
+        np.array_equal(dev.last_min_pm, res["min_pm"]) and np.array_equal(dev.last_status & 0xFF, res["exit_class"])
+    if not ok:
+        bad += 1
+        d = np.flatnonzero((out != want).any(axis=1) | (dev.last_iterations != res["bp_iteration"]) | (dev.last_min_pm != res["min_pm"])
+                           | ((dev.last_status & 0xFF) != res["exit_class"]))
+        print(f"trial {t}: MISMATCH m={m} n={n} kw={ {k: v for k, v in kw.items() if k != 'channel_probs'} } shots {d[:5].tolist()} "
+              f"classes dev {(dev.last_status[d[:5]] & 0xFF).tolist()} ora {res['exit_class'][d[:5]].tolist()} "
+              f"its dev {dev.last_iterations[d[:5]].tolist()} ora {res['bp_iteration'][d[:5]].tolist()} "
+              f"vector differs {(out[d[:5]] != want[d[:5]]).sum(axis=1).tolist()} threads {getattr(dev, 'threads', None)}")
+print(f"{trials} trials, {bad} mismatching")
+sys.exit(1 if bad else 0)

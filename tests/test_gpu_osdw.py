@@ -209,3 +209,15 @@ def test_constructor_and_decode_errors():
     # float 0.0/1.0 syndromes are accepted like the reference's (char) cast (osd.py:165,178)
     out = d.decode(np.zeros(36, dtype=np.float64))
     assert out.dtype == np.int64 and not out.any()
+
+
+def test_fuzz_medium_codes_vs_oracle():
+    """Randomised matrices with 65..120 checks (the 256-thread kernel variants: a check is served by a thread of
+    another wave than the one that initialised it) -- tests/fuzz_vs_oracle.py with a fixed seed."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_vs_oracle.py"), "40", "7"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
