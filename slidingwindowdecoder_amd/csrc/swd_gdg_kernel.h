@@ -354,6 +354,12 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     }
     for (int v = tid; v < n; v += NT) G.bp_hard[v] = s.hard[v];
     __syncthreads();
+    // BPGD keeps its own 4-slot history (bpgd.cpp:357-358, never initialised by the reference) and
+    // restarts at slot 0 in every block (bpgd.cpp:166): with fewer than 4 iterations per block
+    // the upper slots are never written.  The oracle defines them as zero; the pre-phase
+    // values this buffer still holds there must not leak into select_vn / decimate_vn_reliable.
+    if (P.max_iter_per_step < 4)
+        for (int i = P.max_iter_per_step * n + tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
     sort_pairs<NT>(key, idx, L.npad);
     for (int i = tid; i < n; i += NT) {
         const int v = idx[i];

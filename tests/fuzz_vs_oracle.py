@@ -14,10 +14,12 @@ from slidingwindowdecoder_amd import osd_window  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+mlo, mhi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6, 120)
+mode = sys.argv[5] if len(sys.argv) > 5 else "osdw"  # osdw | gdg | gd | bp
 bad = 0
 for t in range(trials):
-    m = int(rng.integers(6, 120))
-    n = int(rng.integers(m + 4, min(6 * m, 700)))
+    m = int(rng.integers(mlo, mhi))
+    n = int(rng.integers(m + 4, min(6 * m, 2000)))
     dens = rng.uniform(1.5, 4.0) / m
     H = (rng.random((m, n)) < dens).astype(np.uint8)
     for c in range(n):
@@ -36,6 +38,30 @@ for t in range(trials):
     kw = dict(channel_probs=p, pre_max_iter=int(rng.integers(1, 10)), post_max_iter=int(rng.integers(1, 60)),
               ms_scaling_factor=float(rng.choice([1.0, 0.9, 0.75, 0.625])), osd_method=method, osd_order=order,
               new_n=int(rng.integers(m, n + 1)))
+    if mode != "osdw":
+        from slidingwindowdecoder_amd import bp_history_decoder, bpgd_decoder, bpgdg_decoder
+        okw = dict(channel_probs=p, max_iter=int(rng.integers(1, 12)), ms_scaling_factor=kw["ms_scaling_factor"],
+                   max_iter_per_step=int(rng.integers(2, 8)), max_step=int(rng.integers(3, 20)), max_tree_depth=int(rng.integers(1, 4)),
+                   max_side_depth=int(rng.integers(4, 10)), max_tree_branch_step=10, max_side_branch_step=int(rng.integers(3, 10)),
+                   new_n=kw["new_n"], low_error_mode=bool(rng.integers(2)))
+        dc, oc = {"gdg": (bpgdg_decoder, O.bpgdg_decoder), "gd": (bpgd_decoder, O.bpgd_decoder), "bp": (bp_history_decoder, O.bp_history_decoder)}[mode]
+        if mode != "gdg":
+            okw.pop("low_error_mode")
+        dev, ora = dc(H, **okw), oc(H, **okw)
+        B = 48
+        e = (rng.random((B, n)) < p * rng.uniform(0.5, 3.0)).astype(np.uint8)
+        synd = (e @ H.T) % 2
+        out = dev.decode_batch(synd)
+        bad_here = 0
+        for b in range(B):
+            ora = oc(H, **okw)  # a fresh object per shot: the device gives every shot of a batch a fresh decoder's state
+            w = ora.decode(synd[b])
+            if not np.array_equal(w, out[b]) or bool(ora.converge) != bool(dev.last_status[b] & 0x100):
+                bad_here += 1
+        if bad_here:
+            bad += 1
+            print(f"trial {t}: {mode} MISMATCH m={m} n={n} shots {bad_here}/{B} kw={ {k: v for k, v in okw.items() if k != 'channel_probs'} }")
+        continue
     try:
         ora = O.osd_window(H, **kw)
     except ValueError:

@@ -221,3 +221,16 @@ def test_fuzz_medium_codes_vs_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_vs_oracle.py"), "40", "7"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", ["gd", "gdg", "bp"])
+def test_fuzz_guessing_decoders_vs_oracle(mode):
+    """Randomised matrices and parameters for bpgd_decoder / bpgdg_decoder / bp_history_decoder, including
+    max_iter_per_step < 4 where BPGD's 4-slot history (bpgd.cpp:357-358) is only partly written per block."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_vs_oracle.py"), "30", "5", "6", "200", mode],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
