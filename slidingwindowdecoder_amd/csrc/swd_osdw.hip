@@ -143,6 +143,10 @@ struct Plan {
             set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", w.new_n - w.g->rank);
             return -1;
         }
+        if (commit < 0 || commit > n || row0 < 0 || col0 < 0) { // osd.py:140,170-173: e_hat[:commit] is a slice of the window's estimate
+            set_error("invalid window placement: row0 %d col0 %d commit %d for a window with %d columns", row0, col0, commit, n);
+            return -1;
+        }
         w.row0 = row0; w.col0 = col0; w.commit = commit;
         wins.push_back(w);
         return 0;
@@ -223,6 +227,8 @@ struct Plan {
             d_rows = (const uint16_t *)((char *)d_chk.p + o_rows);
             for (auto &w : wins)
                 if (w.col0 + w.commit > num_col) { set_error("commit range exceeds the global column count"); return -1; }
+            for (auto &w : wins)
+                if (w.row0 + w.g->m > chk->m) { set_error("invalid window placement: rows %d..%d exceed the %d detectors", w.row0, w.row0 + w.g->m, chk->m); return -1; }
         }
         return 0;
     }

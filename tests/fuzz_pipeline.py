@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Randomised whole-pipeline comparison (not collected by pytest; run by hand or from the GPU suite):
+    python tests/fuzz_pipeline.py [trials] [seed] [decoder] [max detectors per round]
+Random block-banded detector error models (R rounds of h detectors; faults local to a round or
+reaching into the next one), random (W, F), priors and decoder parameters.  The device runs all
+shots and windows in one launch; the expectation is the host-side window loop of
+windows.sliding_window_decode_host (commit rule of osd.py:130-179) driven with the oracle, a fresh
+oracle state per decode.  Everything must agree bit for bit."""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from slidingwindowdecoder_amd import SlidingWindowDecoder  # noqa: E402
+from slidingwindowdecoder_amd.windows import Window, WindowPlan, sliding_window_decode_host  # noqa: E402
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+decoder = sys.argv[3] if len(sys.argv) > 3 else "osd_window"
+hmax = int(sys.argv[4]) if len(sys.argv) > 4 else 48
+
+
+class Fresh:
+    """Oracle decoder whose state is that of a newly built object at every decode."""
+
+    def __init__(self, make):
+        self.make = make
+
+    def decode(self, s):
+        self.d = self.make()
+        return self.d.decode(s)
+
+
+def random_plan():
+    h = int(rng.integers(6, hmax))
+    R = int(rng.integers(4, 9))
+    W = int(rng.integers(2, min(R, 4) + 1))
+    F = int(rng.integers(1, W))  # F < W: the committed columns must lie inside the window
+    nloc = [int(rng.integers(h, 3 * h)) for _ in range(R)]
+    nspan = [int(rng.integers(h // 2, 2 * h)) if r < R - 1 else 0 for r in range(R)]
+    rows, cols = [], []
+    col = 0
+    starts = []
+    for r in range(R):
+        starts.append(col)
+        for kind, cnt in (("loc", nloc[r]), ("span", nspan[r])):
+            for i in range(cnt):
+                if kind == "loc":
+                    k = int(rng.integers(1, 4))
+                    rr = r * h + rng.choice(h, size=min(k, h), replace=False)
+                    if i < h:  # every detector has a fault local to its own round: no empty window rows
+                        rr = np.union1d(rr, [r * h + i])
+                else:
+                    k0, k1 = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+                    rr = np.concatenate((r * h + rng.choice(h, size=k0, replace=False),
+                                         (r + 1) * h + rng.choice(h, size=k1, replace=False)))
+                rows += rr.tolist()
+                cols += [col] * len(rr)
+                col += 1
+    starts.append(col)
+    num_row, num_col = R * h, col
+    chk = sp.csr_matrix((np.ones(len(rows), np.uint8), (rows, cols)), shape=(num_row, num_col))
+    if np.diff(chk.indptr).max() > 60 or np.diff(chk.indptr).min() == 0:
+        return None
+    priors = rng.uniform(0.002, 0.06, size=num_col)
+    if rng.random() < 0.3:
+        priors[:] = rng.uniform(0.005, 0.03)
+    nobs = int(rng.integers(1, 13))
+    obs = sp.csr_matrix((rng.random((nobs, num_col)) < 0.1).astype(np.uint8))
+    noisy_prior = float(rng.uniform(0.01, 0.1))
+    anchors = [(r * h, starts[r]) for r in range(R)] + [(num_row, num_col)]
+    wins = []
+    top = 0
+    while True:
+        last = top + W >= R
+        a = anchors[top]
+        b = anchors[min(top + W, R)]
+        if not last:
+            c1 = starts[top + W - 1] + nloc[top + W - 1]
+            sub = chk[a[0]:b[0], a[1]:c1]
+            nrow = b[0] - a[0]
+            ident = sp.csr_matrix((np.ones(h, np.uint8), (np.arange(nrow - h, nrow), np.arange(h))), shape=(nrow, h))
+            mat = sp.hstack((sub, ident), format="csr")
+            prior = np.concatenate((priors[a[1]:c1], np.full(h, noisy_prior)))
+            ncg = c1 - a[1]
+            commit = anchors[top + F][1] - a[1]
+        else:
+            mat = sp.csr_matrix(chk[a[0]:b[0], a[1]:b[1]])
+            prior = priors[a[1]:b[1]].copy()
+            ncg = commit = b[1] - a[1]
+        mat.sort_indices()
+        wins.append(Window(a[0], b[0], a[1], ncg, commit, mat, prior, last))
+        if last:
+            break
+        top += F
+    return WindowPlan(chk, obs, priors, np.arange(num_col), anchors, wins, noisy_prior, h), (h, R, W, F)
+
+
+bad = done = 0
+while done < trials:
+    r = random_plan()
+    if r is None:
+        continue
+    plan, geo = r
+    mmax = max(w.mat.shape[0] for w in plan.windows)
+    nmax = max(w.mat.shape[1] for w in plan.windows)
+    nmin = min(w.mat.shape[1] for w in plan.windows)
+    if decoder == "osd_window":
+        method = ["osd_0", "osd_cs", "osd_e"][int(rng.integers(3))]
+        kw = dict(pre_max_iter=int(rng.integers(1, 10)), post_max_iter=int(rng.integers(1, 40)),
+                  ms_scaling_factor=float(rng.choice([1.0, 0.9, 0.75, 0.625])), osd_method=method,
+                  osd_order=0 if method == "osd_0" else int(rng.integers(0, 6)), new_n=int(rng.integers(mmax, nmax + 1)))
+        make = lambda w: Fresh(lambda: O.osd_window(w.mat, channel_probs=w.prior, **kw))  # noqa: E731
+    else:
+        kw = dict(max_iter=int(rng.integers(1, 12)), ms_scaling_factor=float(rng.choice([1.0, 0.9, 0.75, 0.625])),
+                  max_iter_per_step=int(rng.integers(1, 8)), max_step=int(rng.integers(3, 20)), max_tree_depth=int(rng.integers(1, 4)),
+                  max_side_depth=int(rng.integers(4, 10)), max_tree_branch_step=10, max_side_branch_step=int(rng.integers(3, 10)),
+                  new_n=int(rng.integers(mmax, nmax + 1)))
+        if decoder == "bpgdg_decoder":
+            kw["low_error_mode"] = bool(rng.integers(2))
+        oc = getattr(O, decoder)
+        make = lambda w: Fresh(lambda: oc(w.mat, channel_probs=w.prior, **kw))  # noqa: E731
+    try:
+        for w in plan.windows:
+            make(w).decode(np.zeros(w.mat.shape[0], np.uint8))
+    except ValueError:
+        continue  # a window matrix the oracle rejects (rank deficient for OSD)
+    done += 1
+    B = 64
+    e = (rng.random((B, plan.chk.shape[1])) < plan.priors * rng.uniform(0.5, 2.5)).astype(np.uint8)
+    det = ((sp.csr_matrix(e) @ plan.chk.T.astype(np.int32)).toarray() % 2).astype(np.uint8)
+    det[B - 8:] = (rng.random((8, plan.chk.shape[0])) < 0.2).astype(np.uint8)  # inconsistent tail
+    try:
+        dev = SlidingWindowDecoder(plan, decoder=decoder, **kw)
+    except (ValueError, RuntimeError) as ex:
+        print(f"trial {done}: device rejected geo={geo} m<={mmax} n<={nmax}: {ex}")
+        bad += 1
+        continue
+    total = dev.decode(det)
+    its = np.zeros((B, len(plan.windows)), np.int64)
+    conv = np.zeros((B, len(plan.windows)), bool)
+
+    def tap(wi, j, dec, s, e_hat):
+        its[j, wi] = dec.d.bp_iteration if hasattr(dec.d, "bp_iteration") else 0
+        conv[j, wi] = bool(dec.d.converge)
+
+    want, _ = sliding_window_decode_host(plan, det, make, on_decode=tap)
+    ok = np.array_equal(total, want) and np.array_equal((dev.last_stats[:, :, 0] & 0x100) != 0, conv)
+    if decoder == "osd_window":
+        ok = ok and np.array_equal(dev.last_stats[:, :, 1], its)
+    pred = (sp.csr_matrix(want) @ plan.obs.T.astype(np.int32)).toarray() % 2
+    mask = (pred.astype(np.uint32) << np.arange(plan.obs.shape[0], dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+    resid = ((det + (sp.csr_matrix(want) @ plan.chk.T.astype(np.int32)).toarray()) % 2).any(axis=1)
+    ok = ok and np.array_equal(dev.last_obs_flips, mask) and np.array_equal(dev.last_flagged, resid)
+    if not ok:
+        bad += 1
+        d = np.flatnonzero((total != want).any(axis=1))
+        print(f"trial {done}: MISMATCH {decoder} geo(h,R,W,F)={geo} windows={len(plan.windows)} m<={mmax} n in [{nmin},{nmax}] "
+              f"kw={kw} shots differing {d.size}/{B} first {d[:6].tolist()} threads {dev.threads} "
+              f"flips_ok {np.array_equal(dev.last_obs_flips, mask)} flagged_ok {np.array_equal(dev.last_flagged, resid)} "
+              f"conv_ok {np.array_equal((dev.last_stats[:, :, 0] & 0x100) != 0, conv)}")
+print(f"{trials} trials, {bad} mismatching")
+sys.exit(1 if bad else 0)

@@ -91,3 +91,27 @@ def test_bb288_pipeline_vs_oracle_host_loop():
     want, _ = sliding_window_decode_host(plan, det, lambda w: O.osd_window(w.mat, channel_probs=w.prior, **kw))
     bad = np.flatnonzero((total != want).any(axis=1))
     assert bad.size == 0, f"shots {bad.tolist()} differ; exit classes {(dec.last_stats[bad, :, 0] & 0xFF).tolist()}, iterations {dec.last_stats[bad, :, 1].tolist()}"
+
+
+@pytest.mark.parametrize("decoder", ["osd_window", "bpgdg_decoder", "bpgd_decoder"])
+def test_fuzz_random_window_plans_vs_oracle_host_loop(decoder):
+    """Random block-banded detector error models, (W, F), priors and decoder parameters: one device launch
+    against the host window loop driven with the oracle (tests/fuzz_pipeline.py, fixed seed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_pipeline.py"), "12", "3", decoder],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_window_placement_is_validated():
+    """A commit count larger than the window (osd.py:170-173 would fail to broadcast) is refused at create time."""
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    w = plan.windows[0]
+    plan.windows[0] = type(w)(w.row0, w.row1, w.col0, w.ncols_global, w.mat.shape[1] + 1, w.mat, w.prior, w.is_last)
+    with pytest.raises(ValueError, match="invalid window placement"):
+        SlidingWindowDecoder(plan, **fx.params(f, "osd0_params"))
