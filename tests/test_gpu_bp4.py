@@ -47,3 +47,13 @@ def test_bp4_single_decode_surface():
         dec.decode(np.zeros(5), np.zeros(36))
     with pytest.raises(ValueError):
         bp4_osd(c["code"].hx, c["code"].hz[:, :-1], channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"])
+
+
+def test_fuzz_random_codes_vs_oracle():
+    """Random ragged Hx / Hz, priors and parameters (tests/fuzz_bp4.py, fixed seed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_bp4.py"), "30", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
