@@ -155,6 +155,15 @@ int swd_bp4_decode_batch(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t
                          int32_t *stats, double *lpr, uint8_t *osd0);
 int swd_bp4_decode_batch_dev(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
                              int32_t *stats, double *lpr, uint8_t *osd0, void *stream);
+/* bp4_osd.camel_decode (/root/reference/src/bp4_osd.pyx:223-247, called by Misc.ipynb): the last qubit is fixed to
+ * I, X, Z, Y in turn, plain BP4 decodes the rest, the converged run of smallest path metric wins (ties: the
+ * earliest).  out [B*2*n]; stats [B*SWD_STAT_WORDS] ([0] converge flag, [1] bp_iteration of the last run,
+ * [5] winning Pauli or -1); min_pm [B] nullable (10000.0 when no run converged).  Every shot has the state of a
+ * newly constructed reference object: without a converged run the zero vectors are returned. */
+int swd_bp4_camel_decode_batch(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                               int32_t *stats, double *min_pm);
+int swd_bp4_camel_decode_batch_dev(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                                   int32_t *stats, double *min_pm, void *stream);
 
 /* ---- DEM sampler -----------------------------------------------------------------------------
  * Replaces `dem.compile_sampler().sample(shots)` of the reference harness (/root/reference/osd.py:124-125,

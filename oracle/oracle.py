@@ -65,6 +65,7 @@ def lib():
         L.swo_bp4_create.argtypes = [C.c_int] * 3 + [C.c_void_p] * 7 + [C.POINTER(_Bp4Params)]
         L.swo_bp4_free.argtypes = [C.c_void_p]
         L.swo_bp4_decode.argtypes = [C.c_void_p] * 5 + [C.POINTER(_Result)] + [C.c_void_p] * 3
+        L.swo_bp4_camel_decode.argtypes = [C.c_void_p] * 5 + [C.POINTER(_Result)]
         L.swo_bp4_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.swo_graph_create.restype = C.c_void_p
         L.swo_graph_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -288,8 +289,16 @@ class bp4_osd:
                              self._lpr.ctypes.data, self._o0x.ctypes.data, self._o0z.ctypes.data)
         return np.stack([ox, oz]).astype(np.int64)
 
+    def camel_decode(self, sx, sz):
+        sx, sz = _synd_u8(sx, self.mx), _synd_u8(sz, self.mz)
+        ox, oz = np.zeros(self.n, np.uint8), np.zeros(self.n, np.uint8)
+        lib().swo_bp4_camel_decode(self._h, sx.ctypes.data, sz.ctypes.data, ox.ctypes.data, oz.ctypes.data, C.byref(self._res))
+        self._o0x[:], self._o0z[:] = ox, oz
+        return np.stack([ox, oz]).astype(np.int64)
+
     converge = property(lambda self: self._res.converge)
     bp_iteration = property(lambda self: self._res.bp_iteration)
+    min_pm = property(lambda self: self._res.min_pm)
     log_prob_ratios = property(lambda self: self._lpr.copy())
     osd0_decoding_x = property(lambda self: self._o0x.astype(np.int64))
     osd0_decoding_z = property(lambda self: self._o0z.astype(np.int64))

@@ -1127,29 +1127,79 @@ static void bp4_osd_basis(swo_bp4 *d, int is_x) {
     free(x);
 }
 
-int swo_bp4_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *out_x, uint8_t *out_z,
-                   swo_result *res, double *lpr, uint8_t *osd0_x, uint8_t *osd0_z) {
+/* reset (bp4_osd.pyx:370-385) + bp_init (:425-442); every VN is undecided after reset */
+static void bp4_reset_init(swo_bp4 *d) {
     const int n = d->n;
-    for (int c = 0; c < d->mx; c++) d->synd_x[c] = d->cn_x[c] = (signed char)sx[c];
-    for (int c = 0; c < d->mz; c++) d->synd_z[c] = d->cn_z[c] = (signed char)sz[c];
+    for (int c = 0; c < d->mx; c++) d->cn_x[c] = d->synd_x[c];
+    for (int c = 0; c < d->mz; c++) d->cn_z[c] = d->synd_z[c];
     d->bp_iteration = 0;
     for (int v = 0; v < n; v++) { d->vn[v] = -1; d->dec_x[v] = d->dec_z[v] = 0; }
-    for (int v = 0; v < n; v++) { /* bp_init bp4_osd.pyx:425-442 */
+    for (int v = 0; v < n; v++) {
         double llrx = d->llr_x[v], llry = d->llr_y[v], llrz = d->llr_z[v];
         double msg_x = log1pexp_(-1. * llrx) - logaddexp_(-1. * llry, -1. * llrz);
         for (int k = d->hx.col_ptr[v]; k < d->hx.col_ptr[v + 1]; k++) d->hx.b2c[d->hx.c2r[k]] = msg_x;
         double msg_z = log1pexp_(-1. * llrz) - logaddexp_(-1. * llry, -1. * llrz);
         for (int k = d->hz.col_ptr[v]; k < d->hz.col_ptr[v + 1]; k++) d->hz.b2c[d->hz.c2r[k]] = msg_z;
     }
+}
+
+/* bp4_decode_llr (bp4_osd.pyx:444-481): decided VNs keep their messages and decisions (:456-459), checks are
+   never masked (:483-529) */
+static int bp4_run(swo_bp4 *d) {
     d->converge = 0;
-    for (int it = 0; it < d->p.max_iter; it++) { /* bp4_decode_llr :444-481 */
+    for (int it = 0; it < d->p.max_iter; it++) {
         d->bp_iteration += 1;
         bp4_cn_update(&d->hx, d->cn_x, d->p.ms_scaling_factor);
         bp4_cn_update(&d->hz, d->cn_z, d->p.ms_scaling_factor);
-        for (int v = 0; v < n; v++) bp4_vn_update(d, v);
+        for (int v = 0; v < d->n; v++) if (d->vn[v] == -1) bp4_vn_update(d, v);
         if (syndrome_matches(&d->hx, d->dec_z, d->synd_x, d->scratch) &&
-            syndrome_matches(&d->hz, d->dec_x, d->synd_z, d->scratch)) { d->converge = 1; break; }
+            syndrome_matches(&d->hz, d->dec_x, d->synd_z, d->scratch)) { d->converge = 1; return 1; }
     }
+    return 0;
+}
+
+/* camel_decode (bp4_osd.pyx:223-247): the last qubit is fixed to I, X, Z, Y in turn (vn_set_value :388-423),
+   plain BP4 runs on the rest, the converged run of smallest path metric (cal_pm :249-258) wins; strict <
+   keeps the earliest.  The returned osd0 vectors and min_pm persist in the object like in the reference:
+   when no run converges the previous call's vectors come back (zeros for a new object). */
+int swo_bp4_camel_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *out_x, uint8_t *out_z, swo_result *res) {
+    const int n = d->n;
+    for (int c = 0; c < d->mx; c++) d->synd_x[c] = (signed char)sx[c];
+    for (int c = 0; c < d->mz; c++) d->synd_z[c] = (signed char)sz[c];
+    double min_pm = 10000.0;
+    for (int value = 0; value < 4; value++) {
+        bp4_reset_init(d);
+        const int vn = n - 1, x = value % 2, z = value / 2;
+        d->vn[vn] = (signed char)value;
+        d->dec_x[vn] = (signed char)x; d->dec_z[vn] = (signed char)z;
+        if (z) for (int k = d->hx.col_ptr[vn]; k < d->hx.col_ptr[vn + 1]; k++) { int cn = d->hx.row_idx[k]; d->cn_x[cn] = (signed char)(1 - d->cn_x[cn]); }
+        if (x) for (int k = d->hz.col_ptr[vn]; k < d->hz.col_ptr[vn + 1]; k++) { int cn = d->hz.row_idx[k]; d->cn_z[cn] = (signed char)(1 - d->cn_z[cn]); }
+        if (bp4_run(d)) {
+            double pm = 0.0;
+            for (int v = 0; v < n; v++) {
+                if (d->dec_x[v] && d->dec_z[v]) pm += d->llr_y[v];
+                else if (d->dec_x[v]) pm += d->llr_x[v];
+                else if (d->dec_z[v]) pm += d->llr_z[v];
+            }
+            if (pm < min_pm) {
+                min_pm = pm;
+                for (int v = 0; v < n; v++) { d->osd0_x[v] = d->dec_x[v]; d->osd0_z[v] = d->dec_z[v]; }
+            }
+        }
+    }
+    if (min_pm < 9999.0) d->converge = 1;
+    for (int v = 0; v < n; v++) { out_x[v] = (uint8_t)d->osd0_x[v]; out_z[v] = (uint8_t)d->osd0_z[v]; }
+    if (res) { res->converge = d->converge; res->bp_iteration = d->bp_iteration; res->exit_class = SWO_EXIT_PRE; res->reserved = 0; res->min_pm = min_pm; }
+    return 0;
+}
+
+int swo_bp4_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *out_x, uint8_t *out_z,
+                   swo_result *res, double *lpr, uint8_t *osd0_x, uint8_t *osd0_z) {
+    const int n = d->n;
+    for (int c = 0; c < d->mx; c++) d->synd_x[c] = (signed char)sx[c];
+    for (int c = 0; c < d->mz; c++) d->synd_z[c] = (signed char)sz[c];
+    bp4_reset_init(d);
+    bp4_run(d);
     int exit_class;
     const signed char *rx = d->dec_x, *rz = d->dec_z;
     if (d->converge) {

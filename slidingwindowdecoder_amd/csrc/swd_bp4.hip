@@ -15,7 +15,7 @@ struct Bp4 {
     int device = 0, nt = 256, dm = 4, n = 0;
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
-    DevBuf llr, sx, sz, out, osd0, stats, lpr;
+    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm;
     const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
 };
 
@@ -26,7 +26,7 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
         SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<NT, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
         lds_limit[d->device & 63] = d->L.total;
     }
-    hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(a.B), dim3(NT), d->L.total, st, a);
+    hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(a.camel ? 4 * a.B : a.B), dim3(NT), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
@@ -141,6 +141,55 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     hipStream_t st = (hipStream_t)stream;
     if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : bp4_launch<256, 8>(d, a, st);
     return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : bp4_launch<1024, 8>(d, a, st);
+}
+
+extern "C" int swd_bp4_camel_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                                              int32_t *stats, double *min_pm, void *stream) {
+    Bp4 *d = (Bp4 *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (B <= 0) return 0;
+    if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    const size_t n = d->n;
+    if (d->lpr.reserve((size_t)4 * B * 3 * n * 8) || d->cdec.reserve((size_t)4 * B * 2 * n) || d->cpm.reserve((size_t)4 * B * 8) ||
+        d->cst.reserve((size_t)4 * B * 2 * 4))
+        return -1;
+    SwdBp4Args a{};
+    a.gx = d->gx.d; a.gz = d->gz.d; a.Lx = d->Lx; a.Lz = d->Lz; a.L = d->L;
+    a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
+    a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
+    a.B = B; a.sx = sx; a.sz = sz; a.out = nullptr; a.osd0 = nullptr; a.stats = nullptr; a.lpr = d->lpr.as<double>();
+    a.camel = 1; a.camel_dec = d->cdec.as<uint8_t>(); a.camel_pm = d->cpm.as<double>(); a.camel_st = d->cst.as<int32_t>();
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (d->nt == 256) rc = d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : bp4_launch<256, 8>(d, a, st);
+    else rc = d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : bp4_launch<1024, 8>(d, a, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bp4_camel_select, dim3(B), dim3(256), 0, st, (int)n, a.camel_dec, a.camel_pm, a.camel_st, out, stats, min_pm);
+    SWD_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int swd_bp4_camel_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                                          int32_t *stats, double *min_pm) {
+    Bp4 *d = (Bp4 *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (B <= 0) return 0;
+    SWD_HIP(hipSetDevice(d->device));
+    const size_t n = d->n, mx = d->gx.m, mz = d->gz.m;
+    if (d->sx.reserve(B * mx) || d->sz.reserve(B * mz) || d->out.reserve(B * 2 * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
+        d->pm.reserve((size_t)B * 8))
+        return -1;
+    SWD_HIP(hipMemcpy(d->sx.p, sx, B * mx, hipMemcpyHostToDevice));
+    SWD_HIP(hipMemcpy(d->sz.p, sz, B * mz, hipMemcpyHostToDevice));
+    int rc = swd_bp4_camel_decode_batch_dev(h, B, d->sx.as<uint8_t>(), d->sz.as<uint8_t>(), d->out.as<uint8_t>(), d->stats.as<int32_t>(),
+                                            d->pm.as<double>(), nullptr);
+    if (rc) return rc;
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(out, d->out.p, B * 2 * n, hipMemcpyDeviceToHost));
+    SWD_HIP(hipMemcpy(stats, d->stats.p, (size_t)B * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
+    if (min_pm) SWD_HIP(hipMemcpy(min_pm, d->pm.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,

@@ -26,6 +26,12 @@ struct SwdBp4Args {
     uint8_t *osd0;           // nullable [B][2][n]
     int32_t *stats;          // [B][SWD_STAT_WORDS]
     double *lpr;             // [B][3][n] posterior LLRs (x, y, z); also the OSD ordering input
+    // camel_decode (bp4_osd.pyx:223-247): 4 workgroups per shot, workgroup 4b+v fixes the last qubit to Pauli v
+    // (0 I, 1 X, 2 Z, 3 Y) and runs plain BP4; out/osd0 are unused, lpr is [4B][3][n] scratch
+    int32_t camel;
+    uint8_t *camel_dec;      // [4B][2][n] decisions of every run
+    double *camel_pm;        // [4B] cal_pm of the converged runs
+    int32_t *camel_st;       // [4B][2] converged, iterations
 };
 
 namespace swd {
@@ -80,7 +86,8 @@ template <int NT, int DM>
 __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SwdGraphDev &gx = a.gx, &gz = a.gz;
-    const int tid = threadIdx.x, b = blockIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
+    const int tid = threadIdx.x, unit = blockIdx.x, b = a.camel ? unit >> 2 : unit, n = gx.n, mx = gx.m, mz = gz.m;
+    const int fixed = a.camel ? n - 1 : -1; // the decided qubit of a camel run
     double *msgx = (double *)smem, *msgz = (double *)(smem + a.L.off_msgz);
     uint16_t *jpx = (uint16_t *)(smem + a.L.off_jptrx), *jpz = (uint16_t *)(smem + a.L.off_jptrz);
     int8_t *cnx = (int8_t *)(smem + a.L.off_cnx), *cnz = (int8_t *)(smem + a.L.off_cnz);
@@ -92,7 +99,7 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
     s.flags = (int *)(smem + a.L.off_misc); s.scal = s.flags + 32; s.dbl = (double *)(s.scal + 32); s.iaux = (int *)(s.dbl + 24);
     s.fpar = 0; s.ctid = s.vtid = threadIdx.x;
     const uint8_t *sx_b = a.sx + (int64_t)b * mx, *sz_b = a.sz + (int64_t)b * mz;
-    double *lpr_b = a.lpr + (int64_t)b * 3 * n;
+    double *lpr_b = a.lpr + (int64_t)unit * 3 * n;
 
     // reset + bp_init (bp4_osd.pyx:371-386, 425-442)
     for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
@@ -111,6 +118,13 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         for (int k = 0; k < dz; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
     }
     __syncthreads();
+    if (a.camel) { // vn_set_value(n - 1, value) after bp_init (bp4_osd.pyx:234-236, 388-423): the qubit keeps its prior messages
+        const int value = unit & 3, x = value & 1, z = value >> 1;
+        if (tid == 0) { decx[fixed] = (uint8_t)x; decz[fixed] = (uint8_t)z; }
+        if (z) for (int k = tid; k < gx.col_deg[fixed]; k += NT) cnx[swd_edge_lane(gx.vn_edge[k * n + fixed])] ^= 1;
+        if (x) for (int k = tid; k < gz.col_deg[fixed]; k += NT) cnz[swd_edge_lane(gz.vn_edge[k * n + fixed])] ^= 1;
+        __syncthreads();
+    }
 
     // bp4_decode_llr (bp4_osd.pyx:444-481)
     int conv = 0, iters = 0;
@@ -121,6 +135,15 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         const bool any = block_any<NT>(unsat, s);
         if (it > 0 && !any) { conv = 1; iters = it; break; }
         for (int v = tid; v < n; v += NT) { // vn_update (bp4_osd.pyx:533-589)
+            if (v == fixed) { // decided (bp4_osd.pyx:456-458): its bit-to-check messages stay the priors of bp_init; the
+                              // CN pass has just overwritten the shared slots with check-to-bit values, so put them back
+                const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
+                const double m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
+                const double m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz);
+                for (int k = 0; k < gx.col_deg[v]; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
+                for (int k = 0; k < gz.col_deg[v]; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
+                continue;
+            }
             const int dx = gx.col_deg[v], dz = gz.col_deg[v];
             uint32_t ex[DM], ez[DM];
             double cx[DM], cz[DM];
@@ -176,6 +199,22 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         iters = a.max_iter;
         conv = any ? 0 : 1;
     }
+    if (a.camel) {
+        uint8_t *dst = a.camel_dec + (int64_t)unit * 2 * n;
+        for (int v = tid; v < n; v += NT) { dst[v] = decx[v]; dst[n + v] = decz[v]; }
+        if (tid == 0) {
+            double pm = 0.0; // cal_pm (bp4_osd.pyx:249-258), summed in qubit order
+            if (conv)
+                for (int v = 0; v < n; ++v) {
+                    if (decx[v] && decz[v]) pm += a.llr_y[v];
+                    else if (decx[v]) pm += a.llr_x[v];
+                    else if (decz[v]) pm += a.llr_z[v];
+                }
+            a.camel_pm[unit] = pm;
+            a.camel_st[2 * unit] = conv; a.camel_st[2 * unit + 1] = iters;
+        }
+        return;
+    }
     uint8_t *out_b = a.out + (int64_t)b * 2 * n;
     int exit_class = SWD_EXIT_PRE, rowadds = 0;
     if (conv || a.osd_order < 0) {
@@ -218,6 +257,28 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         int32_t *st = a.stats + (int64_t)b * SWD_STAT_WORDS;
         st[0] = exit_class | (conv ? SWD_STATUS_CONVERGE : 0);
         st[1] = iters; st[2] = iters; st[3] = 0; st[4] = n; st[5] = mx + mz; st[6] = gx.E + gz.E; st[7] = rowadds;
+    }
+}
+
+// camel_decode's choice among the four runs of a shot: the converged run of smallest path metric, strict < keeps
+// the earliest (bp4_osd.pyx:237-243); converge = min_pm < 9999 (:244-245); bp_iteration = that of the last run.
+// A shot without a converged run returns the zero vectors of a new reference object.
+__global__ void __launch_bounds__(256) bp4_camel_select(int n, const uint8_t *dec, const double *pm, const int32_t *st,
+                                                        uint8_t *out, int32_t *stats, double *min_pm) {
+    const int b = blockIdx.x;
+    double best = 10000.0;
+    int arg = -1;
+    for (int v = 0; v < 4; ++v)
+        if (st[2 * (4 * b + v)] && pm[4 * b + v] < best) { best = pm[4 * b + v]; arg = v; }
+    uint8_t *o = out + (int64_t)b * 2 * n;
+    const uint8_t *src = dec + (int64_t)(4 * b + (arg < 0 ? 0 : arg)) * 2 * n;
+    for (int i = threadIdx.x; i < 2 * n; i += 256) o[i] = arg < 0 ? (uint8_t)0 : src[i];
+    if (threadIdx.x == 0) {
+        int32_t *s = stats + (int64_t)b * SWD_STAT_WORDS;
+        const int it = st[2 * (4 * b + 3) + 1];
+        s[0] = SWD_EXIT_PRE | (best < 9999.0 ? SWD_STATUS_CONVERGE : 0);
+        s[1] = it; s[2] = it; s[3] = 0; s[4] = n; s[5] = arg; s[6] = 0; s[7] = 0;
+        if (min_pm) min_pm[b] = best;
     }
 }
 

@@ -381,8 +381,40 @@ class bp4_osd:
             self._osd0 = self.last_osd0[0].astype(np.int64)
         return self._out.copy()
 
+    def camel_decode_batch(self, synd_x, synd_z):
+        """camel_decode (bp4_osd.pyx:223-247) for a batch: uint8 [B, 2, n]; ``last_status`` / ``last_iterations`` /
+        ``last_min_pm`` per shot.  Every shot sees a newly built object: zero vectors when no run converges."""
+        sx, sz = np.asarray(synd_x), np.asarray(synd_z)
+        if sx.ndim != 2 or sx.shape[1] != self.mx or sz.ndim != 2 or sz.shape[1] != self.mz or sx.shape[0] != sz.shape[0]:
+            raise ValueError(f"syndromes must have shapes [B, {self.mx}] and [B, {self.mz}]")
+        sx = np.ascontiguousarray((sx.astype(np.int64) & 0xFF).astype(np.uint8))
+        sz = np.ascontiguousarray((sz.astype(np.int64) & 0xFF).astype(np.uint8))
+        B = sx.shape[0]
+        out = np.zeros((B, 2, self.n), np.uint8)
+        st = np.zeros((B, _lib.STAT_WORDS), np.int32)
+        pm = np.full(B, 10000.0)
+        rc = _lib.lib().swd_bp4_camel_decode_batch(self._h, B, sx.ctypes.data, sz.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                                   pm.ctypes.data)
+        if rc:
+            raise RuntimeError(f"swd_bp4_camel_decode_batch failed: {_lib.last_error()}")
+        self.last_stats, self.last_status, self.last_iterations, self.last_min_pm = st, st[:, 0].copy(), st[:, 1].copy(), pm
+        return out
+
+    def camel_decode(self, input_vector_x, input_vector_z):
+        """Same call as the reference's ``camel_decode``; the returned (2, n) array is also what
+        ``osd0_decoding_x`` / ``osd0_decoding_z`` hold afterwards."""
+        sx, sz = np.asarray(input_vector_x), np.asarray(input_vector_z)
+        if sx.shape[0] != self.mx or sz.shape[0] != self.mz:
+            raise ValueError(f"The input to the bp4_osd.decode must be a syndrome (of length={self.mx}).")
+        out = self.camel_decode_batch(sx[None, :], sz[None, :])
+        self._last = dict(status=int(self.last_status[0]), iters=int(self.last_iterations[0]))
+        self._min_pm = float(self.last_min_pm[0])
+        self._osd0 = out[0].astype(np.int64)
+        return self._osd0.copy()
+
     converge = property(lambda self: 1 if (self._last["status"] & STATUS_CONVERGE) else 0)
     bp_iteration = property(lambda self: self._last["iters"])
+    min_pm = property(lambda self: getattr(self, "_min_pm", 0.0))
     osd0_decoding_x = property(lambda self: self._osd0[0].copy())
     osd0_decoding_z = property(lambda self: self._osd0[1].copy())
 

@@ -73,6 +73,20 @@ while done < trials:
             llr_bad += 1
             a, r = dev.last_llr[b].T, ora.log_prob_ratios
             worst = max(worst, float(np.max(np.abs(a - r) / (np.abs(r) + 1e-3))))
+    # camel_decode (bp4_osd.pyx:223-247) on the first shots, oracle state fresh per shot like the device's
+    cam = dev.camel_decode_batch(sx[:24], sz[:24])
+    cdiff = 0
+    for b in range(24):
+        o = O.bp4_osd(Hx, Hz, **kw)
+        w = o.camel_decode(sx[b], sz[b])
+        okc = np.array_equal(w, cam[b]) and bool(o.converge) == bool(dev.last_status[b] & 0x100)
+        if okc and o.converge:
+            okc = abs(o.min_pm - dev.last_min_pm[b]) <= 1e-9 * abs(o.min_pm)
+        cdiff += not okc
+    if cdiff > 1:
+        bad += 1
+        print(f"trial {done}: camel_decode MISMATCH n={n} mx={mx} mz={mz} differing shots {cdiff}/24 kw={ {k: v for k, v in kw.items() if not k.startswith('channel')} }")
+        continue
     if diff > 0.02 * B or llr_bad:
         bad += 1
         print(f"trial {done}: MISMATCH n={n} mx={mx} mz={mz} differing shots {diff}/{B} llr {llr_bad} worst rel {worst:.2e} kw={ {k: v for k, v in kw.items() if not k.startswith('channel')} }")

@@ -359,10 +359,42 @@ def gen_bp4(ref):
     save("bp4_depolarizing.npz", **arrs)
 
 
+def gen_bp4_camel(ref):
+    """bp4_osd.camel_decode (src/bp4_osd.pyx:223-247, used by Misc.ipynb): one reference object per case, calls in
+    sequence (the returned vectors persist in the object when no run converges)."""
+    from slidingwindowdecoder_amd.codes import bb_code
+    arrs = {}
+    sets = [("bb72", 72, 0.06, dict(max_iter=32, ms_scaling_factor=0.625, osd_method="osd_0", osd_order=0), 200),
+            ("bb144", 144, 0.08, dict(max_iter=50, ms_scaling_factor=0.8, osd_method="osd_0", osd_order=0), 150)]
+    for tag, N, p, kw, shots in sets:
+        code, _, _ = bb_code(N)
+        n = code.N
+        rng = np.random.default_rng(7 * N + 1)
+        px, py, pz = (p / 3 * rng.uniform(0.5, 1.5, n) for _ in range(3))  # unequal priors: distinct path metrics
+        dec = ref.bp4_osd(code.hx.astype(int), code.hz.astype(int), channel_probs_x=px, channel_probs_y=py,
+                          channel_probs_z=pz, **kw)
+        sxs, szs, outs, conv, its, pms = [], [], [], [], [], []
+        for _ in range(shots):
+            noise = rng.uniform(0, 1, n)
+            err_z = np.logical_and(noise > px, noise < px + py + pz)
+            err_x = noise < px + py
+            sx = (err_z @ code.hx.T) % 2
+            sz = (err_x @ code.hz.T) % 2
+            out = dec.camel_decode(sx, sz)
+            sxs.append(sx); szs.append(sz); outs.append(np.asarray(out, np.uint8))
+            conv.append(int(dec.converge)); its.append(int(dec.bp_iteration)); pms.append(float(dec.min_pm))
+        arrs.update({tag + "_N": np.int32(N), tag + "_params": json.dumps(kw), tag + "_px": px, tag + "_py": py, tag + "_pz": pz,
+                     tag + "_sx": pack(np.array(sxs)), tag + "_sz": pack(np.array(szs)), tag + "_out": pack(np.array(outs)),
+                     tag + "_converge": np.array(conv, np.uint8), tag + "_bp_iteration": np.array(its, np.int32),
+                     tag + "_min_pm": np.array(pms, np.float64)})
+        print(f"  bp4_camel/{tag}: converge {sum(conv)}/{shots}")
+    save("bp4_camel.npz", **arrs)
+
+
 def main():
     ensure_reference()
     import src as ref
-    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4"]
+    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4", "camel"]
     if "bb72" in which:
         gen_bb72(ref)
     if "bb144" in which:
@@ -373,6 +405,8 @@ def main():
         gen_kat288(ref)
     if "bp4" in which:
         gen_bp4(ref)
+    if "camel" in which:
+        gen_bp4_camel(ref)
 
 
 if __name__ == "__main__":

@@ -57,3 +57,29 @@ def test_fuzz_random_codes_vs_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_bp4.py"), "30", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("tag", ["bb72", "bb144"])
+def test_bp4_camel_decode_matches_reference(tag):
+    """camel_decode (bp4_osd.pyx:223-247) against the reference's recorded run.  A shot without a converged run
+    returns what a new reference object returns (zeros); the recorded object returns its previous vectors there."""
+    from slidingwindowdecoder_amd import bp4_osd
+    from tests.test_oracle_bp4 import load_camel
+    c = load_camel(tag)
+    dec = bp4_osd(c["code"].hx, c["code"].hz, channel_probs_x=c["px"], channel_probs_y=c["py"], channel_probs_z=c["pz"], **c["kw"])
+    out = dec.camel_decode_batch(c["sx"], c["sz"])
+    conv = (dec.last_status & 0x100) != 0
+    want = c["converge"] != 0
+    assert (conv == want).mean() >= 0.99
+    ok = conv & want
+    same = (out == c["out"]).all(axis=(1, 2))
+    assert same[ok].mean() >= 0.99, f"{(~same[ok]).sum()} of {ok.sum()} converged shots differ"
+    good = ok & same
+    np.testing.assert_allclose(dec.last_min_pm[good], c["min_pm"][good], rtol=1e-12)
+    assert np.array_equal(dec.last_iterations[good], c["its"][good])
+    assert not out[~conv].any() and (dec.last_min_pm[~conv] == 10000.0).all()
+    # single-call surface
+    k = int(np.flatnonzero(good)[0])
+    one = dec.camel_decode(c["sx"][k], c["sz"][k])
+    assert one.dtype == np.int64 and (one == c["out"][k]).all() and dec.converge == 1 and dec.min_pm == dec.last_min_pm[0]
+    assert (np.stack([dec.osd0_decoding_x, dec.osd0_decoding_z]) == one).all()
