@@ -150,11 +150,12 @@ void swd_bp4_destroy(swd_bp4 *d);
 int swd_bp4_info(const swd_bp4 *d, int32_t *mx, int32_t *mz, int32_t *n, int32_t *rank_x, int32_t *rank_z);
 /* sx [B*mx], sz [B*mz] -> out [B*2*n] (row 0: X string, row 1: Z string, like the (2, n) array decode()
  * returns); stats [B*SWD_STAT_WORDS] ([0] exit|converge, [1] bp_iteration); lpr [B*3*n] nullable posterior
- * LLRs laid out [shot][x|y|z][vn] (property log_prob_ratios transposed); osd0 [B*2*n] nullable. */
+ * LLRs laid out [shot][x|y|z][vn] (property log_prob_ratios transposed); osd0 [B*2*n] nullable;
+ * bp_dec [B*2*n] nullable: BP hard decisions at exit (properties bp_decoding_x / bp_decoding_z). */
 int swd_bp4_decode_batch(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
-                         int32_t *stats, double *lpr, uint8_t *osd0);
+                         int32_t *stats, double *lpr, uint8_t *osd0, uint8_t *bp_dec);
 int swd_bp4_decode_batch_dev(swd_bp4 *d, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
-                             int32_t *stats, double *lpr, uint8_t *osd0, void *stream);
+                             int32_t *stats, double *lpr, uint8_t *osd0, uint8_t *bp_dec, void *stream);
 /* bp4_osd.camel_decode (/root/reference/src/bp4_osd.pyx:223-247, called by Misc.ipynb): the last qubit is fixed to
  * I, X, Z, Y in turn, plain BP4 decodes the rest, the converged run of smallest path metric wins (ties: the
  * earliest).  out [B*2*n]; stats [B*SWD_STAT_WORDS] ([0] converge flag, [1] bp_iteration of the last run,

@@ -300,5 +300,14 @@ class bp4_osd:
     bp_iteration = property(lambda self: self._res.bp_iteration)
     min_pm = property(lambda self: self._res.min_pm)
     log_prob_ratios = property(lambda self: self._lpr.copy())
+    def _bpdec(self, z):
+        L = lib()
+        L.swo_bp4_bp_decoding.restype = C.c_void_p
+        L.swo_bp4_bp_decoding.argtypes = [C.c_void_p, C.c_int]
+        p = L.swo_bp4_bp_decoding(self._h, z)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int8)), (self.n,)).astype(np.int64)
+
+    bp_decoding_x = property(lambda self: self._bpdec(0))
+    bp_decoding_z = property(lambda self: self._bpdec(1))
     osd0_decoding_x = property(lambda self: self._o0x.astype(np.int64))
     osd0_decoding_z = property(lambda self: self._o0z.astype(np.int64))

@@ -973,6 +973,7 @@ struct swo_bp4 {
 };
 
 int swo_bp4_ranks(const swo_bp4 *d, int32_t *rx, int32_t *rz) { *rx = d->rank_x; *rz = d->rank_z; return 0; }
+const signed char *swo_bp4_bp_decoding(const swo_bp4 *d, int z) { return z ? d->dec_z : d->dec_x; }
 
 swo_bp4 *swo_bp4_create(int mx, int mz, int n, const int32_t *rpx, const int32_t *cix, const int32_t *rpz,
                         const int32_t *ciz, const double *px, const double *py, const double *pz,

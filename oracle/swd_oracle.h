@@ -118,6 +118,7 @@ int swo_bp4_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *ou
                    swo_result *res, double *lpr, uint8_t *osd0_x, uint8_t *osd0_z);
 /* bp4_osd.camel_decode (src/bp4_osd.pyx:223-247); res->min_pm = the object's min_pm afterwards */
 int swo_bp4_camel_decode(swo_bp4 *d, const uint8_t *sx, const uint8_t *sz, uint8_t *out_x, uint8_t *out_z, swo_result *res);
+const signed char *swo_bp4_bp_decoding(const swo_bp4 *d, int z); /* bp_decoding_x / bp_decoding_z after the last call */
 int swo_bp4_ranks(const swo_bp4 *d, int32_t *rank_x, int32_t *rank_z);
 
 #ifdef __cplusplus

@@ -63,8 +63,8 @@ SYMBOLS = [
     ("swd_bp4_create", _vp, [C.POINTER(GraphDesc), C.POINTER(GraphDesc), _vp, _vp, _vp, C.POINTER(Bp4Params), C.c_int]),
     ("swd_bp4_destroy", None, [_vp]),
     ("swd_bp4_info", C.c_int, [_vp] + [C.POINTER(_i32)] * 5),
-    ("swd_bp4_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("swd_bp4_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("swd_bp4_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("swd_bp4_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("swd_bp4_camel_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("swd_bp4_camel_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("swd_pipeline_create_gdg", _vp, [_i32, _vp, C.POINTER(GraphDesc), C.POINTER(GdgParams), C.c_int]),

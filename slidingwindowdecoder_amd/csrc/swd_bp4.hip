@@ -15,7 +15,7 @@ struct Bp4 {
     int device = 0, nt = 256, dm = 4, n = 0;
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
-    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm;
+    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd;
     const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
 };
 
@@ -123,7 +123,7 @@ extern "C" int swd_bp4_info(const swd_bp4 *h, int32_t *mx, int32_t *mz, int32_t 
 }
 
 extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
-                                        int32_t *stats, double *lpr, uint8_t *osd0, void *stream) {
+                                        int32_t *stats, double *lpr, uint8_t *osd0, uint8_t *bp_dec, void *stream) {
     Bp4 *d = (Bp4 *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
@@ -137,7 +137,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     a.gx = d->gx.d; a.gz = d->gz.d; a.Lx = d->Lx; a.Lz = d->Lz; a.L = d->L;
     a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
-    a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.stats = stats; a.lpr = lpr;
+    a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.bp_dec = bp_dec; a.stats = stats; a.lpr = lpr;
     hipStream_t st = (hipStream_t)stream;
     if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : bp4_launch<256, 8>(d, a, st);
     return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : bp4_launch<1024, 8>(d, a, st);
@@ -193,25 +193,26 @@ extern "C" int swd_bp4_camel_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *
 }
 
 extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
-                                    int32_t *stats, double *lpr, uint8_t *osd0) {
+                                    int32_t *stats, double *lpr, uint8_t *osd0, uint8_t *bp_dec) {
     Bp4 *d = (Bp4 *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
     SWD_HIP(hipSetDevice(d->device));
     const size_t n = d->n, mx = d->gx.m, mz = d->gz.m;
     if (d->sx.reserve(B * mx) || d->sz.reserve(B * mz) || d->out.reserve(B * 2 * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
-        d->lpr.reserve((size_t)B * 3 * n * 8) || d->osd0.reserve(B * 2 * n))
+        d->lpr.reserve((size_t)B * 3 * n * 8) || d->osd0.reserve(B * 2 * n) || (bp_dec && d->bpd.reserve(B * 2 * n)))
         return -1;
     SWD_HIP(hipMemcpy(d->sx.p, sx, B * mx, hipMemcpyHostToDevice));
     SWD_HIP(hipMemcpy(d->sz.p, sz, B * mz, hipMemcpyHostToDevice));
     SWD_HIP(hipMemset(d->osd0.p, 0, B * 2 * n));
     int rc = swd_bp4_decode_batch_dev(h, B, d->sx.as<uint8_t>(), d->sz.as<uint8_t>(), d->out.as<uint8_t>(), d->stats.as<int32_t>(),
-                                      d->lpr.as<double>(), d->osd0.as<uint8_t>(), nullptr);
+                                      d->lpr.as<double>(), d->osd0.as<uint8_t>(), bp_dec ? d->bpd.as<uint8_t>() : nullptr, nullptr);
     if (rc) return rc;
     SWD_HIP(hipDeviceSynchronize());
     SWD_HIP(hipMemcpy(out, d->out.p, B * 2 * n, hipMemcpyDeviceToHost));
     SWD_HIP(hipMemcpy(stats, d->stats.p, (size_t)B * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
     if (lpr) SWD_HIP(hipMemcpy(lpr, d->lpr.p, (size_t)B * 3 * n * 8, hipMemcpyDeviceToHost));
     if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * 2 * n, hipMemcpyDeviceToHost));
+    if (bp_dec) SWD_HIP(hipMemcpy(bp_dec, d->bpd.p, B * 2 * n, hipMemcpyDeviceToHost));
     return 0;
 }

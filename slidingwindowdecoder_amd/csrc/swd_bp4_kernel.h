@@ -24,6 +24,7 @@ struct SwdBp4Args {
     const uint8_t *sx, *sz;  // [B][mx], [B][mz]
     uint8_t *out;            // [B][2][n]  rows: X string, Z string
     uint8_t *osd0;           // nullable [B][2][n]
+    uint8_t *bp_dec;         // nullable [B][2][n] BP hard decisions at exit
     int32_t *stats;          // [B][SWD_STAT_WORDS]
     double *lpr;             // [B][3][n] posterior LLRs (x, y, z); also the OSD ordering input
     // camel_decode (bp4_osd.pyx:223-247): 4 workgroups per shot, workgroup 4b+v fixes the last qubit to Pauli v
@@ -216,6 +217,8 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         return;
     }
     uint8_t *out_b = a.out + (int64_t)b * 2 * n;
+    if (a.bp_dec)
+        for (int v = tid; v < n; v += NT) { a.bp_dec[(int64_t)b * 2 * n + v] = decx[v]; a.bp_dec[(int64_t)b * 2 * n + n + v] = decz[v]; }
     int exit_class = SWD_EXIT_PRE, rowadds = 0;
     if (conv || a.osd_order < 0) {
         for (int v = tid; v < n; v += NT) { out_b[v] = decx[v]; out_b[n + v] = decz[v]; }

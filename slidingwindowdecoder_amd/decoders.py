@@ -361,12 +361,13 @@ class bp4_osd:
         st = np.zeros((B, _lib.STAT_WORDS), np.int32)
         lpr = np.zeros((B, 3, self.n))
         osd0 = np.zeros((B, 2, self.n), np.uint8)
+        bpd = np.zeros((B, 2, self.n), np.uint8)
         rc = _lib.lib().swd_bp4_decode_batch(self._h, B, sx.ctypes.data, sz.ctypes.data, out.ctypes.data, st.ctypes.data,
-                                             lpr.ctypes.data, osd0.ctypes.data)
+                                             lpr.ctypes.data, osd0.ctypes.data, bpd.ctypes.data)
         if rc:
             raise RuntimeError(f"swd_bp4_decode_batch failed: {_lib.last_error()}")
         self.last_stats, self.last_status, self.last_iterations = st, st[:, 0].copy(), st[:, 1].copy()
-        self.last_llr, self.last_osd0 = lpr, osd0
+        self.last_llr, self.last_osd0, self.last_bp_decoding = lpr, osd0, bpd
         return out
 
     def decode(self, input_vector_x, input_vector_z):
@@ -377,8 +378,11 @@ class bp4_osd:
         self._last = dict(status=int(self.last_status[0]), iters=int(self.last_iterations[0]))
         self._lpr = self.last_llr[0]
         self._out = out[0].astype(np.int64)
+        self._bp = self.last_bp_decoding[0].astype(np.int64)
         if (self._last["status"] & 0xFF) in (EXIT_PRE, EXIT_OSD):
             self._osd0 = self.last_osd0[0].astype(np.int64)
+        if (self._last["status"] & 0xFF) == EXIT_OSD:  # osdw_decoding_* only change when the OSD ran (bp4_osd.pyx:217-219)
+            self._osdw = self._out.copy()
         return self._out.copy()
 
     def camel_decode_batch(self, synd_x, synd_z):
@@ -415,6 +419,10 @@ class bp4_osd:
     converge = property(lambda self: 1 if (self._last["status"] & STATUS_CONVERGE) else 0)
     bp_iteration = property(lambda self: self._last["iters"])
     min_pm = property(lambda self: getattr(self, "_min_pm", 0.0))
+    bp_decoding_x = property(lambda self: getattr(self, "_bp", np.zeros((2, self.n), np.int64))[0].copy())
+    bp_decoding_z = property(lambda self: getattr(self, "_bp", np.zeros((2, self.n), np.int64))[1].copy())
+    osdw_decoding_x = property(lambda self: getattr(self, "_osdw", np.zeros((2, self.n), np.int64))[0].copy())
+    osdw_decoding_z = property(lambda self: getattr(self, "_osdw", np.zeros((2, self.n), np.int64))[1].copy())
     osd0_decoding_x = property(lambda self: self._osd0[0].copy())
     osd0_decoding_z = property(lambda self: self._osd0[1].copy())
 

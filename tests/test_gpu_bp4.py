@@ -43,6 +43,14 @@ def test_bp4_single_decode_surface():
         # the returned correction reproduces both syndromes
         assert not ((c["code"].hx.astype(int) @ out[1] + c["sx"][k]) % 2).any()
         assert not ((c["code"].hz.astype(int) @ out[0] + c["sz"][k]) % 2).any()
+    # bp_decoding_x/z and osdw_decoding_x/z (bp4_osd.pyx:606-620) on a shot where the OSD ran, vs the oracle
+    from oracle import oracle as O
+    ora = O.bp4_osd(c["code"].hx, c["code"].hz, channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"], **c["kw"])
+    k = int(np.flatnonzero(c["converge"] == 0)[0])
+    out, want = dec.decode(c["sx"][k], c["sz"][k]), ora.decode(c["sx"][k], c["sz"][k])
+    assert (out == want).all() and dec.converge == 0
+    assert (dec.bp_decoding_x == ora.bp_decoding_x).all() and (dec.bp_decoding_z == ora.bp_decoding_z).all()
+    assert (dec.osdw_decoding_x == out[0]).all() and (dec.osdw_decoding_z == out[1]).all()
     with pytest.raises(ValueError):
         dec.decode(np.zeros(5), np.zeros(36))
     with pytest.raises(ValueError):
