@@ -21,7 +21,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 out = {}
-for f in glob.glob(os.path.join(src, "prof_stats", "*kernel_stats.csv")):
+for f in glob.glob(os.path.join(src, "prof_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     for row in csv.DictReader(open(f)):
         if "pipeline_kernel" in row["Name"]:
@@ -33,7 +33,7 @@ for f in glob.glob(os.path.join(src, "prof_stats", "*kernel_stats.csv")):
 
 for name, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
     vals, meta = [], {}
-    for f in glob.glob(os.path.join(src, d, "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if "pipeline_kernel" in row["Kernel_Name"] and row["Counter_Name"] == name:
                 vals.append(float(row["Counter_Value"]))
