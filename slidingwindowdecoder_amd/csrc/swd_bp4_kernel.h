@@ -66,8 +66,11 @@ __device__ __forceinline__ bool bp4_cn_pass(const SwdGraphDev &g, double *msg, c
         uint64_t negm = 0;
         for (int k = 0; k < deg; ++k) {
             double x = msg[jptr[k] + l];
-            x = fmin(fmax(x, -50.0), 50.0);
-            const double ax = fabs(x);
+            // the reference clips and compares with plain < and > (bp4_osd.pyx:503-509): a NaN message (inf - inf
+            // in vn_update when a qubit collects +-1e308 sentinels of degree-1 checks) passes the clip, never
+            // lowers the running minimum and counts as positive -- fmin/fmax would turn it into -50
+            x = (x > 50.0) ? 50.0 : ((x < -50.0) ? -50.0 : x);
+            const double ax = (x != x) ? 1e308 : fabs(x);
             arg = (ax < min1) ? k : arg;
             min2 = fmin(min2, fmax(min1, ax));
             min1 = fmin(min1, ax);
