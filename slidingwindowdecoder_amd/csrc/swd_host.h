@@ -42,6 +42,22 @@ struct DevBuf {
     template <class T> T *as() { return (T *)p; }
 };
 
+// Page-locked host staging area: one asynchronous copy in and one out per host-buffer call instead of a
+// synchronous pageable copy per array (a one-syndrome decode() spent most of its time in those).
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        SWD_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return 0;
+    }
+};
+
 // Host copy of the device graph arrays + the device allocation holding them.
 struct Graph {
     int m = 0, n = 0, E = 0, K = 0, D = 0, rank = 0, wm = 0;

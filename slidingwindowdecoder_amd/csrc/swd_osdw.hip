@@ -108,7 +108,8 @@ struct Plan {
     const uint16_t *d_rows = nullptr;
     // host-pointer staging
     DevBuf synd, out, stats, pm, hist, osd0, total;
-    DevBuf prof, sched, state;
+    DevBuf prof, sched, state, io;
+    PinnedBuf stage;
     bool profiling = false;
     bool timing = false;
     double t_total_ms = 0;
@@ -484,24 +485,33 @@ extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd
     if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
     const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
-    const size_t hbytes = (size_t)B * 4 * n * 8;
-    if (d->synd.reserve(B * m) || d->out.reserve(B * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
-        d->pm.reserve(B * 8) || d->hist.reserve(hbytes))
-        return -1;
-    if (osd0 && d->osd0.reserve(B * n)) return -1;
-    SWD_HIP(hipMemcpy(d->synd.p, synd, B * m, hipMemcpyHostToDevice));
-    if (hist && hist_is_state) SWD_HIP(hipMemcpy(d->hist.p, hist, hbytes, hipMemcpyHostToDevice));
-    if (osd0) SWD_HIP(hipMemset(d->osd0.p, 0, B * n));
-    int rc = swd_osdw_decode_batch_dev(h, B, d->synd.as<uint8_t>(), 0, d->out.as<uint8_t>(), 0, d->stats.as<int32_t>(),
-                                       d->pm.as<double>(), hist ? d->hist.as<double>() : nullptr,
-                                       (hist && hist_is_state) ? 1 : 0, osd0 ? d->osd0.as<uint8_t>() : nullptr, nullptr);
+    // one packed device buffer mirrored by a pinned host buffer: [ syndromes | history ] travel in,
+    // [ history | vectors | statistics | path metrics | OSD-0 vectors ] travel out, one copy each way
+    const bool hist_in = hist && hist_is_state;
+    const size_t hbytes = hist ? (size_t)B * 4 * n * 8 : 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_synd = 0, o_hist = al((size_t)B * m), o_out = o_hist + al(hbytes), o_stats = o_out + al((size_t)B * n),
+                 o_pm = o_stats + al((size_t)B * SWD_STAT_WORDS * 4), o_osd0 = o_pm + al((size_t)B * 8),
+                 total = o_osd0 + (osd0 ? al((size_t)B * n) : 0);
+    if (d->io.reserve(total) || d->stage.reserve(total)) return -1;
+    char *hs = (char *)d->stage.p, *ds = (char *)d->io.p;
+    memcpy(hs + o_synd, synd, (size_t)B * m);
+    if (hist_in) memcpy(hs + o_hist, hist, hbytes);
+    hipStream_t st = nullptr;
+    SWD_HIP(hipMemcpyAsync(ds, hs, hist_in ? o_hist + hbytes : (size_t)B * m, hipMemcpyHostToDevice, st));
+    if (osd0) SWD_HIP(hipMemsetAsync(ds + o_osd0, 0, (size_t)B * n, st));
+    int rc = swd_osdw_decode_batch_dev(h, B, (const uint8_t *)(ds + o_synd), 0, (uint8_t *)(ds + o_out), 0, (int32_t *)(ds + o_stats),
+                                       (double *)(ds + o_pm), hist ? (double *)(ds + o_hist) : nullptr, hist_in ? 1 : 0,
+                                       osd0 ? (uint8_t *)(ds + o_osd0) : nullptr, st);
     if (rc) return rc;
-    SWD_HIP(hipDeviceSynchronize());
-    SWD_HIP(hipMemcpy(out, d->out.p, B * n, hipMemcpyDeviceToHost));
-    SWD_HIP(hipMemcpy(stats, d->stats.p, (size_t)B * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
-    SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * 8, hipMemcpyDeviceToHost));
-    if (hist) SWD_HIP(hipMemcpy(hist, d->hist.p, hbytes, hipMemcpyDeviceToHost));
-    if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * n, hipMemcpyDeviceToHost));
+    const size_t first = hist ? o_hist : o_out;
+    SWD_HIP(hipMemcpyAsync(hs + first, ds + first, total - first, hipMemcpyDeviceToHost, st));
+    SWD_HIP(hipStreamSynchronize(st));
+    memcpy(out, hs + o_out, (size_t)B * n);
+    memcpy(stats, hs + o_stats, (size_t)B * SWD_STAT_WORDS * 4);
+    memcpy(min_pm, hs + o_pm, (size_t)B * 8);
+    if (hist) memcpy(hist, hs + o_hist, hbytes);
+    if (osd0) memcpy(osd0, hs + o_osd0, (size_t)B * n);
     return 0;
 }
 
