@@ -15,7 +15,8 @@ struct Bp4 {
     int device = 0, nt = 256, dm = 4, n = 0;
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
-    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd;
+    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd, io;
+    PinnedBuf stage;
     const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
 };
 
@@ -192,7 +193,8 @@ extern "C" int swd_bp4_camel_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *
     return 0;
 }
 
-extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+// large batches: one synchronous copy per array straight from / to the caller's buffers
+static int bp4_decode_batch_direct(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
                                     int32_t *stats, double *lpr, uint8_t *osd0, uint8_t *bp_dec) {
     Bp4 *d = (Bp4 *)h;
     if (!d) { set_error("null decoder"); return -1; }
@@ -214,5 +216,40 @@ extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, co
     if (lpr) SWD_HIP(hipMemcpy(lpr, d->lpr.p, (size_t)B * 3 * n * 8, hipMemcpyDeviceToHost));
     if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * 2 * n, hipMemcpyDeviceToHost));
     if (bp_dec) SWD_HIP(hipMemcpy(bp_dec, d->bpd.p, B * 2 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
+                                    int32_t *stats, double *lpr, uint8_t *osd0, uint8_t *bp_dec) {
+    Bp4 *d = (Bp4 *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (B <= 0) return 0;
+    if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    const size_t n = d->n, mx = d->gx.m, mz = d->gz.m;
+    // packed device buffer + pinned mirror: [ sx | sz ] in, [ out | stats | lpr | osd0 | bp_dec ] out, one copy each way
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_sx = 0, o_sz = al(B * mx), o_out = o_sz + al(B * mz), o_stats = o_out + al(B * 2 * n),
+                 o_lpr = o_stats + al((size_t)B * SWD_STAT_WORDS * 4), o_osd0 = o_lpr + al((size_t)B * 3 * n * 8),
+                 o_bpd = o_osd0 + al(B * 2 * n), total = o_bpd + al(B * 2 * n);
+    if (total > SWD_STAGE_MAX) return bp4_decode_batch_direct(h, B, sx, sz, out, stats, lpr, osd0, bp_dec); // large batches: copy time dominates, no second host copy
+    if (d->io.reserve(total) || d->stage.reserve(total)) return -1;
+    char *hs = (char *)d->stage.p, *ds = (char *)d->io.p;
+    memcpy(hs + o_sx, sx, B * mx);
+    memcpy(hs + o_sz, sz, B * mz);
+    hipStream_t st = nullptr;
+    SWD_HIP(hipMemcpyAsync(ds, hs, o_sz + B * mz, hipMemcpyHostToDevice, st));
+    SWD_HIP(hipMemsetAsync(ds + o_osd0, 0, B * 2 * n, st));
+    int rc = swd_bp4_decode_batch_dev(h, B, (const uint8_t *)(ds + o_sx), (const uint8_t *)(ds + o_sz), (uint8_t *)(ds + o_out),
+                                      (int32_t *)(ds + o_stats), (double *)(ds + o_lpr), (uint8_t *)(ds + o_osd0),
+                                      (uint8_t *)(ds + o_bpd), st);
+    if (rc) return rc;
+    SWD_HIP(hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, st));
+    SWD_HIP(hipStreamSynchronize(st));
+    memcpy(out, hs + o_out, B * 2 * n);
+    memcpy(stats, hs + o_stats, (size_t)B * SWD_STAT_WORDS * 4);
+    if (lpr) memcpy(lpr, hs + o_lpr, (size_t)B * 3 * n * 8);
+    if (osd0) memcpy(osd0, hs + o_osd0, B * 2 * n);
+    if (bp_dec) memcpy(bp_dec, hs + o_bpd, B * 2 * n);
     return 0;
 }

@@ -44,6 +44,7 @@ struct DevBuf {
 
 // Page-locked host staging area: one asynchronous copy in and one out per host-buffer call instead of a
 // synchronous pageable copy per array (a one-syndrome decode() spent most of its time in those).
+constexpr size_t SWD_STAGE_MAX = 4u << 20; // host-buffer calls moving more than this copy array by array instead
 struct PinnedBuf {
     void *p = nullptr;
     size_t cap = 0;

@@ -477,6 +477,36 @@ extern "C" int swd_osdw_decode_batch_dev(swd_osdw *h, int32_t B, const uint8_t *
     return launch(d, a, (hipStream_t)stream);
 }
 
+// large batches: one synchronous copy per array straight from / to the caller's buffers
+static int osdw_decode_batch_direct(swd_osdw *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
+                                     double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0) {
+    Plan *d = (Plan *)h;
+    if (!d) { set_error("null decoder"); return -1; }
+    if (B <= 0) return 0;
+    if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
+    const size_t hbytes = (size_t)B * 4 * n * 8;
+    if (d->synd.reserve(B * m) || d->out.reserve(B * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
+        d->pm.reserve(B * 8) || d->hist.reserve(hbytes))
+        return -1;
+    if (osd0 && d->osd0.reserve(B * n)) return -1;
+    SWD_HIP(hipMemcpy(d->synd.p, synd, B * m, hipMemcpyHostToDevice));
+    if (hist && hist_is_state) SWD_HIP(hipMemcpy(d->hist.p, hist, hbytes, hipMemcpyHostToDevice));
+    if (osd0) SWD_HIP(hipMemset(d->osd0.p, 0, B * n));
+    int rc = swd_osdw_decode_batch_dev(h, B, d->synd.as<uint8_t>(), 0, d->out.as<uint8_t>(), 0, d->stats.as<int32_t>(),
+                                       d->pm.as<double>(), hist ? d->hist.as<double>() : nullptr,
+                                       (hist && hist_is_state) ? 1 : 0, osd0 ? d->osd0.as<uint8_t>() : nullptr, nullptr);
+    if (rc) return rc;
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(out, d->out.p, B * n, hipMemcpyDeviceToHost));
+    SWD_HIP(hipMemcpy(stats, d->stats.p, (size_t)B * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
+    SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * 8, hipMemcpyDeviceToHost));
+    if (hist) SWD_HIP(hipMemcpy(hist, d->hist.p, hbytes, hipMemcpyDeviceToHost));
+    if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
                                      double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0) {
     Plan *d = (Plan *)h;
@@ -493,6 +523,7 @@ extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd
     const size_t o_synd = 0, o_hist = al((size_t)B * m), o_out = o_hist + al(hbytes), o_stats = o_out + al((size_t)B * n),
                  o_pm = o_stats + al((size_t)B * SWD_STAT_WORDS * 4), o_osd0 = o_pm + al((size_t)B * 8),
                  total = o_osd0 + (osd0 ? al((size_t)B * n) : 0);
+    if (total > SWD_STAGE_MAX) return osdw_decode_batch_direct(h, B, synd, out, stats, min_pm, hist, hist_is_state, osd0); // copy time dominates there
     if (d->io.reserve(total) || d->stage.reserve(total)) return -1;
     char *hs = (char *)d->stage.p, *ds = (char *)d->io.p;
     memcpy(hs + o_synd, synd, (size_t)B * m);
