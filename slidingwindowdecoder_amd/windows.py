@@ -104,12 +104,18 @@ def plan_windows(chk, obs, priors, n_half: int, W: int, F: int, method: int = 1,
             return (c[0], c[1] + (n_half * 3 if z_basis else n))
         return c
 
+    # osd.py:79-89: one merged prior PER ROW of the identity block (np.sum(..., axis=1)); the rows agree for
+    # the BB circuits (the reference prints element 0) but not e.g. for SHYPS.  A caller-given scalar is broadcast.
+    noisy_vec = None
     if noisy_prior is None and method != 0:
         b = anchors[W]
         c = shifted(anchors[W - 1])
         block = chk_r[c[0]:b[0], c[1]:b[1]]
-        noisy = np.asarray(block.multiply(priors[c[1]:b[1]]).sum(axis=1)).ravel()
-        noisy_prior = float(noisy[0])
+        noisy_vec = np.asarray(block.multiply(priors[c[1]:b[1]]).sum(axis=1)).ravel()
+        noisy_prior = float(noisy_vec[0])
+    elif method != 0:
+        noisy_vec = np.ones(n_half) * np.asarray(noisy_prior, dtype=np.float64)
+        noisy_prior = float(noisy_vec[0])
 
     num_win = math.ceil((len(anchors) - W + F - 1) / F)
     windows = []
@@ -126,7 +132,7 @@ def plan_windows(chk, obs, priors, n_half: int, W: int, F: int, method: int = 1,
                                    (np.arange(nrow - n_half, nrow), np.arange(n_half))),
                                   shape=(nrow, n_half))
             mat = sp.hstack((sub, ident), format="csr")
-            prior = np.concatenate((priors[a[1]:c[1]], np.full(n_half, noisy_prior)))
+            prior = np.concatenate((priors[a[1]:c[1]], noisy_vec))
             ncg = c[1] - a[1]
         else:
             mat = sp.csr_matrix(chk_r[a[0]:b[0], a[1]:b[1]])

@@ -96,3 +96,34 @@ def test_bb288_window_shapes():
     plan = plan_windows(dem.chk, dem.obs, dem.priors, 144, 4, 1, method=1)
     assert [w.mat.shape for w in plan.windows] == [(576, 4752), (576, 4896), (576, 4896), (576, 4752)]
     assert plan.windows[1].mat.nnz == 16992
+
+
+def test_merged_prior_is_per_row_like_the_reference():
+    """osd.py:79-89 sums the replaced faults' priors per row of the identity block: a vector.  Uniform for the BB
+    circuits, not in general; a caller-given scalar is broadcast."""
+    import scipy.sparse as sp
+    from slidingwindowdecoder_amd.windows import plan_windows
+    rng = np.random.default_rng(2)
+    h, R = 4, 4
+    cols = []
+    for r in range(R):          # per round: 3h local faults (one per detector, three times), then h faults into the next round
+        for rep in range(3):
+            for i in range(h):
+                cols.append([r * h + i])
+        if r < R - 1:
+            for i in range(h):
+                cols.append([r * h + i, (r + 1) * h + (i + 1) % h])
+    rows = np.concatenate(cols)
+    cidx = np.concatenate([[j] * len(c) for j, c in enumerate(cols)])
+    chk = sp.csr_matrix((np.ones(len(rows), np.uint8), (rows, cidx)), shape=(R * h, len(cols)))
+    priors = rng.uniform(0.001, 0.01, size=len(cols))
+    obs = sp.csr_matrix((1, len(cols)), dtype=np.uint8)
+    plan = plan_windows(chk, obs, priors, h, 2, 1, method=1)
+    w0 = plan.windows[0]
+    tail = w0.prior[-h:]
+    a1, b1 = plan.anchors[1], plan.anchors[2]
+    block = sp.csr_matrix(plan.chk)[a1[0]:b1[0], a1[1] + 3 * h:b1[1]]
+    want = np.asarray(block.multiply(plan.priors[a1[1] + 3 * h:b1[1]]).sum(axis=1)).ravel()
+    assert np.allclose(tail, want) and len(np.unique(np.round(tail, 12))) > 1
+    plan2 = plan_windows(chk, obs, priors, h, 2, 1, method=1, noisy_prior=0.02)
+    assert np.allclose(plan2.windows[0].prior[-h:], 0.02)
