@@ -801,7 +801,14 @@ __device__ __forceinline__ int osd0_block(const SwdGraphDev &g, Lds &s, const ui
     int *ctl = s.iaux + 8;
     uint64_t Pw = 0;                    // word w of the pivoted-row mask (replicated per column group), wave 0
     int npiv = 0, rowadds = 0, p = 0;
+#ifdef SWD_OSDPROF // diagnostic build: cycles of the pick (wave 0), the barrier waits and the row operation, per elimination
+    long long tp_ = 0, tb_ = 0, tu_ = 0, q0_, q1_, q2_, q3_;
+    int nsteps_ = 0;
+#endif
     for (;;) {
+#ifdef SWD_OSDPROF
+        q0_ = clock64();
+#endif
         if (tid < 64) {
             int found = 0;
             while (!found && p < n && npiv < rank) { // T only changes at a pivot: runs of dependent columns need no barrier
@@ -848,7 +855,13 @@ __device__ __forceinline__ int osd0_block(const SwdGraphDev &g, Lds &s, const ui
             }
             if (lane == 0) ctl[0] = found | ((p < n && npiv < rank) ? 0 : 2);
         }
+#ifdef SWD_OSDPROF
+        q1_ = clock64();
+#endif
         __syncthreads();
+#ifdef SWD_OSDPROF
+        q2_ = clock64();
+#endif
         const int c0 = ctl[0];
         if (c0 & 1) { // T[:, j] ^= S for every column j of T with T[r][j] = 1
             const int r = ctl[1];
@@ -861,6 +874,12 @@ __device__ __forceinline__ int osd0_block(const SwdGraphDev &g, Lds &s, const ui
             }
         }
         __syncthreads();
+#ifdef SWD_OSDPROF
+        q3_ = clock64();
+        tp_ += q1_ - q0_; tb_ += q2_ - q1_; tu_ += q3_ - q2_; ++nsteps_;
+        if ((c0 & 2) && (tid == 0 || tid == 512) && (blockIdx.x & 63) == 0)
+            printf("osdprof thread %d: eliminations %d  pick %lld  barrier wait %lld  row operation + barrier %lld cycles\n", tid, nsteps_, tp_, tb_, tu_);
+#endif
         if (c0 & 2) break;
     }
     if (tid < 64) {
