@@ -135,8 +135,13 @@ int swd_gdg_decode_batch_dev(swd_gdg *d, int32_t B, const uint8_t *synd, int64_t
 /* ---- quaternary BP + OSD -------------------------------------------------------------------
  * Replaces bp4_osd(Hx, Hz, channel_probs_x/y/z, max_iter, ms_scaling_factor, osd_method, osd_order)
  * (/root/reference/src/bp4_osd.pyx:8-140) and its decode(sx, sz) (bp4_osd.pyx:197-221).  The
- * variable-node update uses exp/log1p, so posterior LLRs agree with the reference to rounding of the
- * math library (not bit for bit); decisions are equal except on exact ties of those LLRs. */
+ * variable-node update uses exp/log1p; the device evaluates them with the algorithms of the C library the
+ * reference links (glibc >= 2.28: table-driven exp in its FMA build, fdlibm log1p -- csrc/swd_libm.h), so
+ * posterior LLRs, decisions and OSD orderings are bit-identical to a reference run on an FMA-capable x86-64.
+ * Restrictions (swd_bp4_create fails with a message): column weight of Hx / Hz <= 10; osd_order > 0 needs
+ * rank(Hx) == rank(Hz) -- the reference accepts unequal ranks there but then sizes the z-basis sweep with
+ * kz = n - rank_x (bp4_osd.pyx:103-104, :284), i.e. reads candidates that do not exist; that quirk is not
+ * reproduced. */
 typedef struct swd_bp4_params {
     int32_t max_iter;          /* default 32 */
     double ms_scaling_factor;

@@ -31,6 +31,11 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
     SWD_HIP(hipGetLastError());
     return 0;
 }
+
+static int bp4_dispatch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+    if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<256, 8>(d, a, st) : bp4_launch<256, SWD_DMAX>(d, a, st));
+    return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<1024, 8>(d, a, st) : bp4_launch<1024, SWD_DMAX>(d, a, st));
+}
 } // namespace swd
 
 using namespace swd;
@@ -64,8 +69,8 @@ extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_des
     }
     if (d->p.osd_method == 1 && d->p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); delete d; return nullptr; }
     const int D = std::max(d->gx.D, d->gz.D);
-    if (D > 8) { set_error("column weight %d exceeds this build's bound 8", D); delete d; return nullptr; }
-    d->dm = D <= 4 ? 4 : 8;
+    if (D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", D, SWD_DMAX); delete d; return nullptr; }
+    d->dm = D <= 4 ? 4 : (D <= 8 ? 8 : SWD_DMAX); // SHYPS stabiliser matrices reach column weight 9
     d->nt = n <= 3072 ? 256 : 1024;
     if (d->gx.upload() || d->gz.upload()) { delete d; return nullptr; }
     d->gx.d.new_n = n; d->gz.d.new_n = n;
@@ -140,8 +145,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
     a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.bp_dec = bp_dec; a.stats = stats; a.lpr = lpr;
     hipStream_t st = (hipStream_t)stream;
-    if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : bp4_launch<256, 8>(d, a, st);
-    return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : bp4_launch<1024, 8>(d, a, st);
+    return bp4_dispatch(d, a, st);
 }
 
 extern "C" int swd_bp4_camel_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
@@ -163,8 +167,7 @@ extern "C" int swd_bp4_camel_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8
     a.camel = 1; a.camel_dec = d->cdec.as<uint8_t>(); a.camel_pm = d->cpm.as<double>(); a.camel_st = d->cst.as<int32_t>();
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (d->nt == 256) rc = d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : bp4_launch<256, 8>(d, a, st);
-    else rc = d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : bp4_launch<1024, 8>(d, a, st);
+    rc = bp4_dispatch(d, a, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bp4_camel_select, dim3(B), dim3(256), 0, st, (int)n, a.camel_dec, a.camel_pm, a.camel_st, out, stats, min_pm);
     SWD_HIP(hipGetLastError());

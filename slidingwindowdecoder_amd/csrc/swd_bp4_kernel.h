@@ -2,10 +2,12 @@
 // (/root/reference/src/bp4_osd.pyx:197-221) for one pair of syndromes per workgroup.
 //   bp_init 425-442, bp4_decode_llr 444-481, cn_update_all 483-529, vn_update 533-589, osd 261-368,
 //   log1pexp / logaddexp  /root/reference/src/include/bpgd.cpp:399-416.
-// Messages of both Tanner graphs (Hx and Hz share the variable nodes) live in LDS; the variable-node
-// update needs exp/log1p, so unlike the binary decoders its results depend on the math library:
-// parity is asserted on the posterior LLRs with a tolerance and on the decisions.
+// Messages of both Tanner graphs (Hx and Hz share the variable nodes) live in LDS.  The variable-node update
+// needs exp / log1p: they are evaluated with the algorithms of the C library the reference links against
+// (swd_libm.h: glibc's table-driven exp in its FMA build, fdlibm's log1p), so posteriors, decisions and OSD
+// orderings are bit-identical to a reference run on such a host, not merely "equal up to the math library".
 #pragma once
+#include "swd_libm.h"
 #include "swd_osdw_kernel.h"
 
 struct SwdBp4Layout {
@@ -38,8 +40,8 @@ struct SwdBp4Args {
 namespace swd {
 
 __device__ __forceinline__ double bp4_log1pexp(double x) {
-    if (x > 36.04365338911715) return x + log1p(exp(-x)); // -log(DBL_EPSILON)
-    return log1p(exp(x));
+    if (x > 36.04365338911715) return x + swd_log1p(swd_exp(-x)); // -log(DBL_EPSILON)
+    return swd_log1p(swd_exp(x));
 }
 __device__ __forceinline__ double bp4_logaddexp(double x, double y) {
     const double tmp = x - y;

@@ -59,6 +59,14 @@ def simplex_matrices(r: int):
     return H, G
 
 
+def shyps_stabilizers(r: int):
+    """(S_X, S_Z) of the subsystem hypergraph-product simplex code: S_X = H^T (x) G, S_Z = G (x) H^T
+    (build_SHYPS_circuit.py:37-45), both (n_r r) x n_r^2 -- the check matrices `bp4_osd(S_X, S_Z, ...)` takes for
+    code-capacity decoding (r = 3: 21 x 49, row weight 12, column weight <= 9, rank 12 each)."""
+    H, G = simplex_matrices(r)
+    return (np.kron(H.T, G) % 2).astype(np.uint8), (np.kron(G, H.T) % 2).astype(np.uint8)
+
+
 def maximum_matching(adj: dict[int, list[int]], left: list[int]) -> dict[int, int]:
     """Hopcroft-Karp maximum matching of a bipartite graph given as left -> ordered neighbour lists.
     Free left vertices are taken in `left` order and neighbours in list order, which fixes the matching

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised bp4_osd device-vs-oracle comparison (run by hand or from the GPU suite):
     python tests/fuzz_bp4.py [trials] [seed]
-Random ragged Hx / Hz, X/Y/Z priors, iteration counts, scaling factors and OSD methods.  The device's
-exp/log1p differ from glibc's in the last bit, so a shot may legitimately differ when it sits on a
-numerical tie: at most 2 % of a trial's shots may differ.  LLRs of the agreeing shots: within 1e-5 for up
-to 10 iterations; non-converging BP on these short-cycle random graphs amplifies a last-bit difference by a
-small factor per iteration (observed 6e-4 after 39 iterations, decisions identical), so longer runs are held to 1e-2."""
+Random ragged Hx / Hz, X/Y/Z priors, iteration counts, scaling factors and OSD methods.  The device evaluates
+exp / log1p like glibc's FMA build (csrc/swd_libm.h); on a host whose libm selects that build (x86-64 with FMA,
+glibc >= 2.28) the oracle and the device must agree on EVERY shot and every posterior LLR bit for bit.  On any
+other host the oracle's own libm differs in the last bit: there up to 2 % of a trial's shots may differ and the
+LLRs are held to 1e-5 (1e-2 beyond 10 iterations, where non-converging BP amplifies a last-bit difference)."""
 import os
 import sys
 
@@ -15,6 +15,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O  # noqa: E402
 from slidingwindowdecoder_amd import bp4_osd  # noqa: E402
 
+def _host_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+EXACT = _host_fma()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
@@ -79,7 +87,8 @@ while done < trials:
                 print(f"   shot {b}: vec differs {int((w != out[b]).sum())} conv dev {bool(dev.last_status[b] & 0x100)} ora {bool(ora.converge)} its dev "
                       f"{dev.last_iterations[b]} ora {ora.bp_iteration} nonfinite dev {int((~np.isfinite(a)).sum())} ora {int((~np.isfinite(r)).sum())} "
                       f"max|llr| ora {np.nanmax(np.abs(r)):.3g} max abs diff {np.nanmax(np.abs(a - r)):.3g}")
-        elif not np.allclose(dev.last_llr[b].T, ora.log_prob_ratios, rtol=1e-5 if kw['max_iter'] <= 10 else 1e-2, atol=1e-8, equal_nan=True):
+        elif (EXACT and not np.array_equal(dev.last_llr[b].T, ora.log_prob_ratios, equal_nan=True)) or not np.allclose(
+                dev.last_llr[b].T, ora.log_prob_ratios, rtol=1e-5 if kw['max_iter'] <= 10 else 1e-2, atol=1e-8, equal_nan=True):
             llr_bad += 1
             a, r = dev.last_llr[b].T, ora.log_prob_ratios
             worst = max(worst, float(np.max(np.abs(a - r) / (np.abs(r) + 1e-3))))
@@ -93,12 +102,12 @@ while done < trials:
         if okc and o.converge:
             okc = abs(o.min_pm - dev.last_min_pm[b]) <= 1e-9 * abs(o.min_pm)
         cdiff += not okc
-    if cdiff > 1:
+    if cdiff > (0 if EXACT else 1):
         bad += 1
         print(f"trial {done}: camel_decode MISMATCH n={n} mx={mx} mz={mz} differing shots {cdiff}/24 kw={ {k: v for k, v in kw.items() if not k.startswith('channel')} }")
         continue
-    if diff > 0.02 * B or llr_bad:
+    if diff > (0 if EXACT else 0.02 * B) or llr_bad:
         bad += 1
         print(f"trial {done}: MISMATCH n={n} mx={mx} mz={mz} differing shots {diff}/{B} llr {llr_bad} worst rel {worst:.2e} kw={ {k: v for k, v in kw.items() if not k.startswith('channel')} }")
-print(f"{trials} trials, {bad} mismatching")
+print(f"{trials} trials, {bad} mismatching ({'every shot and LLR bit for bit' if EXACT else 'host libm without the FMA exp: tolerances applied'})")
 sys.exit(1 if bad else 0)

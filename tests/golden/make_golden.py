@@ -391,10 +391,50 @@ def gen_bp4_camel(ref):
     save("bp4_camel.npz", **arrs)
 
 
+def gen_bp4_shyps(ref):
+    """bp4_osd on the SHYPS r=3 stabiliser matrices S_X = H^T (x) G, S_Z = G (x) H^T (src/build_SHYPS_circuit.py:37-45;
+    21 x 49 each, column weight up to 9) under depolarizing code-capacity noise -- BASELINE config 5's decoder on
+    config 5's code, the setting in which the reference itself can run BP4 (it has no circuit-level BP4)."""
+    from slidingwindowdecoder_amd import shyps
+    SX, SZ = shyps.shyps_stabilizers(3)
+    n = SX.shape[1]
+    arrs = {}
+    arrs.update(graph_arrays(sp.csr_matrix(SX), np.zeros(n), "sx_"))
+    arrs.update(graph_arrays(sp.csr_matrix(SZ), np.zeros(n), "sz_"))
+    sets = [("osd0_p02", 0.02, dict(max_iter=32, ms_scaling_factor=0.625, osd_method="osd_0", osd_order=0), 400),
+            ("osd0_p05", 0.05, dict(max_iter=32, ms_scaling_factor=1.0, osd_method="osd_0", osd_order=0), 400),
+            ("cs10_p02", 0.02, dict(max_iter=32, ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10), 400),
+            ("cs10_p05", 0.05, dict(max_iter=20, ms_scaling_factor=0.75, osd_method="osd_cs", osd_order=10), 400)]
+    for tag, p, kw, shots in sets:
+        px = py = pz = p / 3 * np.ones(n)
+        dec = ref.bp4_osd(SX.astype(int), SZ.astype(int), channel_probs_x=px, channel_probs_y=py, channel_probs_z=pz, **kw)
+        rng = np.random.default_rng(int(p * 1000) + shots + len(tag))
+        sxs, szs, outs, conv, its, lprs, o0 = [], [], [], [], [], [], []
+        for k in range(shots):
+            noise = rng.uniform(0, 1, n)
+            sc = 1.0 if k % 4 else 2.5                       # every fourth shot is heavier: more OSD exits
+            err_z = np.logical_and(noise > sc * px, noise < sc * (px + py + pz))
+            err_x = noise < sc * (px + py)
+            sx = (err_z @ SX.T) % 2
+            sz = (err_x @ SZ.T) % 2
+            out = dec.decode(sx, sz)
+            sxs.append(sx); szs.append(sz); outs.append(np.asarray(out, np.uint8))
+            conv.append(int(dec.converge)); its.append(int(dec.bp_iteration))
+            lprs.append(np.asarray(dec.log_prob_ratios))
+            o0.append(np.stack([dec.osd0_decoding_x, dec.osd0_decoding_z]).astype(np.uint8))
+        arrs.update({tag + "_p": np.float64(p), tag + "_params": json.dumps(kw),
+                     tag + "_sx": pack(np.array(sxs)), tag + "_sz": pack(np.array(szs)),
+                     tag + "_out": pack(np.array(outs)), tag + "_osd0": pack(np.array(o0)),
+                     tag + "_converge": np.array(conv, np.uint8), tag + "_bp_iteration": np.array(its, np.int32),
+                     tag + "_lpr": np.array(lprs)})
+        print(f"  bp4_shyps/{tag}: converge {sum(conv)}/{shots}")
+    save("bp4_shyps.npz", **arrs)
+
+
 def main():
     ensure_reference()
     import src as ref
-    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4", "camel"]
+    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4", "camel", "bp4_shyps"]
     if "bb72" in which:
         gen_bb72(ref)
     if "bb144" in which:
@@ -407,6 +447,8 @@ def main():
         gen_bp4(ref)
     if "camel" in which:
         gen_bp4_camel(ref)
+    if "bp4_shyps" in which:
+        gen_bp4_shyps(ref)
 
 
 if __name__ == "__main__":

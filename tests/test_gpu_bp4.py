@@ -1,14 +1,32 @@
-"""GPU parity of bp4_osd.  exp/log1p of the device math library differ from glibc's in the last bit, so
-the posterior LLRs are compared with the north star's 1e-5 relative tolerance (observed: ~1e-13) and the
-decisions must agree on (nearly) every shot: a differing shot is only tolerated when the reference's own
-LLRs put it on a numerical tie."""
+"""GPU parity of bp4_osd against vectors recorded from the reference.  The device evaluates exp / log1p with the
+algorithms of the C library the reference ran on (csrc/swd_libm.h, pinned by tests/test_libm_restatement.py), so
+EVERY shot has to agree: error vectors, converge flags, iteration counts and OSD-0 solutions bit for bit; the
+posterior LLRs are held to the north star's 1e-5 relative tolerance and the number of them that is bit-identical
+is printed (all of them, when the goldens come from an FMA-capable glibc 2.35 host as committed)."""
 import numpy as np
 import pytest
 
 from tests import fixtures as fx
-from tests.test_oracle_bp4 import TAGS, load_case
+from tests.test_oracle_bp4 import SHYPS_TAGS, TAGS, load_case, load_shyps
 
 pytestmark = pytest.mark.gpu
+
+
+def _check_all_shots(dec, out, c, label):
+    same = (out == c["out"]).all(axis=(1, 2))
+    conv = (dec.last_status & 0x100) != 0
+    csame = conv == (c["converge"] != 0)
+    isame = dec.last_iterations == c["its"]
+    k = c["lpr"].shape[0]
+    got = np.transpose(dec.last_llr[:k], (0, 2, 1))
+    exact = (got == c["lpr"]) | (np.isnan(got) & np.isnan(c["lpr"]))
+    print(f"{label}: {len(same)} shots, differing vectors {(~same).sum()}, converge flags {(~csame).sum()}, iteration counts "
+          f"{(~isame).sum()}; posterior LLRs bit-identical {exact.sum()} of {exact.size}")
+    assert same.all(), f"{label}: shots {np.flatnonzero(~same)[:10].tolist()} differ from the reference"
+    assert csame.all() and isame.all()
+    np.testing.assert_allclose(got, c["lpr"], rtol=1e-5, atol=1e-8)  # north star: within 1e-5 relative
+    assert (dec.last_osd0 == c["osd0"]).all()
+    return exact.mean()
 
 
 @pytest.mark.parametrize("tag", TAGS)
@@ -17,19 +35,21 @@ def test_bp4_matches_reference(tag):
     c = load_case(tag)
     dec = bp4_osd(c["code"].hx, c["code"].hz, channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"], **c["kw"])
     out = dec.decode_batch(c["sx"], c["sz"])
-    same = (out == c["out"]).all(axis=(1, 2))
-    conv = (dec.last_status & 0x100) != 0
-    assert same.mean() >= 0.99, f"{(~same).sum()} of {len(same)} shots differ"
-    assert (conv == (c["converge"] != 0)).mean() >= 0.99
-    ok = same & (conv == (c["converge"] != 0))
-    assert np.array_equal(dec.last_iterations[ok], c["its"][ok])
-    # posterior LLRs of the recorded shots
-    k = c["lpr"].shape[0]
-    got = np.transpose(dec.last_llr[:k], (0, 2, 1))
-    sel = ok[:k]
-    np.testing.assert_allclose(got[sel], c["lpr"][sel], rtol=1e-5, atol=1e-8)
-    # OSD-0 solutions of the same shots
-    assert (dec.last_osd0[ok] == c["osd0"][ok]).all()
+    assert _check_all_shots(dec, out, c, tag) == 1.0
+
+
+@pytest.mark.parametrize("tag", SHYPS_TAGS)
+def test_bp4_shyps_matches_reference(tag):
+    """BASELINE config 5: bp4_osd on the SHYPS r=3 stabiliser matrices (column weight 9), reference-recorded."""
+    from slidingwindowdecoder_amd import bp4_osd, shyps
+    c = load_shyps(tag)
+    SX, SZ = shyps.shyps_stabilizers(3)
+    dec = bp4_osd(SX, SZ, channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"], **c["kw"])
+    assert (dec.rank_x, dec.rank_z) == (12, 12)
+    out = dec.decode_batch(c["sx"], c["sz"])
+    assert _check_all_shots(dec, out, c, "shyps " + tag) == 1.0
+    cls = np.bincount(dec.last_status & 0xFF, minlength=6)
+    assert cls[2] > 0  # the OSD ran on some shots
 
 
 def test_bp4_single_decode_surface():
@@ -78,12 +98,12 @@ def test_bp4_camel_decode_matches_reference(tag):
     out = dec.camel_decode_batch(c["sx"], c["sz"])
     conv = (dec.last_status & 0x100) != 0
     want = c["converge"] != 0
-    assert (conv == want).mean() >= 0.99
+    assert (conv == want).all(), f"converge flags differ on shots {np.flatnonzero(conv != want)[:10].tolist()}"
     ok = conv & want
     same = (out == c["out"]).all(axis=(1, 2))
-    assert same[ok].mean() >= 0.99, f"{(~same[ok]).sum()} of {ok.sum()} converged shots differ"
+    assert same[ok].all(), f"{(~same[ok]).sum()} of {ok.sum()} converged shots differ"
     good = ok & same
-    np.testing.assert_allclose(dec.last_min_pm[good], c["min_pm"][good], rtol=1e-12)
+    assert (dec.last_min_pm[good] == c["min_pm"][good]).all()
     assert np.array_equal(dec.last_iterations[good], c["its"][good])
     assert not out[~conv].any() and (dec.last_min_pm[~conv] == 10000.0).all()
     # single-call surface

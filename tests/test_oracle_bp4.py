@@ -61,3 +61,42 @@ def test_bp4_camel_decode_oracle_matches_reference(tag):
         assert (out == c["out"][k]).all(), f"decode {k}"
         assert dec.converge == c["converge"][k] and dec.bp_iteration == c["its"][k], f"decode {k}"
         assert dec.min_pm == c["min_pm"][k], f"decode {k}"
+
+
+SHYPS_TAGS = ["osd0_p02", "osd0_p05", "cs10_p02", "cs10_p05"]
+
+
+def load_shyps(tag):
+    """bp4_osd on the SHYPS r=3 stabiliser matrices (tests/golden/make_golden.py bp4_shyps)."""
+    f = fx.load("bp4_shyps.npz")
+    SX, _ = fx.graph(f, "sx_")
+    SZ, _ = fx.graph(f, "sz_")
+    n = SX.shape[1]
+    p = float(f[tag + "_p"])
+    return dict(SX=SX, SZ=SZ, n=n, kw=fx.params(f, tag + "_params"), pr=p / 3 * np.ones(n),
+                sx=fx.unpack(f[tag + "_sx"], SX.shape[0]), sz=fx.unpack(f[tag + "_sz"], SZ.shape[0]),
+                out=fx.unpack(f[tag + "_out"], n), osd0=fx.unpack(f[tag + "_osd0"], n), converge=f[tag + "_converge"],
+                its=f[tag + "_bp_iteration"], lpr=f[tag + "_lpr"])
+
+
+def test_shyps_stabilizers_are_the_recorded_matrices():
+    from slidingwindowdecoder_amd import shyps
+    c = load_shyps("osd0_p02")
+    SX, SZ = shyps.shyps_stabilizers(3)
+    assert (c["SX"].toarray() == SX).all() and (c["SZ"].toarray() == SZ).all()
+    assert SX.shape == (21, 49) and SX.sum(1).max() == 12 and SX.sum(0).max() == 9
+    assert not (SX.astype(int) @ SZ.T % 2).any()
+
+
+@pytest.mark.parametrize("tag", SHYPS_TAGS)
+def test_bp4_shyps_oracle_matches_reference(tag):
+    """BASELINE config 5's decoder on config 5's code: vectors, converge, iterations, OSD-0 solutions and posteriors
+    of every recorded decode (posteriors exactly: oracle and reference call the same libm here)."""
+    c = load_shyps(tag)
+    dec = O.bp4_osd(c["SX"], c["SZ"], channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"], **c["kw"])
+    for k in range(c["sx"].shape[0]):
+        out = dec.decode(c["sx"][k], c["sz"][k])
+        assert (out == c["out"][k]).all(), f"decode {k}"
+        assert dec.converge == c["converge"][k] and dec.bp_iteration == c["its"][k]
+        assert (np.stack([dec.osd0_decoding_x, dec.osd0_decoding_z]) == c["osd0"][k]).all()
+        np.testing.assert_allclose(dec.log_prob_ratios, c["lpr"][k], rtol=1e-12, atol=1e-12)
