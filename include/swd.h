@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SWD_ABI_VERSION 1
+#define SWD_ABI_VERSION 2
 
 /* exit class of one window decode, low byte of status[]; bit 8 = converge flag */
 enum {
@@ -32,7 +32,9 @@ enum {
     SWD_EXIT_OSD = 2,       /* OSD produced the answer        osd_window.pyx:193-195 */
     SWD_EXIT_FAIL_SET = 3,  /* "setting vn failed"            osd_window.pyx:179-181 */
     SWD_EXIT_FAIL_PEEL = 4, /* "peeling failed"               osd_window.pyx:184-186 */
-    SWD_EXIT_NO_OSD = 5     /* BP failed and osd_order == -1  osd_window.pyx:199     */
+    SWD_EXIT_NO_OSD = 5,    /* BP failed and osd_order == -1  osd_window.pyx:199     */
+    SWD_EXIT_SCHED_FAULT = 6 /* pipeline only: the window's predecessor never finished (see swd_pipeline_status);
+                                nothing was decoded or committed for this window */
 };
 #define SWD_STATUS_CONVERGE 0x100
 
@@ -84,16 +86,19 @@ int swd_osdw_info(const swd_osdw *d, int32_t *m, int32_t *n, int32_t *new_n, int
  *                  its transpose).  If hist_is_state != 0 the buffer is read as the initial
  *                  history too (the reference object keeps it between decodes); otherwise
  *                  every shot starts from a zero history like a freshly built object.
- *   osd0   [B*n]   nullable; property osd0_decoding (only written for SWD_EXIT_OSD shots)   */
+ *   osd0   [B*n]   nullable; property osd0_decoding (only written for SWD_EXIT_OSD shots)
+ *   bp_dec [B*n]   nullable; for SWD_EXIT_OSD shots the BP hard decisions the OSD started from (property
+ *                  bp_decoding after such a decode, osd_window.pyx:499-501); for every other exit class
+ *                  bp_decoding is `out` itself and bp_dec is left untouched                               */
 int swd_osdw_decode_batch(swd_osdw *d, int32_t B, const uint8_t *synd, uint8_t *out,
                           int32_t *stats, double *min_pm, double *hist, int32_t hist_is_state,
-                          uint8_t *osd0);
+                          uint8_t *osd0, uint8_t *bp_dec);
 
 /* same, device-resident buffers, asynchronous on `stream` (hipStream_t).  stats / min_pm / hist /
- * osd0 may be NULL; strides are in bytes between consecutive shots (0 = dense). */
+ * osd0 / bp_dec may be NULL; strides are in bytes between consecutive shots (0 = dense). */
 int swd_osdw_decode_batch_dev(swd_osdw *d, int32_t B, const uint8_t *synd, int64_t synd_stride,
                               uint8_t *out, int64_t out_stride, int32_t *stats, double *min_pm,
-                              double *hist, int32_t hist_is_state, uint8_t *osd0, void *stream);
+                              double *hist, int32_t hist_is_state, uint8_t *osd0, uint8_t *bp_dec, void *stream);
 
 /* average duration (ms) of the decode kernel launches since the last call, measured with HIP
  * events on the launch stream when timing was enabled with swd_osdw_set_timing(d, 1) */
@@ -228,6 +233,18 @@ int swd_pipeline_decode(swd_pipeline *pl, int32_t B, const uint8_t *det, uint8_t
 int swd_pipeline_decode_dev(swd_pipeline *pl, int32_t B, const uint8_t *det, int64_t det_stride,
                             uint8_t *total, int64_t total_stride, int32_t *stats, double *min_pm,
                             int32_t *shot_result, void *stream);
+/* Scheduling-fault flags accumulated by every launch of this pipeline since the last call, read and cleared
+ * (0 = none; bit 0: a window waited more than 10 s for its predecessor window of the same shot, which cannot
+ * happen by construction -- its statistics record SWD_EXIT_SCHED_FAULT).  Synchronises the device, so call it
+ * after the asynchronous swd_pipeline_decode_dev launches it should cover; swd_pipeline_decode checks it itself. */
+int swd_pipeline_status(swd_pipeline *pl, uint32_t *flags);
+
+/* Threading and streams: every entry point may be called from any host thread.  Launches of ONE decoder /
+ * pipeline handle are serialised on the host while they are prepared; on the device, launches on different streams
+ * run concurrently -- each launch takes its scheduling scratch from a ring of four launch slots, and a fifth launch
+ * in flight makes its stream wait for the first (hipStreamWaitEvent).  Host-buffer entry points of one handle are
+ * mutually exclusive for their whole duration (they share staging buffers). */
+
 /* diagnostics: device-side phase timers (100 MHz ticks) of the last launch, out [B*W*8]:
  * init, pre BP, sort, shorten+peel, post BP, OSD sort, OSD elimination, OSD sweep + epilogue */
 int swd_pipeline_set_profiling(swd_pipeline *pl, int32_t on);

@@ -52,8 +52,8 @@ SYMBOLS = [
     ("swd_osdw_create", _vp, [C.POINTER(GraphDesc), C.POINTER(OsdwParams), C.c_int]),
     ("swd_osdw_destroy", None, [_vp]),
     ("swd_osdw_info", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
-    ("swd_osdw_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    ("swd_osdw_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    ("swd_osdw_decode_batch", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    ("swd_osdw_decode_batch_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     ("swd_osdw_set_timing", C.c_int, [_vp, _i32]),
     ("swd_osdw_get_timing", C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64)]),
     ("swd_gdg_create", _vp, [C.POINTER(GraphDesc), C.POINTER(GdgParams), C.c_int]),
@@ -74,6 +74,7 @@ SYMBOLS = [
     ("swd_pipeline_set_observables", C.c_int, [_vp, C.POINTER(GraphDesc)]),
     ("swd_pipeline_decode", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("swd_pipeline_decode_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_status", C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     ("swd_pipeline_set_profiling", C.c_int, [_vp, _i32]),
     ("swd_pipeline_get_profile", C.c_int, [_vp, _i32, _vp]),
     ("swd_pipeline_set_timing", C.c_int, [_vp, _i32]),

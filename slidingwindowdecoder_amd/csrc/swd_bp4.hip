@@ -179,6 +179,7 @@ extern "C" int swd_bp4_camel_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *
     Bp4 *d = (Bp4 *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
+    if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
     const size_t n = d->n, mx = d->gx.m, mz = d->gz.m;
     if (d->sx.reserve(B * mx) || d->sz.reserve(B * mz) || d->out.reserve(B * 2 * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
@@ -202,6 +203,7 @@ static int bp4_decode_batch_direct(swd_bp4 *h, int32_t B, const uint8_t *sx, con
     Bp4 *d = (Bp4 *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
+    if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
     const size_t n = d->n, mx = d->gx.m, mz = d->gz.m;
     if (d->sx.reserve(B * mx) || d->sz.reserve(B * mz) || d->out.reserve(B * 2 * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||

@@ -8,6 +8,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include <stdlib.h>
 
@@ -106,10 +107,24 @@ struct Plan {
     DevBuf shot;
     const uint32_t *d_colptr = nullptr;
     const uint16_t *d_rows = nullptr;
-    // host-pointer staging
+    // host-pointer staging (the host-buffer entry points hold `mu` for their whole duration)
     DevBuf synd, out, stats, pm, hist, osd0, total;
-    DevBuf prof, sched, state, io;
+    DevBuf prof, io;
     PinnedBuf stage;
+    // Scratch a launch writes and reads back -- ticket counter + per-shot progress, the window hand-over
+    // records, the per-workgroup history ring and snapshot stack -- comes from a small ring of launch slots, so
+    // launches of one decoder on different streams (or from different host threads) never share it: a launch
+    // that re-uses a slot first makes its stream wait for the slot's previous launch (hipStreamWaitEvent).
+    struct LaunchSlot {
+        DevBuf sched, state, hist, snap;
+        hipEvent_t done = nullptr;
+    };
+    static constexpr int kSlots = 4;
+    LaunchSlot slot[kSlots];
+    LaunchSlot *cur = nullptr; // slot of the launch being prepared (valid under mu)
+    int next_slot = 0;
+    std::recursive_mutex mu;
+    DevBuf status;             // one word, never reset by a launch: scheduling faults (swd_pipeline_status)
     bool profiling = false;
     bool timing = false;
     double t_total_ms = 0;
@@ -118,6 +133,7 @@ struct Plan {
 
     ~Plan() {
         if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+        for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
     }
 
     int add_window(const swd_graph_desc *gd, int row0, int col0, int commit,
@@ -191,6 +207,8 @@ struct Plan {
             set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
             return -1;
         }
+        if (status.reserve(4)) return -1;
+        SWD_HIP(hipMemset(status.p, 0, 4));
         std::vector<SwdWindowDev> hw(wins.size());
         if (variant->sf) {
             std::vector<uint32_t> all, one;
@@ -239,7 +257,9 @@ struct Plan {
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
 static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     SwdPipeArgs a = a0;
-    static int lds_limit[64] = {0}; // per device, monotone: the attribute belongs to the function
+    static std::mutex fn_mu; // the attribute and the occupancy answer belong to the function, not to a decoder
+    std::lock_guard<std::mutex> fn_lock(fn_mu);
+    static int lds_limit[64] = {0}; // per device, monotone
     if (d->lds_total > lds_limit[d->device & 63]) {
         SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
@@ -257,13 +277,16 @@ static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     }
     const long long units = (long long)a.B * a.W;
     const unsigned grid = (unsigned)std::min<long long>(units, slots[d->device & 63]);
-    if (a.slot_scratch) { // per-workgroup scratch (sliding-window plans): history ring and, for the guessing decoders, snapshots
-        if (d->hist.reserve((size_t)grid * a.hist_stride * sizeof(double))) return -1;
-        a.hist = d->hist.as<double>();
-        if (d->kind != 0) {
-            if (d->snap.reserve((size_t)grid * d->snap_stride + 8)) return -1;
-            a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
-        }
+    // history ring and (guessing decoders) snapshot stack: per workgroup for sliding-window plans, per shot
+    // otherwise; a caller-provided history buffer (single-window calls) is used as it is
+    const size_t nscr = a.slot_scratch ? (size_t)grid : (size_t)a.B;
+    if (!a.hist) {
+        if (d->cur->hist.reserve(nscr * a.hist_stride * sizeof(double))) return -1;
+        a.hist = d->cur->hist.as<double>();
+    }
+    if (d->kind != 0) {
+        if (d->cur->snap.reserve(nscr * d->snap_stride + 8)) return -1;
+        a.snap = d->cur->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
     }
     hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF>), dim3(grid), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
@@ -315,6 +338,7 @@ static const Variant kVariants[] = {
     {256, 7, 8, 16, 0, launch_nt<256, 7, 8, 16, 0>, launch_nt<256, 7, 8, 16, 1>},
     {1024, 5, 6, 6, 1, launch_nt<1024, 5, 6, 6, 0, true>, nullptr},                   // [[288,12,18]] circuit-level windows, osd_window
     {1024, 5, 6, 9, 0, launch_nt<1024, 5, 6, 9, 0>, launch_nt<1024, 5, 6, 9, 1>},    // [[288,12,18]] circuit-level windows
+    {1024, 3, 10, 12, 0, launch_nt<1024, 3, 10, 12, 0>, launch_nt<1024, 3, 10, 12, 1>}, // SHYPS r=3 twelve-round windows (252 x 2240, column weight 9, row weight 44)
     {1024, 8, 8, 16, 0, launch_nt<1024, 8, 8, 16, 0>, launch_nt<1024, 8, 8, 16, 1>},
 #endif
 };
@@ -338,10 +362,17 @@ static const Variant *select_variant(const std::vector<WindowHost> &wins, int mm
 static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // work-unit scheduling state: ticket counter + per-shot progress (zeroed per launch), hand-over buffer
     SwdPipeArgs a = a0;
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
+    Plan::LaunchSlot &sl = d->slot[d->next_slot];
+    d->next_slot = (d->next_slot + 1) % Plan::kSlots;
+    d->cur = &sl;
+    if (!sl.done) SWD_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    else SWD_HIP(hipStreamWaitEvent(st, sl.done, 0)); // the slot's previous launch (possibly on another stream) is done first
     a.state_stride = 16 + align_up(d->num_det, 16);
-    if (d->sched.reserve((size_t)(a.B + 2) * 4) || d->state.reserve((size_t)a.B * a.state_stride)) return -1; // + ticket, + error flag
-    a.sched = d->sched.as<uint32_t>(); a.state = d->state.as<uint8_t>();
-    SWD_HIP(hipMemsetAsync(a.sched, 0, (size_t)(a.B + 2) * 4, st));
+    if (sl.sched.reserve((size_t)(a.B + 1) * 4) || sl.state.reserve((size_t)a.B * a.state_stride)) return -1;
+    a.sched = sl.sched.as<uint32_t>(); a.state = sl.state.as<uint8_t>();
+    a.status = d->status.as<uint32_t>();
+    SWD_HIP(hipMemsetAsync(a.sched, 0, (size_t)(a.B + 1) * 4, st));
     if (d->timing) {
         if (!d->ev0) { SWD_HIP(hipEventCreate(&d->ev0)); SWD_HIP(hipEventCreate(&d->ev1)); }
         SWD_HIP(hipEventRecord(d->ev0, st));
@@ -349,6 +380,7 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     int rc;
     rc = (d->kind == 0) ? d->variant->launch(d, a, st) : d->variant->launch_gdg(d, a, st);
     if (rc) return rc;
+    SWD_HIP(hipEventRecord(sl.done, st));
     if (d->timing) {
         SWD_HIP(hipEventRecord(d->ev1, st));
         SWD_HIP(hipEventSynchronize(d->ev1));
@@ -451,7 +483,7 @@ extern "C" int swd_osdw_get_timing(swd_osdw *h, double *total_ms, int64_t *launc
 
 extern "C" int swd_osdw_decode_batch_dev(swd_osdw *h, int32_t B, const uint8_t *synd, int64_t synd_stride,
                                          uint8_t *out, int64_t out_stride, int32_t *stats, double *min_pm,
-                                         double *hist, int32_t hist_is_state, uint8_t *osd0, void *stream) {
+                                         double *hist, int32_t hist_is_state, uint8_t *osd0, uint8_t *bp_dec, void *stream) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
@@ -459,44 +491,38 @@ extern "C" int swd_osdw_decode_batch_dev(swd_osdw *h, int32_t B, const uint8_t *
     SWD_HIP(hipSetDevice(d->device));
     const int n = d->wins[0].g->n, m = d->wins[0].g->m;
     const bool hist_out = hist != nullptr;
-    if (!hist) {
-        if (hist_is_state) { set_error("hist_is_state requires a caller-provided history buffer"); return -1; }
-        if (d->hist.reserve((size_t)B * 4 * n * sizeof(double))) return -1;
-        hist = d->hist.as<double>();
-    }
+    if (!hist && hist_is_state) { set_error("hist_is_state requires a caller-provided history buffer"); return -1; }
     SwdPipeArgs a{};
     a.wins = d->d_wins.as<SwdWindowDev>(); a.W = 1; a.B = B;
     fill_params(d, a.P, hist_is_state != 0, hist_out);
     a.det = synd; a.det_stride = synd_stride ? synd_stride : m; a.num_det = m; a.off_det = d->off_det;
     a.total = nullptr; a.win_out = out; a.win_out_stride = out_stride ? out_stride : n;
-    a.stats = stats; a.min_pm = min_pm; a.hist = hist; a.hist_stride = 4 * (int64_t)n; a.osd0 = osd0;
-    if (d->kind != 0) {
-        if (d->snap.reserve((size_t)B * d->snap_stride + 8)) return -1;
-        a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
-    }
-    return launch(d, a, (hipStream_t)stream);
+    a.stats = stats; a.min_pm = min_pm; a.hist = hist; a.hist_stride = 4 * (int64_t)n; a.osd0 = osd0; a.bp_dec = bp_dec;
+    return launch(d, a, (hipStream_t)stream); // a null history / the snapshot stack come from the launch slot
 }
 
 // large batches: one synchronous copy per array straight from / to the caller's buffers
 static int osdw_decode_batch_direct(swd_osdw *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
-                                     double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0) {
+                                     double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0, uint8_t *bp_dec) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
     if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
     const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
     const size_t hbytes = (size_t)B * 4 * n * 8;
     if (d->synd.reserve(B * m) || d->out.reserve(B * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
-        d->pm.reserve(B * 8) || d->hist.reserve(hbytes))
+        d->pm.reserve(B * 8) || (hist && d->hist.reserve(hbytes)))
         return -1;
-    if (osd0 && d->osd0.reserve(B * n)) return -1;
+    if ((osd0 || bp_dec) && d->osd0.reserve(2 * B * n)) return -1; // [ osd0 | bp_dec ]
     SWD_HIP(hipMemcpy(d->synd.p, synd, B * m, hipMemcpyHostToDevice));
     if (hist && hist_is_state) SWD_HIP(hipMemcpy(d->hist.p, hist, hbytes, hipMemcpyHostToDevice));
-    if (osd0) SWD_HIP(hipMemset(d->osd0.p, 0, B * n));
+    if (osd0 || bp_dec) SWD_HIP(hipMemset(d->osd0.p, 0, 2 * B * n));
     int rc = swd_osdw_decode_batch_dev(h, B, d->synd.as<uint8_t>(), 0, d->out.as<uint8_t>(), 0, d->stats.as<int32_t>(),
                                        d->pm.as<double>(), hist ? d->hist.as<double>() : nullptr,
-                                       (hist && hist_is_state) ? 1 : 0, osd0 ? d->osd0.as<uint8_t>() : nullptr, nullptr);
+                                       (hist && hist_is_state) ? 1 : 0, osd0 ? d->osd0.as<uint8_t>() : nullptr,
+                                       bp_dec ? d->osd0.as<uint8_t>() + B * n : nullptr, nullptr);
     if (rc) return rc;
     SWD_HIP(hipDeviceSynchronize());
     SWD_HIP(hipMemcpy(out, d->out.p, B * n, hipMemcpyDeviceToHost));
@@ -504,15 +530,17 @@ static int osdw_decode_batch_direct(swd_osdw *h, int32_t B, const uint8_t *synd,
     SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * 8, hipMemcpyDeviceToHost));
     if (hist) SWD_HIP(hipMemcpy(hist, d->hist.p, hbytes, hipMemcpyDeviceToHost));
     if (osd0) SWD_HIP(hipMemcpy(osd0, d->osd0.p, B * n, hipMemcpyDeviceToHost));
+    if (bp_dec) SWD_HIP(hipMemcpy(bp_dec, d->osd0.as<uint8_t>() + B * n, B * n, hipMemcpyDeviceToHost));
     return 0;
 }
 
 extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
-                                     double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0) {
+                                     double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0, uint8_t *bp_dec) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
     if (B <= 0) return 0;
     if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
     const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
     // one packed device buffer mirrored by a pinned host buffer: [ syndromes | history ] travel in,
@@ -522,18 +550,18 @@ extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_synd = 0, o_hist = al((size_t)B * m), o_out = o_hist + al(hbytes), o_stats = o_out + al((size_t)B * n),
                  o_pm = o_stats + al((size_t)B * SWD_STAT_WORDS * 4), o_osd0 = o_pm + al((size_t)B * 8),
-                 total = o_osd0 + (osd0 ? al((size_t)B * n) : 0);
-    if (total > SWD_STAGE_MAX) return osdw_decode_batch_direct(h, B, synd, out, stats, min_pm, hist, hist_is_state, osd0); // copy time dominates there
+                 o_bpd = o_osd0 + (osd0 ? al((size_t)B * n) : 0), total = o_bpd + (bp_dec ? al((size_t)B * n) : 0);
+    if (total > SWD_STAGE_MAX) return osdw_decode_batch_direct(h, B, synd, out, stats, min_pm, hist, hist_is_state, osd0, bp_dec); // copy time dominates there
     if (d->io.reserve(total) || d->stage.reserve(total)) return -1;
     char *hs = (char *)d->stage.p, *ds = (char *)d->io.p;
     memcpy(hs + o_synd, synd, (size_t)B * m);
     if (hist_in) memcpy(hs + o_hist, hist, hbytes);
     hipStream_t st = nullptr;
     SWD_HIP(hipMemcpyAsync(ds, hs, hist_in ? o_hist + hbytes : (size_t)B * m, hipMemcpyHostToDevice, st));
-    if (osd0) SWD_HIP(hipMemsetAsync(ds + o_osd0, 0, (size_t)B * n, st));
+    if (osd0 || bp_dec) SWD_HIP(hipMemsetAsync(ds + o_osd0, 0, total - o_osd0, st));
     int rc = swd_osdw_decode_batch_dev(h, B, (const uint8_t *)(ds + o_synd), 0, (uint8_t *)(ds + o_out), 0, (int32_t *)(ds + o_stats),
                                        (double *)(ds + o_pm), hist ? (double *)(ds + o_hist) : nullptr, hist_in ? 1 : 0,
-                                       osd0 ? (uint8_t *)(ds + o_osd0) : nullptr, st);
+                                       osd0 ? (uint8_t *)(ds + o_osd0) : nullptr, bp_dec ? (uint8_t *)(ds + o_bpd) : nullptr, st);
     if (rc) return rc;
     const size_t first = hist ? o_hist : o_out;
     SWD_HIP(hipMemcpyAsync(hs + first, ds + first, total - first, hipMemcpyDeviceToHost, st));
@@ -543,6 +571,7 @@ extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd
     memcpy(min_pm, hs + o_pm, (size_t)B * 8);
     if (hist) memcpy(hist, hs + o_hist, hbytes);
     if (osd0) memcpy(osd0, hs + o_osd0, (size_t)B * n);
+    if (bp_dec) memcpy(bp_dec, hs + o_bpd, (size_t)B * n);
     return 0;
 }
 
@@ -611,24 +640,30 @@ extern "C" int swd_pipeline_decode_dev(swd_pipeline *h, int32_t B, const uint8_t
     SwdPipeArgs a{};
     a.wins = d->d_wins.as<SwdWindowDev>(); a.W = (int)d->wins.size(); a.B = B;
     a.slot_scratch = a.W > 1 ? 1 : 0;
-    if (!a.slot_scratch && d->hist.reserve((size_t)B * 4 * d->nmax * sizeof(double))) return -1;
     fill_params(d, a.P, false, false);
     a.det = det; a.det_stride = det_stride ? det_stride : d->num_det; a.num_det = d->num_det; a.off_det = d->off_det;
     a.total = total; a.total_stride = total_stride ? total_stride : d->num_col;
     a.chk_colptr = d->d_colptr; a.chk_rows = d->d_rows;
     a.win_out = nullptr; a.stats = stats; a.min_pm = min_pm;
-    a.hist = d->hist.as<double>(); a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
+    a.hist = nullptr; a.hist_stride = 4 * (int64_t)d->nmax; a.osd0 = nullptr;
     a.obs_mask = d->d_obs.p ? d->d_obs.as<uint32_t>() : nullptr;
     a.shot_result = shot_result;
-    if (d->kind != 0 && !a.slot_scratch) {
-        if (d->snap.reserve((size_t)B * d->snap_stride + 8)) return -1;
-        a.snap = d->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
-    }
     if (d->profiling) {
         if (d->prof.reserve((size_t)B * a.W * 8 * sizeof(int64_t))) return -1;
         a.prof = d->prof.as<int64_t>();
     }
     return launch(d, a, (hipStream_t)stream);
+}
+
+extern "C" int swd_pipeline_status(swd_pipeline *h, uint32_t *flags) {
+    Plan *d = (Plan *)h;
+    if (!d || !flags) { set_error("null argument"); return -1; }
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
+    SWD_HIP(hipSetDevice(d->device));
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(flags, d->status.p, 4, hipMemcpyDeviceToHost));
+    if (*flags) SWD_HIP(hipMemset(d->status.p, 0, 4)); // read-and-clear
+    return 0;
 }
 
 extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats,
@@ -637,6 +672,7 @@ extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *de
     if (!d) { set_error("null pipeline"); return -1; }
     if (B <= 0) return 0;
     if (!det || !total) { set_error("null output/input pointer"); return -1; }
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
     const size_t W = d->wins.size();
     if (d->synd.reserve((size_t)B * d->num_det) || d->total.reserve((size_t)B * d->num_col) ||
@@ -646,11 +682,10 @@ extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *de
     int rc = swd_pipeline_decode_dev(h, B, d->synd.as<uint8_t>(), 0, d->total.as<uint8_t>(), 0, d->stats.as<int32_t>(),
                                      d->pm.as<double>(), d->shot.as<int32_t>(), nullptr);
     if (rc) return rc;
-    SWD_HIP(hipDeviceSynchronize());
     {
         uint32_t err = 0;
-        SWD_HIP(hipMemcpy(&err, d->sched.as<uint32_t>() + 1 + B, 4, hipMemcpyDeviceToHost));
-        if (err) { set_error("internal: a window waited more than 10 s for its predecessor (scheduling bug)"); return -1; }
+        if (swd_pipeline_status(h, &err)) return -1; // synchronises
+        if (err) { set_error("internal: a window waited more than 10 s for its predecessor (scheduling fault, flags 0x%x)", err); return -1; }
     }
     SWD_HIP(hipMemcpy(total, d->total.p, (size_t)B * d->num_col, hipMemcpyDeviceToHost));
     if (shot_result) SWD_HIP(hipMemcpy(shot_result, d->shot.p, (size_t)B * 8, hipMemcpyDeviceToHost));
@@ -703,13 +738,13 @@ extern "C" void swd_gdg_destroy(swd_gdg *h) { swd_osdw_destroy((swd_osdw *)h); }
 
 extern "C" int swd_gdg_decode_batch(swd_gdg *h, int32_t B, const uint8_t *synd, uint8_t *out, int32_t *stats,
                                     double *min_pm, double *hist, int32_t hist_is_state) {
-    return swd_osdw_decode_batch((swd_osdw *)h, B, synd, out, stats, min_pm, hist, hist_is_state, nullptr);
+    return swd_osdw_decode_batch((swd_osdw *)h, B, synd, out, stats, min_pm, hist, hist_is_state, nullptr, nullptr);
 }
 
 extern "C" int swd_gdg_decode_batch_dev(swd_gdg *h, int32_t B, const uint8_t *synd, int64_t synd_stride, uint8_t *out,
                                         int64_t out_stride, int32_t *stats, double *min_pm, void *stream) {
     return swd_osdw_decode_batch_dev((swd_osdw *)h, B, synd, synd_stride, out, out_stride, stats, min_pm, nullptr, 0,
-                                     nullptr, stream);
+                                     nullptr, nullptr, stream);
 }
 
 extern "C" swd_pipeline *swd_pipeline_create_gdg(int32_t num_windows, const swd_window_desc *wins,

@@ -76,13 +76,15 @@ struct SwdPipeArgs {
     double *hist;             // [B][4][nmax]
     int64_t hist_stride;      // doubles per shot
     uint8_t *osd0;            // nullable [B][n] (single-window use)
+    uint8_t *bp_dec;          // nullable [B][n] (single-window use): BP hard decisions when the OSD takes over (property bp_decoding)
     uint8_t *snap;            // guessing decoders: [B][snap_stride] snapshot stack in HBM
     int64_t snap_stride;
     const uint32_t *obs_mask; // nullable [num_col]: bit k set if fault flips observable k (obs matrix)
     int32_t *shot_result;     // nullable [B][2]: predicted observable flips, residual syndrome != 0
     int64_t *prof;            // nullable [B][W][8]: 100 MHz ticks per phase (diagnostics only)
     // work-unit scheduling (one workgroup = one window of one shot, see pipeline_kernel)
-    uint32_t *sched;          // [1 + B]: ticket counter, then per shot the number of windows finished
+    uint32_t *sched;          // [1 + B]: ticket counter, then per shot the number of windows finished (zeroed per launch)
+    uint32_t *status;         // one word owned by the decoder, never reset by a launch: bit 0 = a window gave up waiting for its predecessor
     uint8_t *state;           // [B][state_stride]: residual syndrome + accumulators handed to the next window
     int64_t state_stride;
     int32_t slot_scratch;     // hist / snap are private to the workgroup (indexed by blockIdx.x), not to the shot
@@ -1346,7 +1348,7 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 // order).  On return s.hard[0..n) is the vector decode() returns.
 template <int NT, int VF, int DM, int KG, bool SF>
 __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
-                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, WinResult &R, const uint32_t *cn_map) {
+                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map) {
     const int tid = threadIdx.x;
     const int m = g.m, n = g.n;
 #pragma unroll
@@ -1585,6 +1587,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         return;
     }
     if (P.osd_order < 0) { R.exit_class = SWD_EXIT_NO_OSD; return; }
+    // osd_window.bp_decoding after an OSD exit = the post-phase BP decisions incl. the decided values (osd_window.pyx:499-501)
+    if (bpdec_b)
+        for (int v = tid; v < n; v += NT) bpdec_b[v] = s.hard[v];
     // ---- OSD (osd_window.pyx:201-284): keys -1000 / +1000 / history sum, stable ascending order.
     // The decided-0 columns (most of the window after shortening) all carry +1000 and therefore form one
     // block in index order; only the rest (decided-1 and live columns, <= new_n) needs sorting:
@@ -1653,12 +1658,30 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 
 #include "swd_gdg_kernel.h"
 
-// One workgroup carries one shot through all W windows of the sliding-window plan
-// (/root/reference/osd.py:130-179): decode window t on the residual syndrome, commit the
-// leading `commit` columns into total_e_hat, fold the committed faults back into the
-// residual syndrome (osd.py:178, done sparsely on the shot's LDS copy), next window.  Windows
-// of one shot are sequentially dependent, shots are independent, so there is no inter-workgroup
-// traffic at all.  W = 1 with commit = 0 is the plain batched osd_window.decode.
+// The window loop of the reference harness (/root/reference/osd.py:130-179) as work units on a persistent
+// grid: one unit = one window of one shot -- decode window t on the shot's residual syndrome, commit the
+// leading `commit` columns into total_e_hat, fold the committed faults back into the residual syndrome
+// (osd.py:178, done sparsely on the LDS copy), hand the residual syndrome + observable accumulator to the
+// unit of window t+1 through HBM.  W = 1 with commit = 0 is the plain batched osd_window.decode.
+//
+// Invariants of the hand-over (regression: scripts/stress_handoff.py, tests/test_gpu_scheduler.py):
+//   1. units are drawn in ticket order, window-major; unit (t, b) waits only for unit (t-1, b), whose ticket
+//      is older, so its workgroup is already resident and running: the wait cannot deadlock under any
+//      dispatch order and needs no co-residency beyond the grid the launch itself sized;
+//   2. producer: every state word is written with an agent-scope atomic store (sc1, write-through past the
+//      XCD's L2), every wave waits for the acknowledgement of its stores (s_waitcnt vmcnt(0), in an asm
+//      statement the compiler cannot drop or move), the workgroup barrier orders all waves' acknowledgements
+//      before thread 0's agent-scope store of the progress counter;
+//   3. consumer: thread 0 polls the counter with agent-scope atomic loads (sc1: served past L1), a workgroup
+//      barrier, then every state word is read with an agent-scope atomic load issued after the poll returned
+//      (a wave's vector-memory loads return in order), so no L1- or L2-resident stale line can be read;
+//   4. state words are never accessed with plain loads or stores, and scratch that one unit writes and reads
+//      back (history ring, snapshots) is indexed by workgroup, never shared between units.
+// This relies on gfx950's implementation of sc1 accesses (guide: "sc1 payload -> asm vmcnt(0) -> sc1 flag" is a
+// valid form) rather than on release/acquire fences, which write back / invalidate a whole L2 or L1 per window;
+// -DSWD_HANDOFF_RELACQ builds the formally fenced variant for comparison.
+// A wait that exceeds its 10 s bound sets bit 0 of *status, records exit class SWD_EXIT_SCHED_FAULT for the unit
+// and commits nothing for it: the caller sees the fault (swd_pipeline_status) instead of a plausible wrong answer.
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1679,7 +1702,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
     for (;;) {
     const long long t_unit0 = wall_clock64();
     __syncthreads();
-    if (tid == 0) acc[2] = atomicAdd(a.sched, 1u);
+    if (tid == 0) { acc[2] = atomicAdd(a.sched, 1u); acc[3] = 0u; }
     __syncthreads();
     const uint32_t ticket = acc[2];
     if (ticket >= nunits) break;
@@ -1703,8 +1726,11 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                 __builtin_amdgcn_s_sleep(8);
                 // cannot happen by construction (the awaited ticket is older and running); a bound keeps a bug
                 // from hanging the device: flag the launch and go on (wall_clock64 ticks at 100 MHz -> 10 s)
-                if (wall_clock64() - t_wait0 > 1000000000ll) { atomicOr(&a.sched[1 + a.B], 1u); break; }
+                if (wall_clock64() - t_wait0 > 1000000000ll) { atomicOr(a.status, 1u); acc[3] = 1u; break; }
             }
+#ifdef SWD_HANDOFF_RELACQ
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         }
         __syncthreads();
         const uint32_t *st32 = (const uint32_t *)state_b;
@@ -1728,8 +1754,13 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
 #ifdef SWD_BPPROF
         if (tid == 0) { s.scal[24] = s.scal[25] = s.scal[26] = s.scal[27] = 0; s.scal[20] = s.scal[21] = s.scal[22] = 0; }
 #endif
-        if constexpr (KIND == 0)
-            decode_window<NT, VF, DM, KG, SF>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr, R, w.cn_map);
+        if (acc[3]) { // the predecessor never arrived: nothing is decoded or committed for this unit
+            for (int v = tid; v < g.n; v += NT) s.hard[v] = 0;
+            R = WinResult{};
+            R.exit_class = SWD_EXIT_SCHED_FAULT;
+        } else if constexpr (KIND == 0)
+            decode_window<NT, VF, DM, KG, SF>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
+                                              a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
         else
             decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.snap + (int64_t)sidx * a.snap_stride, R);
         __syncthreads();
@@ -1800,6 +1831,12 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state stores are acknowledged ...
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();                                  // ... by every wave, before the counter moves
+#ifdef SWD_HANDOFF_RELACQ
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#endif
             if (tid == 0) __hip_atomic_store(&a.sched[1 + b], (uint32_t)(wi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -71,6 +71,11 @@ extern "C" swd_sampler *swd_sampler_create(const swd_graph_desc *chk, const swd_
     if (!chk || !chk->row_ptr || !chk->col_idx || !chk->channel_probs) { set_error("null argument"); return nullptr; }
     if (chk->m <= 0 || chk->n <= 0 || chk->m > 65535) { set_error("detector matrix %d x %d out of range", chk->m, chk->n); return nullptr; }
     if (obs && (obs->m > 32 || obs->n != chk->n)) { set_error("observable matrix must be (<= 32) x %d", chk->n); return nullptr; }
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: the MI355X decoder has no CPU fallback"); return nullptr; }
+        if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return nullptr; }
+    }
     Sampler *s = new Sampler();
     s->device = device; s->num_det = chk->m; s->num_col = chk->n; s->num_obs = obs ? obs->m : 0;
     const int n = chk->n, E = chk->row_ptr[chk->m];

@@ -16,7 +16,7 @@ import scipy.sparse as sp
 
 from . import _lib
 
-EXIT_PRE, EXIT_POST, EXIT_OSD, EXIT_FAIL_SET, EXIT_FAIL_PEEL, EXIT_NO_OSD = range(6)
+EXIT_PRE, EXIT_POST, EXIT_OSD, EXIT_FAIL_SET, EXIT_FAIL_PEEL, EXIT_NO_OSD, EXIT_SCHED_FAULT = range(7)
 STATUS_CONVERGE = 0x100
 
 _OSD_METHODS = {  # aliases of osd_window.pyx:69-79
@@ -120,8 +120,9 @@ class osd_window:
         st = np.zeros(_lib.STAT_WORDS, np.int32)
         pm = np.zeros(1, np.float64)
         osd0 = np.zeros(self.n, dtype=np.uint8)
+        bpd = np.zeros(self.n, dtype=np.uint8)
         rc = _lib.lib().swd_osdw_decode_batch(self._h, 1, s.ctypes.data, out.ctypes.data, st.ctypes.data,
-                                              pm.ctypes.data, self._hist.ctypes.data, 1, osd0.ctypes.data)
+                                              pm.ctypes.data, self._hist.ctypes.data, 1, osd0.ctypes.data, bpd.ctypes.data)
         if rc:
             raise RuntimeError(f"swd_osdw_decode_batch failed: {_lib.last_error()}")
         self._last = dict(status=int(st[0]), iters=int(st[1]), min_pm=float(pm[0]))
@@ -129,6 +130,7 @@ class osd_window:
         if (int(st[0]) & 0xFF) == EXIT_OSD:
             self._osdw_decoding = res
             self._osd0_decoding = osd0.astype(np.int64)
+            self._bp_decoding = bpd.astype(np.int64)  # the BP decisions the OSD started from (osd_window.pyx:499-501)
         else:
             self._bp_decoding = res
         return res
@@ -149,7 +151,7 @@ class osd_window:
         osd0 = np.zeros((B, self.n), np.uint8) if return_osd0 else None
         rc = _lib.lib().swd_osdw_decode_batch(self._h, B, s.ctypes.data, out.ctypes.data, st.ctypes.data,
                                               pm.ctypes.data, hist.ctypes.data if hist is not None else None, 0,
-                                              osd0.ctypes.data if osd0 is not None else None)
+                                              osd0.ctypes.data if osd0 is not None else None, None)
         if rc:
             raise RuntimeError(f"swd_osdw_decode_batch failed: {_lib.last_error()}")
         self.last_stats = st
@@ -169,7 +171,7 @@ class osd_window:
         min_pm = torch.empty(B, dtype=torch.float64, device=dev) if min_pm is None else min_pm
         st = torch.cuda.current_stream(dev) if stream is None else stream
         rc = _lib.lib().swd_osdw_decode_batch_dev(self._h, B, synd.data_ptr(), synd.stride(0), out.data_ptr(),
-                                                  out.stride(0), stats.data_ptr(), min_pm.data_ptr(), None, 0, None,
+                                                  out.stride(0), stats.data_ptr(), min_pm.data_ptr(), None, 0, None, None,
                                                   st.cuda_stream)
         if rc:
             raise RuntimeError(f"swd_osdw_decode_batch_dev failed: {_lib.last_error()}")
@@ -518,6 +520,12 @@ class SlidingWindowDecoder:
         asynchronous on the current torch stream.  ``shot_result`` (int32 [B, 2] CUDA tensor, optional)
         receives the predicted observable-flip mask and the flagged bit of every shot."""
         import torch
+        if det.dtype != torch.uint8 or det.dim() != 2 or det.shape[1] != self.num_det or det.stride(1) != 1:
+            raise ValueError(f"det must be a uint8 tensor [B, {self.num_det}] with unit column stride")
+        if not det.is_cuda or det.device.index != self.device:
+            raise ValueError(f"det lives on {det.device}, the pipeline on cuda:{self.device}")
+        if shot_result is not None and self.num_obs > 32:
+            raise ValueError("shot_result carries at most 32 observables; decode the observables on the host for more")
         B, dev = det.shape[0], det.device
         total = torch.empty((B, self.num_col), dtype=torch.uint8, device=dev) if total is None else total
         if want_stats:
@@ -532,6 +540,16 @@ class SlidingWindowDecoder:
         if rc:
             raise RuntimeError(f"swd_pipeline_decode_dev failed: {_lib.last_error()}")
         return total, stats, min_pm
+
+    def check_status(self):
+        """Synchronises the device and raises if any launch of this pipeline since the last check recorded a
+        scheduling fault (a window whose predecessor never finished: exit class 6 in ``stats``).  The host-buffer
+        ``decode`` checks by itself; callers of the asynchronous ``decode_device`` call this after their launches."""
+        flags = C.c_uint32(0)
+        if _lib.lib().swd_pipeline_status(self._h, C.byref(flags)):
+            raise RuntimeError(f"swd_pipeline_status failed: {_lib.last_error()}")
+        if flags.value:
+            raise RuntimeError(f"sliding-window pipeline recorded a scheduling fault (flags 0x{flags.value:x})")
 
     def set_profiling(self, on=True):
         _lib.lib().swd_pipeline_set_profiling(self._h, 1 if on else 0)

@@ -1,0 +1,63 @@
+"""bench.py's own multi-process path on CPU: `python bench.py --gpus 2` without a torch.distributed.run environment
+has to start two ranks itself, shard the shots, gather every rank's decisions and print ONE line with n_gpus = 2.
+SWD_BENCH_STUB=1 swaps the device pipeline for a stand-in (gloo backend) -- the launcher, sharding, gather, timing
+bracket and JSON contract are the code under test, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env_extra=None, timeout=300):
+    env = dict(os.environ, SWD_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_self_launch_two_ranks_weak():
+    r, lines = run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--shots", "50")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout  # only rank 0 prints
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["warmup"] == 1
+    assert j["config"]["world_size"] == 2 and j["config"]["shots_total"] == 100 and j["config"]["gather_ok"]
+    assert j["value"] > 0 and abs(j["timed_region_s"] * 1e3 / 3 - j["ms_per_step"]) < 1e-6
+    assert "stub" in j["data"]
+
+
+def test_self_launch_strong_scaling_uneven_shards():
+    r, lines = run_bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--scaling", "strong", "--total-shots", "101")
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["shots_total"] == 101 and j["config"]["shots_this_rank"] == 51 and j["config"]["gather_ok"]
+
+
+def test_single_process_default():
+    r, lines = run_bench("--steps", "2", "--warmup", "1", "--shots", "10")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert lines[0]["n_gpus"] == 1 and lines[0]["config"]["world_size"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    r, _ = run_bench("--gpus", "4", "--steps", "1", "--warmup", "0", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_refuses_more_gpus_than_visible():
+    """without the stub: this container has no GPU, so --gpus 2 must fail loudly instead of measuring one"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SWD_BENCH_STUB")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr
