@@ -60,7 +60,8 @@ class _Bp4Params(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        # SWD_ORACLE_SO: an alternative build of the same source, e.g. libswd_oracle_asan.so (tests/test_oracle_asan.py)
+        L = C.CDLL(os.environ.get("SWD_ORACLE_SO") or build())
         L.swo_bp4_create.restype = C.c_void_p
         L.swo_bp4_create.argtypes = [C.c_int] * 3 + [C.c_void_p] * 7 + [C.POINTER(_Bp4Params)]
         L.swo_bp4_free.argtypes = [C.c_void_p]

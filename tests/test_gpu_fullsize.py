@@ -27,3 +27,40 @@ def test_bb144_p004_full_batch_properties():
     assert np.array_equal(logical, dec.last_obs_flips != mask)  # the device's own accounting
     per_round = 1.0 - (1.0 - logical.mean()) ** (1.0 / 12)
     assert 1.1e-3 < per_round < 2.0e-3, per_round
+
+
+@pytest.mark.parametrize("order", [0, 10])
+def test_bb144_p003_headline_batch_properties(order):
+    """BASELINE configs[1] at its full size: [[144,12,12]], p = 0.003, (3,1), 4096 shots x 11 windows per launch,
+    OSD-CS order 0 (osd.py:160) and 10 (the notebooks' default).  Size-independent properties: every shot's committed
+    faults reproduce its detector data (flagged = 0, as in the reference's runs), the device's logical accounting
+    equals the host's, the per-window records are consistent, results do not depend on how the batch is cut, and the
+    logical error rate per round over 32 768 shots lands where the notebook's decoder of the same family does
+    (`Sliding Window OSD.ipynb:678-686`: 2.93e-4 with ldpc's BP+OSD-CS10; ours 2.4e-4 over 131 072 shots)."""
+    import bench
+    from slidingwindowdecoder_amd import DemSampler, SlidingWindowDecoder
+    plan = bench.build_problem(p=0.003)
+    sampler = DemSampler(plan.chk, plan.obs, plan.priors)
+    dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=order))
+    chk_t, obs_t = sp.csr_matrix(plan.chk).T.astype(np.int32), sp.csr_matrix(plan.obs).T.astype(np.int32)
+    wrong = 0
+    for batch in range(8):
+        det, obs = sampler.sample(4096, seed=20240318, first_shot=batch * 4096)
+        total = dec.decode(det)
+        assert not ((sp.csr_matrix(total) @ chk_t).toarray() % 2 != det).any()
+        assert not dec.last_flagged.any()
+        logical = ((sp.csr_matrix(total) @ obs_t).toarray() % 2 != obs).any(axis=1)
+        mask = (obs.astype(np.uint32) << np.arange(obs.shape[1], dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+        assert np.array_equal(logical, dec.last_obs_flips != mask)
+        wrong += int(logical.sum())
+        st = dec.last_stats
+        cls, conv = st[..., 0] & 0xFF, (st[..., 0] & 0x100) != 0
+        assert set(np.unique(cls)) <= {0, 1, 2}                       # no failed decimation / peel / scheduling fault
+        assert (conv == (cls < 2)).all()                              # converge flag <=> a BP exit
+        assert (st[..., 1] == st[..., 2] + st[..., 3]).all()          # bp_iteration = pre + post
+        assert (st[..., 2][cls == 0] <= 8).all() and (st[..., 2][cls > 0] == 8).all()
+        assert (st[..., 3][cls == 2] == 200).all() and (st[..., 3][cls == 0] == 0).all()
+        if batch == 0:  # idempotence under re-batching: the first 1000 shots alone give the same corrections
+            assert np.array_equal(dec.decode(det[:1000]), total[:1000])
+    per_round = 1.0 - (1.0 - wrong / 32768.0) ** (1.0 / 12)
+    assert 1.0e-4 < per_round < 4.5e-4, per_round
