@@ -125,6 +125,12 @@ typedef struct swd_gdg_params {
     int32_t new_n;               /* <=0: min(n, 2m) */
     int32_t low_error_mode;
     int32_t mode;                /* 0 bpgdg_decoder, 1 bpgd_decoder, 2 bp_history_decoder */
+    int32_t multi_thread;        /* bpgdg_decoder(multi_thread=True): the hypothesis ensemble of bpgd.cpp:419-688 -- every
+                                    leaf of the decimation tree counts (no min_converge_depth pruning, no snapshot cap),
+                                    smallest path metric wins, ties to the earliest in stack order.  Deterministic here;
+                                    the reference's threaded version is racy, so this mode is no parity target.  0: the
+                                    single-thread gdg() semantics (bit-exact).  Either way the side branches of one
+                                    shot run concurrently on different workgroups. */
 } swd_gdg_params;
 
 typedef struct swd_gdg swd_gdg;
@@ -235,7 +241,8 @@ int swd_pipeline_decode_dev(swd_pipeline *pl, int32_t B, const uint8_t *det, int
                             int32_t *shot_result, void *stream);
 /* Scheduling-fault flags accumulated by every launch of this pipeline since the last call, read and cleared
  * (0 = none; bit 0: a window waited more than 10 s for its predecessor window of the same shot, which cannot
- * happen by construction -- its statistics record SWD_EXIT_SCHED_FAULT).  Synchronises the device, so call it
+ * happen by construction -- its statistics record SWD_EXIT_SCHED_FAULT; bit 1: a workgroup of the guessing decoders'
+ * work-item loop found nothing to do for 20 s while units were still outstanding and left -- results incomplete).  Synchronises the device, so call it
  * after the asynchronous swd_pipeline_decode_dev launches it should cover; swd_pipeline_decode checks it itself. */
 int swd_pipeline_status(swd_pipeline *pl, uint32_t *flags);
 

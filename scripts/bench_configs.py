@@ -30,6 +30,7 @@ def run_pipeline(name, plan, shots, reps, **kw):
         dec.decode_device(d, stats=stats)
     torch.cuda.synchronize()
     ms, n = dec.get_timing()
+    dec.check_status()  # raises on a scheduling fault
     st = stats.cpu().numpy()
     conv = ((st[..., 0] & 0x100) != 0).mean()
     print(json.dumps({"config": name, "shots": shots, "windows_per_shot": dec.W, "ms_per_launch": ms / n,

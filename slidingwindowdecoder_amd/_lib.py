@@ -35,7 +35,7 @@ class GdgParams(C.Structure):
                 ("max_step", C.c_int32), ("max_tree_depth", C.c_int32), ("max_side_depth", C.c_int32),
                 ("max_tree_branch_step", C.c_int32), ("max_side_branch_step", C.c_int32),
                 ("gdg_factor", C.c_double), ("new_n", C.c_int32), ("low_error_mode", C.c_int32),
-                ("mode", C.c_int32)]
+                ("mode", C.c_int32), ("multi_thread", C.c_int32)]
 
 
 class Bp4Params(C.Structure):

@@ -5,16 +5,134 @@
 // with the BPGD engine of /root/reference/src/include/bpgd.cpp (reset 199-239, min_sum_log 97-197,
 // vn_set_value 51-80, peel 13-49, set_masks 241-248, get_pm 250-256, decimate_vn_reliable 258-286).
 //
-// One workgroup per shot.  The decimation tree of a shot is explored in exactly the reference's
-// order (main branch, then the saved snapshots in stack order with the min_converge_depth pruning),
-// because that order decides which hypothesis wins; the parallelism is inside each BP block and
-// across shots.  The multi-thread ensemble of the reference is racy and is not a
-// parity target.
+// The decimation tree of a (shot, window) is explored with the RESULT of the reference's order (main branch,
+// then the saved snapshots in stack order with the min_converge_depth pruning), because that order decides
+// which hypothesis wins.  Two execution forms:
+//   serial    one workgroup walks the whole tree in that order (decode_window_gdg, phase 2 below);
+//   parallel  the owner workgroup runs the main branch, then every saved snapshot becomes a task on the
+//             persistent grid's queue (gdg_run_task, any workgroup): a side branch run with the most permissive
+//             pruning state (min_converge_depth as it was after the main branch) does a superset of what the
+//             serial order would do with it -- BP blocks and decimations of a branch depend on nothing outside
+//             the branch; only "is a snapshot pushed here" and "stop here" depend on the evolving
+//             min_converge_depth / snapshot count.  Every step's outcome is recorded and the owner replays the
+//             serial bookkeeping (gdg_replay: pruning, capacity, strict-< arg-min in stack order) over the
+//             records, so the returned vector, converge flag and statistics are those of the serial order.
+// The reference's multi-thread ensemble (bpgd.cpp:419-688, row a23) explores all leaves concurrently and keeps
+// the smallest path metric; it is racy and no parity target.  `ensemble` replays the same
+// records without pruning / capacity: every hypothesis counts, ties to the earliest in stack order.
 //
 // The sub-matrix "pcm" of BPGD::reset (first new_n columns in sorted order) is never built: the
 // selected columns keep their slots in the window graph, `pos_lv[j]` = column at sorted position j,
 // and every scan that the reference does "for vn in range(new_n)" runs over positions.
 #pragma once
+
+#define SWD_GDG_SLOTS 64     // snapshots per (shot, window) the parallel form can hold; beyond: serial fallback
+#define SWD_GDG_MAXSTEP 64   // max_side_branch_step the parallel form records
+#define SWD_GDG_REC_BYTES (16 + 4 * SWD_GDG_MAXSTEP)
+#define SWD_GDG_HDR_BYTES 256
+
+// agent-scope (sc1) word accesses: everything one workgroup publishes for another goes through these
+__device__ __forceinline__ uint32_t ag_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all stores of this workgroup are acknowledged; then a barrier (callers publish a counter / queue entry after it)
+__device__ __forceinline__ void ag_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+}
+
+// Work items of the persistent grid in the parallel form (32-bit payloads of the launch's queue):
+//   UNIT  (shot, window)   decode the window: pre-processing BP and the main branch; a tree with side branches is
+//                          parked in a context (below) and the workgroup goes on to other items
+//   SIDE  (context, slot)  one side branch of a parked tree
+//   FINAL (context)        every branch of the tree is accounted for: pick the winner, commit, hand the shot on
+// Nothing ever waits for another item: a unit is queued when its predecessor window has committed, a FINAL when the
+// last branch has been replayed.
+#define SWD_ITEM_UNIT 0u
+#define SWD_ITEM_SIDE 1u
+#define SWD_ITEM_FINAL 2u
+#define SWD_ITEM_NONE 0xFFFFFFFEu
+#define SWD_ITEM_EXIT 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t item_unit(int b, int wi) { return (SWD_ITEM_UNIT << 30) | ((uint32_t)wi << 22) | (uint32_t)b; }
+__device__ __forceinline__ uint32_t item_side(int ctxid, int slot) { return (SWD_ITEM_SIDE << 30) | ((uint32_t)ctxid << 8) | (uint32_t)slot; }
+__device__ __forceinline__ uint32_t item_final(int ctxid) { return (SWD_ITEM_FINAL << 30) | (uint32_t)ctxid; }
+
+// Context of a parked tree in HBM (SwdGdgPar::ctx + id * ctx_stride; ids come from the free ring), 32-bit words:
+//   hdr  0 lock  1 -  2 snapshot slots allocated  3 overflow
+//        4 window  5 shot  6 dead_unsat  7 published bound on min_converge_depth (side branches prune against it)
+//        scheduler state, touched only under the lock:  8 frontier i  9 nseq  10 used_guess  11 min_converge_depth
+//        12 converge  13 BP blocks  14 iterations  15 best slot  16,17 min_pm  18 tasks launched  19 tasks finished
+//        20,21 launched mask  22 FINAL queued  23 min_converge_depth after the main branch
+//        24 pre-processing iterations  25 snapshots of the main branch  26..41 seq[64]: slots in serial stack order
+//   pos  u16 pos_lv[new_n] (packed)            rec   SWD_GDG_SLOTS records of SWD_GDG_REC_BYTES:
+//     w0 = alt_depth | dec_val << 8 | (dec_vn + 1) << 16
+//     w1 = start_failed | done << 1 | pruned_before_start << 2 | nsteps << 8 | (conv_step + 1) << 16   (written last)
+//     w2,w3 = path metric of the converged block               w4.. per step: iterations | fail_before_push << 8 |
+//     fail_after_push << 9 | (child slot + 1) << 16
+//   err   (SWD_GDG_SLOTS + 1) error vectors by position (slot SWD_GDG_SLOTS = the main branch's)
+//   the snapshots of the tree: SwdGdgPar::csnap + id * csnap_stride
+struct GdgCtx {
+    uint32_t *hdr, *pos, *rec, *err;
+    uint8_t *snap;
+    int err_words; // words per error vector
+};
+__device__ __forceinline__ GdgCtx gdg_ctx(const SwdGdgPar &gp, int id) {
+    uint8_t *b = gp.ctx + (int64_t)id * gp.ctx_stride;
+    GdgCtx c;
+    c.hdr = (uint32_t *)b; c.pos = (uint32_t *)(b + gp.off_pos); c.rec = (uint32_t *)(b + gp.off_rec);
+    c.err = (uint32_t *)(b + gp.off_err); c.err_words = gp.err_stride >> 2;
+    c.snap = gp.csnap + (int64_t)id * gp.csnap_stride;
+    return c;
+}
+__device__ __forceinline__ uint32_t *gdg_rec(const GdgCtx &c, int slot) { return c.rec + slot * (SWD_GDG_REC_BYTES / 4); }
+
+#ifdef SWD_GDG_DEBUG // diagnostic build: counters in the decoder's status array (words 1..)
+#define GDG_COUNT(word, v) atomicAdd(&dbg_status[word], (uint32_t)(v))
+#else
+#define GDG_COUNT(word, v) do { } while (0)
+#endif
+#ifdef SWD_GDG_CHECKS // diagnostic build: invariant violations are reported in the status word (bits 8..) instead of followed
+#define GDG_CHECK(cond, code) do { if (!(cond)) atomicOr(chk_status, 1u << (8 + (code))); } while (0)
+#else
+#define GDG_CHECK(cond, code) do { } while (0)
+#endif
+
+// multi-producer multi-consumer ring: r[0] head, r[1] tail, r[2], r[3] free for the user, then (sequence << 32 | payload)
+__device__ __forceinline__ void ring_push(uint32_t *r, uint32_t mask, uint32_t payload) { // one thread
+    const uint32_t t = atomicAdd(&r[1], 1u);
+    unsigned long long *ring = (unsigned long long *)(r + 4);
+    __hip_atomic_store(&ring[t & mask], ((unsigned long long)(t + 1u) << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Blocking pop: the consumer takes the next sequence number unconditionally (no compare-and-swap race among idle
+// consumers: with hundreds of idle workgroups contending for every item a CAS loop starved single workgroups for
+// milliseconds) and waits on ITS OWN ring slot until a producer fills it.  Every waiter is eventually served: the
+// workgroup that completes the launch's last unit pushes one SWD_ITEM_EXIT per workgroup.  A 20 s bound (100 MHz
+// ticks) turns a bug into SWD_ITEM_EXIT + a status flag instead of a hung device.
+__device__ __forceinline__ uint32_t ring_pop_wait(uint32_t *r, uint32_t mask, uint32_t *status) { // one thread
+    const uint32_t h = atomicAdd(&r[0], 1u);
+    unsigned long long *ring = (unsigned long long *)(r + 4);
+    unsigned long long e;
+    const long long t0 = wall_clock64();
+    while ((uint32_t)((e = __hip_atomic_load(&ring[h & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != h + 1u) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 2000000000ll) { atomicOr(status, 2u); return 0xFFFFFFFFu; }
+    }
+    return (uint32_t)e;
+}
+
+__device__ __forceinline__ int ring_pop(uint32_t *r, uint32_t mask, uint32_t *payload) { // one thread; 0 if empty (free-context ring)
+    for (;;) {
+        const uint32_t h = ag_ld(&r[0]), t = ag_ld(&r[1]);
+        if ((int32_t)(t - h) <= 0) return 0;
+        if (atomicCAS(&r[0], h, h + 1u) != h) continue;
+        unsigned long long *ring = (unsigned long long *)(r + 4);
+        unsigned long long e;
+        while ((uint32_t)((e = __hip_atomic_load(&ring[h & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != h + 1u)
+            __builtin_amdgcn_s_sleep(2);
+        *payload = (uint32_t)e;
+        return 1;
+    }
+}
 
 struct GdgLds {
     uint16_t *pos_lv;  // [new_n] sorted position -> column
@@ -133,15 +251,29 @@ __device__ __forceinline__ double gdg_get_pm(const SwdGraphDev &g, Lds &s, const
 // Snapshot record in HBM: vn state by position | cn_val | cn_deg | livemask
 __device__ __forceinline__ int64_t gdg_snap_bytes(int m, int new_n) { return ((new_n + 2 * m + 7) & ~7) + 8 * (int64_t)m; }
 
+// written and read with agent-scope word accesses: in the parallel form another workgroup (another XCD) reads it
 template <int NT>
 __device__ __forceinline__ void gdg_snap_save(const SwdGraphDev &g, Lds &s, const GdgLds &G, uint8_t *rec) {
     const int m = g.m, new_n = g.new_n;
-    for (int j = threadIdx.x; j < new_n; j += NT) rec[j] = (uint8_t)s.vn_val[G.pos_lv[j]];
-    uint64_t *lm = (uint64_t *)(rec + ((new_n + 2 * m + 7) & ~7));
+    const int nb = (new_n + 2 * m + 7) & ~7;
+    uint32_t *w = (uint32_t *)rec;
+    for (int i = threadIdx.x; i < nb / 4; i += NT) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = 4 * i + k;
+            uint32_t byte = 0;
+            if (q < new_n) byte = (uint8_t)s.vn_val[G.pos_lv[q]];
+            else if (q < new_n + m) byte = (uint8_t)s.cn_val[q - new_n];
+            else if (q < new_n + 2 * m) byte = s.cn_deg[q - new_n - m];
+            x |= byte << (8 * k);
+        }
+        ag_st(&w[i], x);
+    }
+    uint32_t *lm = w + nb / 4;
     for (int l = threadIdx.x; l < m; l += NT) {
-        rec[new_n + l] = (uint8_t)s.cn_val[l];
-        rec[new_n + m + l] = s.cn_deg[l];
-        lm[l] = s.livemask[l];
+        const uint64_t v = s.livemask[l];
+        ag_st(&lm[2 * l], (uint32_t)v); ag_st(&lm[2 * l + 1], (uint32_t)(v >> 32));
     }
 }
 
@@ -150,19 +282,22 @@ __device__ __forceinline__ void gdg_snap_save(const SwdGraphDev &g, Lds &s, cons
 template <int NT>
 __device__ __forceinline__ void gdg_snap_load(const SwdGraphDev &g, Lds &s, const GdgLds &G, const uint8_t *rec) {
     const int m = g.m, new_n = g.new_n;
+    const int nb = (new_n + 2 * m + 7) & ~7;
+    const uint32_t *w = (const uint32_t *)rec;
     __syncthreads();
-    for (int j = threadIdx.x; j < new_n; j += NT) {
-        const int v = G.pos_lv[j];
-        const int8_t val = (int8_t)rec[j];
-        s.vn_val[v] = val;
-        s.hard[v] = (val == 1) ? 1 : 0;
+    for (int i = threadIdx.x; i < nb / 4; i += NT) {
+        const uint32_t x = ag_ld(&w[i]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = 4 * i + k;
+            const int8_t val = (int8_t)(uint8_t)(x >> (8 * k));
+            if (q < new_n) { const int v = G.pos_lv[q]; s.vn_val[v] = val; s.hard[v] = (val == 1) ? 1 : 0; }
+            else if (q < new_n + m) s.cn_val[q - new_n] = val;
+            else if (q < new_n + 2 * m) s.cn_deg[q - new_n - m] = (uint8_t)val;
+        }
     }
-    const uint64_t *lm = (const uint64_t *)(rec + ((new_n + 2 * m + 7) & ~7));
-    for (int l = threadIdx.x; l < m; l += NT) {
-        s.cn_val[l] = (int8_t)rec[new_n + l];
-        s.cn_deg[l] = rec[new_n + m + l];
-        s.livemask[l] = lm[l];
-    }
+    const uint32_t *lm = w + nb / 4;
+    for (int l = threadIdx.x; l < m; l += NT) s.livemask[l] = (uint64_t)ag_ld(&lm[2 * l]) | ((uint64_t)ag_ld(&lm[2 * l + 1]) << 32);
     __syncthreads();
 }
 
@@ -170,10 +305,18 @@ __device__ __forceinline__ void gdg_snap_load(const SwdGraphDev &g, Lds &s, cons
 // Classification of a position is independent of the scan order (num_flip only looks at active
 // neighbour checks, and a live VN has no inactive ones), the decimations are applied by wave 0 in
 // position order so that a contradiction stops exactly where the reference's scan stops.
+// sp != nullptr (a side branch run as a task): min_converge_depth is a bound at least as permissive as the serial
+// order's value at this point, the snapshot slot comes from the tree's shared counter instead of used_guess / max_guess,
+// and what happened is reported in sp (the scheduler's replay decides what counts and queues the child in its turn).
+struct GdgSpec {
+    GdgCtx ctx;
+    int fail_before, fail_after, child; // out
+};
+
 template <int NT>
 __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                              const double *hist_b, bool side, int depth, int min_converge_depth,
-                                             int &used_guess, uint8_t *snap_b) {
+                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr) {
     const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
     const double A = side ? 0.0 : -3.0;
     double A_sum = side ? -10.0 : -12.0;
@@ -245,7 +388,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();
-        if (s.scal[1]) return -1;
+        if (s.scal[1]) { if (sp) sp->fail_before = 1; return -1; }
     }
     int guess_pos, favor;
     if (pos_neg != 0x7fffffff) { guess_pos = pos_neg; favor = 1; }
@@ -254,7 +397,24 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
     if (depth > min_converge_depth) guess = false;
     if (!side && depth >= P.max_side_depth) guess = false;
     if (side && depth > P.max_tree_depth) guess = false;
-    if (guess && used_guess < P.max_guess) {
+    if (guess && sp) {
+        __syncthreads();
+        if (tid == 0) s.iaux[4] = (int)atomicAdd(&sp->ctx.hdr[2], 1u);
+        __syncthreads();
+        const int slot = s.iaux[4];
+        if (slot >= SWD_GDG_SLOTS) {
+            if (tid == 0) ag_st(&sp->ctx.hdr[3], 1u); // more snapshots than the context holds: the unit is redone serially
+        } else {
+            if (tid == 0) {
+                uint32_t *r = gdg_rec(sp->ctx, slot);
+                ag_st(&r[0], (uint32_t)(depth + 1) | ((uint32_t)(uint8_t)(1 - favor) << 8) |
+                                 ((uint32_t)(uint16_t)((guess_pos == 0x7fffffff ? -1 : guess_pos) + 1) << 16));
+                ag_st(&r[1], 0u);
+            }
+            gdg_snap_save<NT>(g, s, G, sp->ctx.snap + (int64_t)slot * gdg_snap_bytes(g.m, new_n));
+            sp->child = slot;
+        }
+    } else if (guess && used_guess < P.max_guess) {
         if (tid == 0) {
             G.dec_val[used_guess] = (int8_t)(1 - favor);
             G.dec_vn[used_guess] = (int16_t)(guess_pos == 0x7fffffff ? -1 : guess_pos);
@@ -263,6 +423,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
         gdg_snap_save<NT>(g, s, G, snap_b + (int64_t)used_guess * gdg_snap_bytes(g.m, new_n));
         used_guess += 1;
     }
+    if (sp) sp->fail_after = 1; // cleared below when the favoured value goes through
     if (guess_pos == 0x7fffffff) return -1; // no candidate left (the reference would index vn_mask[-1])
     __syncthreads();
     if (tid < 64) {
@@ -271,6 +432,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
         if (tid == 0) s.scal[1] = bad ? 1 : 0;
     }
     __syncthreads();
+    if (sp && !s.scal[1]) sp->fail_after = 0;
     return s.scal[1] ? -1 : 0;
 }
 
@@ -301,11 +463,282 @@ __device__ __forceinline__ int gdg_decimate_reliable(const SwdGraphDev &g, Lds &
     return s.scal[1] ? -1 : 0;
 }
 
+// error vector of the current hypothesis by position, packed four per word, to the owner's context
+template <int NT>
+__device__ __forceinline__ void gdg_store_err(Lds &s, const GdgLds &G, int new_n, uint32_t *dst) {
+    for (int i = threadIdx.x; i < (new_n + 3) / 4; i += NT) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int q = 4 * i + k; if (q < new_n) x |= (uint32_t)(s.hard[G.pos_lv[q]] ? 1 : 0) << (8 * k); }
+        ag_st(&dst[i], x);
+    }
+}
+
+// The serial bookkeeping of bpgdg_decoder.gdg's second phase (bp_guessing_decoder.pyx:301-335), run incrementally over
+// the branch records of a parked tree by whoever holds the tree's lock: advance the frontier over the records that
+// are complete, in serial stack order (which snapshots the serial order would have run / pushed / pruned, which
+// hypothesis wins -- strict "<" on the path metric), queue the next branches in that order (at most inflight_max of a
+// tree at a time: speculation beyond the frontier is bounded), publish the current min_converge_depth as the
+// pruning bound for running branches, and queue the tree's FINAL item when every record is accounted for.
+__device__ __forceinline__ bool gdg_sched_step(const SwdGdgPar &gp, const SwdDecodeParams &P, const GdgCtx &c, int ctxid) {
+    uint32_t *h = c.hdr;
+    int i = (int)ag_ld(&h[8]), nseq = (int)ag_ld(&h[9]), used = (int)ag_ld(&h[10]), mcd = (int)ag_ld(&h[11]);
+    int converge = (int)ag_ld(&h[12]), blocks = (int)ag_ld(&h[13]), post_it = (int)ag_ld(&h[14]), best = (int)ag_ld(&h[15]);
+    double min_pm = __longlong_as_double((long long)((unsigned long long)ag_ld(&h[16]) | ((unsigned long long)ag_ld(&h[17]) << 32)));
+    int launched = (int)ag_ld(&h[18]);
+    unsigned long long lmask = (unsigned long long)ag_ld(&h[20]) | ((unsigned long long)ag_ld(&h[21]) << 32);
+    const int finalp = (int)ag_ld(&h[22]), mcd0 = (int)ag_ld(&h[23]);
+#ifdef SWD_GDG_CHECKS
+    uint32_t *chk_status = gp.chk_status;
+#endif
+    GDG_CHECK(!finalp, 0);                                  // scheduler run after the FINAL item was queued
+    GDG_CHECK(nseq >= 0 && nseq <= SWD_GDG_SLOTS && i >= 0 && i <= nseq, 1);
+    GDG_CHECK(launched >= (int)ag_ld(&h[19]), 2);
+    GDG_CHECK(ag_ld(&h[1]) == 1u, 3);                       // context state: 1 = owned by a parked tree
+    if (finalp) return false;
+    const bool ens = gp.ensemble != 0;
+    uint32_t seqw[SWD_GDG_SLOTS / 4];
+#pragma unroll
+    for (int k = 0; k < SWD_GDG_SLOTS / 4; ++k) seqw[k] = ag_ld(&h[26 + k]);
+    auto seq_get = [&](int k) { return (int)((seqw[k >> 2] >> (8 * (k & 3))) & 0xFFu); };
+    auto seq_set = [&](int k, int v) { seqw[k >> 2] = (seqw[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)v << (8 * (k & 3))); };
+    const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
+    while (i < nseq) {
+        const uint32_t *r = gdg_rec(c, seq_get(i));
+        const int alt = (int)(ag_ld(&r[0]) & 0xFFu);
+        if (alt > (ens ? mcd0 : mcd)) { ++i; continue; } // pruned by the serial order (a running copy is ignored)
+        const uint32_t w1 = ag_ld(&r[1]);
+        if (!(w1 & 2u)) break; // not finished yet: the frontier stops here
+        if (!(w1 & 5u)) {      // the decision and the peeling after it went through
+            const int nsteps = (int)((w1 >> 8) & 0xFFu), conv = (int)((w1 >> 16) & 0xFFu) - 1;
+            for (int j = 0; j < maxj && j < nsteps; ++j) {
+                const uint32_t sw = ag_ld(&r[4 + j]);
+                const int depth = alt + j;
+                ++blocks; post_it += (int)(sw & 0xFFu);
+                if (conv == j) {
+                    converge = 1;
+                    const double pm = __longlong_as_double((long long)((unsigned long long)ag_ld(&r[2]) | ((unsigned long long)ag_ld(&r[3]) << 32)));
+                    if (pm < min_pm) {
+                        if (depth < mcd) mcd = depth;
+                        best = seq_get(i);
+                        min_pm = pm;
+                    }
+                    break;
+                }
+                if (depth > (ens ? mcd0 : mcd) + 2) break;
+                if (sw & 0x100u) break; // select_vn failed before its snapshot
+                const bool guess = !(depth > (ens ? mcd0 : mcd)) && !(depth > P.max_tree_depth);
+                if (guess && (ens || used < P.max_guess)) {
+                    const int child = (int)((sw >> 16) & 0xFFu) - 1;
+                    if (child >= 0 && nseq < SWD_GDG_SLOTS) { seq_set(nseq, child); ++nseq; }
+                    ++used;
+                }
+                if (sw & 0x200u) break; // ... or after it
+            }
+        }
+        ++i;
+    }
+    const int fin = (int)ag_ld(&h[19]);
+    for (int k = i; k < nseq && launched - fin < gp.inflight_max; ++k) {
+        const int b = seq_get(k);
+        if ((lmask >> b) & 1ull) continue;
+        if ((int)(ag_ld(&gdg_rec(c, b)[0]) & 0xFFu) > (ens ? mcd0 : mcd)) continue;
+        GDG_CHECK(b >= 0 && b < SWD_GDG_SLOTS, 4);
+        lmask |= 1ull << b; ++launched;
+        ring_push(gp.q, gp.qmask, item_side(ctxid, b));
+    }
+    const bool complete = (i == nseq) && (launched == fin);
+    ag_st(&h[8], (uint32_t)i); ag_st(&h[9], (uint32_t)nseq); ag_st(&h[10], (uint32_t)used); ag_st(&h[11], (uint32_t)mcd);
+    ag_st(&h[12], (uint32_t)converge); ag_st(&h[13], (uint32_t)blocks); ag_st(&h[14], (uint32_t)post_it); ag_st(&h[15], (uint32_t)best);
+    const unsigned long long pb = (unsigned long long)__double_as_longlong(min_pm);
+    ag_st(&h[16], (uint32_t)pb); ag_st(&h[17], (uint32_t)(pb >> 32));
+    ag_st(&h[18], (uint32_t)launched); ag_st(&h[20], (uint32_t)lmask); ag_st(&h[21], (uint32_t)(lmask >> 32));
+#pragma unroll
+    for (int k = 0; k < SWD_GDG_SLOTS / 4; ++k) ag_st(&h[26 + k], seqw[k]);
+    ag_st(&h[7], (uint32_t)(ens ? mcd0 : mcd));
+    if (complete) ag_st(&h[22], 1u);
+    return complete;
+}
+
+// Run the scheduler of a tree (one thread).  The lock is a short spin lock: every holder is a running workgroup that
+// leaves after one step.  A finishing side branch counts itself as finished INSIDE the critical section, so the step
+// that sees "every launched branch finished" is the last access any branch makes to the context; the FINAL item is
+// queued after the lock is open, and nothing touches the context after that but the FINAL handler (which frees it).
+__device__ __forceinline__ void gdg_sched(const SwdGdgPar &gp, const SwdDecodeParams &P, const GdgCtx &c, int ctxid, bool finished_one) {
+    while (atomicCAS(&c.hdr[0], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    if (finished_one) ag_st(&c.hdr[19], ag_ld(&c.hdr[19]) + 1u);
+    const bool complete = gdg_sched_step(gp, P, c, ctxid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state is written back before the lock opens
+    ag_st(&c.hdr[0], 0u);
+    if (complete) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ring_push(gp.q, gp.qmask, item_final(ctxid));
+    }
+}
+
+// One side branch (a saved snapshot) of a parked tree, run by whichever workgroup popped the item.  Uses the
+// workgroup's LDS from scratch and its own history scratch; reads the tree's context / snapshot, writes the branch
+// record back and runs the tree's scheduler.
+template <int NT, int VF, int DM, int KG>
+__device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, uint32_t payload, int ctid, int vtid) {
+    const int tid = threadIdx.x;
+    const SwdGdgPar &gp = a.gdgp;
+    const int ctxid = (int)((payload >> 8) & 0x3FFFFFu), slot = (int)(payload & 0xFFu);
+#ifdef SWD_GDG_DEBUG
+    uint32_t *dbg_status = gp.chk_status;
+    const long long dbg_t0 = wall_clock64();
+#endif
+    GdgSpec sp;
+    sp.ctx = gdg_ctx(gp, ctxid);
+#ifdef SWD_GDG_CHECKS
+    uint32_t *chk_status = gp.chk_status;
+    GDG_CHECK(ctxid >= 0 && ctxid < gp.nctx && slot < SWD_GDG_SLOTS, 5);
+    GDG_CHECK(ag_ld(&sp.ctx.hdr[1]) == 1u, 6);             // the context is owned by a parked tree
+    GDG_CHECK((int)ag_ld(&sp.ctx.hdr[4]) < a.W && (int)ag_ld(&sp.ctx.hdr[5]) < a.B, 7);
+    GDG_CHECK((ag_ld(&gdg_rec(sp.ctx, slot)[1]) & 2u) == 0u, 8); // this branch has not run before
+    if (!(ctxid >= 0 && ctxid < gp.nctx && slot < SWD_GDG_SLOTS && (int)ag_ld(&sp.ctx.hdr[4]) < a.W)) return;
+#endif
+    const int wi = (int)ag_ld(&sp.ctx.hdr[4]);
+    const bool dead_unsat = ag_ld(&sp.ctx.hdr[6]) != 0u;
+    const SwdWindowDev &w = a.wins[wi];
+    const SwdGraphDev &g = w.g;
+    const SwdLdsLayout &L = w.L;
+    const SwdDecodeParams &P = a.P;
+    const int m = g.m, n = g.n, new_n = g.new_n;
+    uint32_t *rec = gdg_rec(sp.ctx, slot);
+    const uint32_t w0 = ag_ld(&rec[0]);
+    const int alt = (int)(w0 & 0xFFu), dval = (int)(int8_t)(uint8_t)(w0 >> 8), gpos = (int)(w0 >> 16) - 1;
+    int nsteps = 0, conv_step = -1;
+    double pm = 0.0;
+    bool start_failed = false;
+    // The pruning bound changes while branches run (the scheduler lowers it): ONE thread reads it and the workgroup
+    // takes that value, or its threads would disagree about leaving the loop.  bcast: two words below the syndrome bytes.
+    const int bound_word = gp.static_bound ? 23 : 7; // diagnostics: prune against the main branch's value only
+    uint32_t *bcast = (uint32_t *)(smem + a.off_det) - 4 + 1;
+    __syncthreads();
+    if (tid == 0) *bcast = ag_ld(&sp.ctx.hdr[bound_word]);
+    __syncthreads();
+    const bool pruned = alt > (int)*bcast; // the serial order has already passed this snapshot by
+    if (!pruned) {
+        Lds s;
+        lds_bind(s, smem, L);
+        s.fpar = 0; s.ctid = ctid; s.vtid = vtid;
+        GdgLds G;
+        gdg_bind(G, s.scratch, L, n, new_n);
+        double *hist_b = a.hist + (int64_t)blockIdx.x * a.hist_stride;
+        __syncthreads();
+        for (int l = tid; l < m; l += NT) s.cn_deg0[l] = g.row_deg[l];
+        for (int v = tid; v < n; v += NT) { s.vn_val[v] = 0; s.hard[v] = 0; }
+        for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
+        for (int i = tid; i < (new_n + 1) / 2; i += NT) {
+            const uint32_t x = ag_ld(&sp.ctx.pos[i]);
+            G.pos_lv[2 * i] = (uint16_t)x;
+            if (2 * i + 1 < new_n) G.pos_lv[2 * i + 1] = (uint16_t)(x >> 16);
+        }
+        if (P.max_iter_per_step < 4)
+            for (int i = P.max_iter_per_step * n + tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
+        gdg_snap_load<NT>(g, s, G, sp.ctx.snap + (int64_t)slot * gdg_snap_bytes(m, new_n));
+        if (tid < 64) {
+            bool bad = (gpos < 0) ? true : gdg_set_value_wave(g, s, G.pos_lv[gpos], dval);
+            if (!bad) bad = peel_wave(g, s);
+            if (tid == 0) s.scal[1] = bad ? 1 : 0;
+        }
+        __syncthreads();
+        start_failed = s.scal[1] != 0;
+        if (!start_failed) {
+            VnCache<VF, DM> vc;
+            CnCache<KG> cn;
+            const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
+            for (int j = 0; j < maxj; ++j) {
+                const int depth = alt + j;
+                const int nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
+                if (j == 0) { bp_init<VF, DM>(s, vc); __syncthreads(); }
+                int it;
+                const int cv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+                uint32_t sw = (uint32_t)it & 0xFFu;
+                nsteps = j + 1;
+                if (cv) {
+                    pm = gdg_get_pm<NT>(g, s, G);
+                    gdg_store_err<NT>(s, G, new_n, sp.ctx.err + (int64_t)slot * sp.ctx.err_words);
+                    conv_step = j;
+                    if (tid == 0) ag_st(&rec[4 + j], sw);
+                    break;
+                }
+                // the bound is the serial order's min_converge_depth as far as the frontier has got: at least as
+                // permissive as the value the serial order has when it reaches this branch
+                __syncthreads();
+                if (tid == 0) *bcast = ag_ld(&sp.ctx.hdr[bound_word]);
+                __syncthreads();
+                const int bound = (int)*bcast;
+                if (depth > bound + 2) { if (tid == 0) ag_st(&rec[4 + j], sw); break; }
+                sp.fail_before = sp.fail_after = 0; sp.child = -1;
+                int dummy = 0;
+                const int rc = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, bound, dummy, nullptr, &sp);
+                sw |= (sp.fail_before ? 0x100u : 0u) | (sp.fail_after ? 0x200u : 0u) | ((uint32_t)(sp.child + 1) << 16);
+                if (tid == 0) ag_st(&rec[4 + j], sw);
+                if (rc == -1) break;
+            }
+        }
+    }
+    if (tid == 0) {
+        const unsigned long long pb = (unsigned long long)__double_as_longlong(pm);
+        ag_st(&rec[2], (uint32_t)pb); ag_st(&rec[3], (uint32_t)(pb >> 32));
+    }
+    ag_publish_barrier(); // the record's body, the error vector and the child snapshots are out ...
+    if (tid == 0) {
+        ag_st(&rec[1], (start_failed ? 1u : 0u) | 2u | (pruned ? 4u : 0u) | ((uint32_t)nsteps << 8) | ((uint32_t)(conv_step + 1) << 16));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ... before the record reads "done"
+#ifdef SWD_GDG_DEBUG
+        const long long dbg_t1 = wall_clock64();
+#endif
+        gdg_sched(gp, P, sp.ctx, ctxid, true);
+#ifdef SWD_GDG_DEBUG
+        GDG_COUNT(1, 1); GDG_COUNT(2, dbg_t1 - dbg_t0); GDG_COUNT(3, wall_clock64() - dbg_t1); GDG_COUNT(4, nsteps); GDG_COUNT(5, pruned ? 1 : 0);
+#endif
+    }
+    __syncthreads();
+}
+
+// FINAL item: the result of a parked tree.  Fills R and s.hard like decode_window_gdg would have; false if the tree's
+// snapshot area overflowed (the caller decodes the unit again in the serial form).
+template <int NT>
+__device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgCtx &c, WinResult &R) {
+    const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
+    if (ag_ld(&c.hdr[3]) != 0u) return false;
+    R = WinResult{};
+    R.exit_class = SWD_EXIT_POST;
+    R.conv = (int)ag_ld(&c.hdr[12]);
+    R.pm = __longlong_as_double((long long)((unsigned long long)ag_ld(&c.hdr[16]) | ((unsigned long long)ag_ld(&c.hdr[17]) << 32)));
+    R.pre_it = (int)ag_ld(&c.hdr[24]); R.post_it = (int)ag_ld(&c.hdr[14]); R.total_it = R.pre_it + R.post_it;
+    R.live_vn = (int)ag_ld(&c.hdr[10]); R.live_cn = (int)ag_ld(&c.hdr[13]); R.live_e = (int)ag_ld(&c.hdr[11]);
+    R.osd_rowadds = (int)ag_ld(&c.hdr[25]); // statistics word 7: snapshots of the main branch that became tasks (0 in the serial form)
+    const int best = (int)ag_ld(&c.hdr[15]);
+    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+    __syncthreads();
+    const uint32_t *ev = c.err + (int64_t)best * c.err_words;
+    for (int i = tid; i < (new_n + 3) / 4; i += NT) {
+        const uint32_t x = ag_ld(&ev[i]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = 4 * i + k;
+            if (q < new_n && ((x >> (8 * k)) & 1u)) {
+                const uint32_t pw = ag_ld(&c.pos[q >> 1]);
+                s.hard[(q & 1) ? (pw >> 16) : (pw & 0xFFFFu)] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 // bpgdg_decoder.decode / bpgd_decoder.decode / bp_history_decoder for one syndrome.  On return
 // s.hard[0..n) is the returned vector.
+// par != nullptr (parallel form): a tree with side branches is parked in a context and its side branches are queued;
+// then R.exit_class = -2 on return and the result arrives later as a FINAL item (gdg_finalize).
 template <int NT, int VF, int DM, int KG>
 __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
-                                                  const uint8_t *synd, double *hist_b, uint8_t *snap_b, WinResult &R) {
+                                                  const uint8_t *synd, double *hist_b, uint8_t *snap_b, WinResult &R,
+                                                  const SwdPipeArgs *par = nullptr, uint32_t *acc = nullptr, int wi = 0, int b = 0) {
     const int tid = threadIdx.x, m = g.m, n = g.n, new_n = g.new_n;
     GdgLds G;
     gdg_bind(G, s.scratch, L, n, new_n);
@@ -404,6 +837,24 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     double min_pm = 10000.0;
     int used_guess = 0, min_converge_depth = P.max_step, converge = 0, blocks = 0;
     const bool gdg = (P.kind == 1);
+    // parallel form: the tree gets a context (snapshots, records) if one is free; without one it is walked serially
+    int ctxid = -1;
+    GdgCtx ctx{};
+    if (gdg && par) {
+        __syncthreads();
+        if (tid == 0) { uint32_t id = 0; acc[1] = ring_pop(par->gdgp.fq, par->gdgp.fmask, &id) ? id : 0xFFFFFFFFu; }
+        __syncthreads();
+        ctxid = (int)acc[1];
+        if (ctxid >= 0) { ctx = gdg_ctx(par->gdgp, ctxid); snap_b = ctx.snap; }
+#ifdef SWD_GDG_CHECKS
+        if (ctxid >= 0 && tid == 0) {
+            uint32_t *chk_status = par->gdgp.chk_status;
+            GDG_CHECK(ctxid < par->gdgp.nctx, 13);
+            const uint32_t st = atomicExch(&ctx.hdr[1], 3u);
+            GDG_CHECK(st != 1u && st != 3u, 14); // a context handed out while a parked tree or another main branch owns it
+        }
+#endif
+    }
     // ---- phase 1: main branch
     for (int depth = 0; depth < P.max_step; ++depth) {
         if (depth > 0) nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
@@ -422,8 +873,53 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     if (!converge)
         for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
     __syncthreads();
-    // ---- phase 2: side branches in stack order (pyx:301-335)
-    for (int i = 0; gdg && i < used_guess; ++i) {
+    // ---- phase 2, parallel form: park the tree, queue its side branches, go on with other work items
+    const bool replayed = false;
+    if (ctxid >= 0) {
+        const SwdGdgPar &gp = par->gdgp;
+        int ninit = 0;
+        for (int i = 0; i < used_guess; ++i) ninit += (G.alt_depth[i] <= min_converge_depth) ? 1 : 0;
+        if (ninit > 0 && P.max_side_branch_step > 0) {
+            uint32_t *h = ctx.hdr;
+            if (tid == 0) {
+                ag_st(&h[0], 0u); ag_st(&h[1], 1u); ag_st(&h[2], (uint32_t)used_guess); ag_st(&h[3], 0u);
+                ag_st(&h[4], (uint32_t)wi); ag_st(&h[5], (uint32_t)b); ag_st(&h[6], dead_unsat ? 1u : 0u);
+                ag_st(&h[7], (uint32_t)min_converge_depth);
+                ag_st(&h[8], 0u); ag_st(&h[9], (uint32_t)used_guess); ag_st(&h[10], (uint32_t)used_guess);
+                ag_st(&h[11], (uint32_t)min_converge_depth); ag_st(&h[12], (uint32_t)converge); ag_st(&h[13], (uint32_t)blocks);
+                ag_st(&h[14], (uint32_t)R.post_it); ag_st(&h[15], (uint32_t)SWD_GDG_SLOTS);
+                const unsigned long long pb = (unsigned long long)__double_as_longlong(min_pm);
+                ag_st(&h[16], (uint32_t)pb); ag_st(&h[17], (uint32_t)(pb >> 32));
+                ag_st(&h[18], 0u); ag_st(&h[19], 0u); ag_st(&h[20], 0u); ag_st(&h[21], 0u); ag_st(&h[22], 0u);
+                ag_st(&h[23], (uint32_t)min_converge_depth); ag_st(&h[24], (uint32_t)R.pre_it); ag_st(&h[25], (uint32_t)used_guess);
+            }
+            for (int k = tid; k < SWD_GDG_SLOTS / 4; k += NT) // serial stack order so far: the main branch's snapshots
+                ag_st(&h[26 + k], (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24));
+            for (int i = tid; i < (new_n + 1) / 2; i += NT)
+                ag_st(&ctx.pos[i], (uint32_t)G.pos_lv[2 * i] | ((2 * i + 1 < new_n) ? ((uint32_t)G.pos_lv[2 * i + 1] << 16) : 0u));
+            for (int i = tid; i < used_guess; i += NT) {
+                uint32_t *r = gdg_rec(ctx, i);
+                ag_st(&r[0], (uint32_t)(uint8_t)G.alt_depth[i] | ((uint32_t)(uint8_t)G.dec_val[i] << 8) | ((uint32_t)(uint16_t)(G.dec_vn[i] + 1) << 16));
+                ag_st(&r[1], 0u);
+            }
+            {   // the main branch's own result
+                uint32_t *dst = ctx.err + (int64_t)SWD_GDG_SLOTS * ctx.err_words;
+                for (int i = tid; i < (new_n + 3) / 4; i += NT) {
+                    uint32_t x = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int q = 4 * i + k; if (q < new_n) x |= (uint32_t)(G.best_err[q] ? 1 : 0) << (8 * k); }
+                    ag_st(&dst[i], x);
+                }
+            }
+            ag_publish_barrier();
+            if (tid == 0) gdg_sched(gp, P, ctx, ctxid, false); // queues the first side branches
+            __syncthreads();
+            R.exit_class = -2;
+            return;
+        }
+    }
+    // ---- phase 2, serial form: side branches in stack order (pyx:301-335)
+    for (int i = 0; gdg && !replayed && i < used_guess; ++i) {
         int depth = G.alt_depth[i];
         if (depth > min_converge_depth) continue;
         gdg_snap_load<NT>(g, s, G, snap_b + (int64_t)i * gdg_snap_bytes(m, new_n));
@@ -457,10 +953,16 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         __syncthreads();
     }
     __syncthreads();
-    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
-    __syncthreads();
-    for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
-    __syncthreads();
+    if (!replayed) {
+        for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+        __syncthreads();
+        for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
+        __syncthreads();
+    }
+#ifdef SWD_GDG_CHECKS
+    if (ctxid >= 0 && tid == 0) { uint32_t *chk_status = par->gdgp.chk_status; GDG_CHECK(atomicExch(&ctx.hdr[1], 0u) == 3u, 15); }
+#endif
+    if (ctxid >= 0 && tid == 0) ring_push(par->gdgp.fq, par->gdgp.fmask, (uint32_t)ctxid); // walked here after all: the context goes back
     R.conv = converge; R.pm = min_pm; R.total_it = R.pre_it + R.post_it;
     R.live_vn = used_guess; R.live_cn = blocks; R.live_e = min_converge_depth;
     R.exit_class = SWD_EXIT_POST;

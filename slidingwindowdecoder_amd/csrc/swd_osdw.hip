@@ -4,23 +4,12 @@
 //   swd_pipeline_*  the whole (W,F) sliding-window loop of /root/reference/osd.py:130-179 for B
 //                   shots in one launch
 // Both run swd::pipeline_kernel (swd_osdw_kernel.h); a single window is a pipeline of length 1.
-#include <string.h>
-
-#include <map>
-#include <memory>
-#include <mutex>
-
-#include <stdlib.h>
-
-#include "swd_host.h"
-#include "swd_osdw_kernel.h"
+#include "swd_plan.h"
+#include "swd_variants.h"
 
 namespace swd {
 
-static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
-static int align_up(int x, int a) { return (x + a - 1) / a * a; }
-
-static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
+int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     const int m = g.m, n = g.n, E = g.E, wm = g.wm;
     const int npad = std::max(next_pow2(n), 2);
     L.npad = npad;
@@ -72,231 +61,11 @@ static int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout
 // off_livemask = bytes of scratch the OSD phase needs
 int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L) { return make_layout(g, g.n, nt, 0, L); }
 
-struct WindowHost {
-    std::shared_ptr<Graph> g;
-    int new_n = 0, row0 = 0, col0 = 0, commit = 0;
-    SwdLdsLayout L{};
-};
-
-struct Plan;
-// Kernel variants: threads per shot, VNs per thread, column-degree bound, groups of four row positions.
-// A plan uses the first variant with NT >= m, NT*VF >= n, DM >= D, 4*KG >= K over all its windows.
-struct Variant {
-    int nt, vf, dm, kg;
-    int sf; // full-graph phase shares heavy checks among threads (needs the host-built map): 4 * kg may be < K
-    int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);      // osd_window kernels
-    int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing-decoder kernels
-};
-static const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
-static bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);
-
-
-// A decode plan: 1..W windows + (for W > 1 or commit > 0) the global check matrix in CSC form.
-struct Plan {
-    std::vector<WindowHost> wins;
-    swd_osdw_params p{};
-    swd_gdg_params gp{};
-    int kind = 0;           // 0 osd_window, 1 bpgdg, 2 bpgd, 3 bp_history
-    int max_guess = 0;
-    int64_t snap_stride = 0;
-    DevBuf snap;
-    int device = 0, nt = 256, vf = 7, dm = 8;
-    const Variant *variant = nullptr;
-    int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
-    DevBuf d_wins, d_chk, d_obs, d_cnmap;
-    DevBuf shot;
-    const uint32_t *d_colptr = nullptr;
-    const uint16_t *d_rows = nullptr;
-    // host-pointer staging (the host-buffer entry points hold `mu` for their whole duration)
-    DevBuf synd, out, stats, pm, hist, osd0, total;
-    DevBuf prof, io;
-    PinnedBuf stage;
-    // Scratch a launch writes and reads back -- ticket counter + per-shot progress, the window hand-over
-    // records, the per-workgroup history ring and snapshot stack -- comes from a small ring of launch slots, so
-    // launches of one decoder on different streams (or from different host threads) never share it: a launch
-    // that re-uses a slot first makes its stream wait for the slot's previous launch (hipStreamWaitEvent).
-    struct LaunchSlot {
-        DevBuf sched, state, hist, snap;
-        hipEvent_t done = nullptr;
-    };
-    static constexpr int kSlots = 4;
-    LaunchSlot slot[kSlots];
-    LaunchSlot *cur = nullptr; // slot of the launch being prepared (valid under mu)
-    int next_slot = 0;
-    std::recursive_mutex mu;
-    DevBuf status;             // one word, never reset by a launch: scheduling faults (swd_pipeline_status)
-    bool profiling = false;
-    bool timing = false;
-    double t_total_ms = 0;
-    int64_t t_launches = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    ~Plan() {
-        if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
-        for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
-    }
-
-    int add_window(const swd_graph_desc *gd, int row0, int col0, int commit,
-                   std::map<std::string, std::shared_ptr<Graph>> &cache) {
-        // identical window matrices (the mid windows of a memory experiment are translates of one
-        // another) share one device graph so the hot read-only data stays small in L2
-        std::string key((const char *)gd->row_ptr, (size_t)(gd->m + 1) * 4);
-        key.append((const char *)gd->col_idx, (size_t)gd->nnz * 4);
-        key.append((const char *)gd->channel_probs, (size_t)gd->n * 8);
-        WindowHost w;
-        auto itc = cache.find(key);
-        if (itc != cache.end()) w.g = itc->second;
-        else {
-            w.g = std::make_shared<Graph>();
-            if (w.g->build(gd)) return -1;
-            if (w.g->D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", w.g->D, SWD_DMAX); return -1; }
-            if (w.g->upload()) return -1;
-            cache[key] = w.g;
-        }
-        const int m = w.g->m, n = w.g->n;
-        const int req_new_n = (kind == 0) ? p.new_n : gp.new_n;
-        w.new_n = (req_new_n <= 0) ? std::min(n, 2 * m) : std::min(req_new_n, n); // osd_window.pyx:60-63
-        if (kind == 0 && p.osd_order > w.new_n - w.g->rank) {                              // osd_window.pyx:88-92
-            set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", w.new_n - w.g->rank);
-            return -1;
-        }
-        if (commit < 0 || commit > n || row0 < 0 || col0 < 0) { // osd.py:140,170-173: e_hat[:commit] is a slice of the window's estimate
-            set_error("invalid window placement: row0 %d col0 %d commit %d for a window with %d columns", row0, col0, commit, n);
-            return -1;
-        }
-        w.row0 = row0; w.col0 = col0; w.commit = commit;
-        wins.push_back(w);
-        return 0;
-    }
-
-    int finalize(const swd_graph_desc *chk) {
-        if (kind == 0 && p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
-        if (kind != 0) {
-            max_guess = ((1 << gp.max_tree_depth) - 1) * 2 + gp.max_side_depth - gp.max_tree_depth; // bp_guessing_decoder.pyx:181
-            if (max_guess < 0) max_guess = 0;
-            if (max_guess > 64) { set_error("max_guess=%d exceeds the device limit of 64 snapshots", max_guess); return -1; }
-            snap_stride = 0;
-            for (auto &w : wins) {
-                const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
-                snap_stride = std::max(snap_stride, rec * std::max(max_guess, 1));
-            }
-        }
-        nmax = 0;
-        int lmax = 0, mmax = 0;
-        dm = 0;
-        for (auto &w : wins) { nmax = std::max(nmax, w.g->n); dm = std::max(dm, w.g->D); }
-        int kmax = 0;
-        mmax = 0;
-        for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
-        variant = select_variant(wins, mmax, nmax, dm, kmax, kind);
-        if (!variant) {
-            set_error("no kernel variant for m=%d n=%d column weight %d row weight %d", mmax, nmax, dm, kmax);
-            return -1;
-        }
-        nt = variant->nt; vf = variant->vf;
-        mmax = 0;
-        for (auto &w : wins) {
-            make_layout(*w.g, w.new_n, nt, kind, w.L);
-            lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
-        }
-        if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
-        if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
-        off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
-        lds_total = off_det + align_up(num_det, 16);
-        if (lds_total > 160 * 1024) {
-            set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
-            return -1;
-        }
-        if (status.reserve(4)) return -1;
-        SWD_HIP(hipMemset(status.p, 0, 4));
-        std::vector<SwdWindowDev> hw(wins.size());
-        if (variant->sf) {
-            std::vector<uint32_t> all, one;
-            for (auto &w : wins) { split_map(*w.g, nt, 4 * variant->kg, &one); all.insert(all.end(), one.begin(), one.end()); }
-            if (d_cnmap.reserve(all.size() * 4)) return -1;
-            SWD_HIP(hipMemcpy(d_cnmap.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-        }
-        for (size_t i = 0; i < wins.size(); ++i) {
-            hw[i].cn_map = variant->sf ? d_cnmap.as<uint32_t>() + i * (size_t)nt : nullptr;
-            hw[i].g = wins[i].g->d;
-            hw[i].g.new_n = wins[i].new_n;
-            hw[i].L = wins[i].L;
-            hw[i].row0 = wins[i].row0; hw[i].col0 = wins[i].col0; hw[i].commit = wins[i].commit; hw[i].pad = 0;
-        }
-        if (d_wins.reserve(hw.size() * sizeof(SwdWindowDev))) return -1;
-        SWD_HIP(hipMemcpy(d_wins.p, hw.data(), hw.size() * sizeof(SwdWindowDev), hipMemcpyHostToDevice));
-        if (chk) {
-            // CSC of the global check matrix for the residual-syndrome update (osd.py:178)
-            if (chk->m > 65535) { set_error("more than 65535 detectors"); return -1; }
-            std::vector<uint32_t> cp(chk->n + 1, 0);
-            for (int e = 0; e < chk->nnz; ++e) {
-                if (chk->col_idx[e] < 0 || chk->col_idx[e] >= chk->n) { set_error("global check matrix: column out of range"); return -1; }
-                cp[chk->col_idx[e] + 1]++;
-            }
-            for (int c = 0; c < chk->n; ++c) cp[c + 1] += cp[c];
-            std::vector<uint16_t> rows(chk->nnz);
-            std::vector<uint32_t> fill(cp.begin(), cp.end() - 1);
-            for (int r = 0; r < chk->m; ++r)
-                for (int e = chk->row_ptr[r]; e < chk->row_ptr[r + 1]; ++e) rows[fill[chk->col_idx[e]]++] = (uint16_t)r;
-            size_t o_rows = align_up((int)(cp.size() * 4), 256);
-            if (d_chk.reserve(o_rows + rows.size() * 2)) return -1;
-            SWD_HIP(hipMemcpy(d_chk.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
-            SWD_HIP(hipMemcpy((char *)d_chk.p + o_rows, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
-            d_colptr = (const uint32_t *)d_chk.p;
-            d_rows = (const uint16_t *)((char *)d_chk.p + o_rows);
-            for (auto &w : wins)
-                if (w.col0 + w.commit > num_col) { set_error("commit range exceeds the global column count"); return -1; }
-            for (auto &w : wins)
-                if (w.row0 + w.g->m > chk->m) { set_error("invalid window placement: rows %d..%d exceed the %d detectors", w.row0, w.row0 + w.g->m, chk->m); return -1; }
-        }
-        return 0;
-    }
-};
-
-
-template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
-static int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
-    SwdPipeArgs a = a0;
-    static std::mutex fn_mu; // the attribute and the occupancy answer belong to the function, not to a decoder
-    std::lock_guard<std::mutex> fn_lock(fn_mu);
-    static int lds_limit[64] = {0}; // per device, monotone
-    if (d->lds_total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
-        lds_limit[d->device & 63] = d->lds_total;
-    }
-    // persistent grid: as many workgroups as fit the device at once (they draw work units until none is left)
-    static int slots[64] = {0};
-    static int slots_lds[64] = {0};
-    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->lds_total) {
-        int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF>, NT, (size_t)d->lds_total));
-        SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
-        slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
-        slots_lds[d->device & 63] = d->lds_total;
-        if (getenv("SWD_DEBUG")) fprintf(stderr, "[swd] pipeline_kernel<%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs, %d B LDS\n", NT, VF, DM, KG, KIND, per_cu, cus, d->lds_total);
-    }
-    const long long units = (long long)a.B * a.W;
-    const unsigned grid = (unsigned)std::min<long long>(units, slots[d->device & 63]);
-    // history ring and (guessing decoders) snapshot stack: per workgroup for sliding-window plans, per shot
-    // otherwise; a caller-provided history buffer (single-window calls) is used as it is
-    const size_t nscr = a.slot_scratch ? (size_t)grid : (size_t)a.B;
-    if (!a.hist) {
-        if (d->cur->hist.reserve(nscr * a.hist_stride * sizeof(double))) return -1;
-        a.hist = d->cur->hist.as<double>();
-    }
-    if (d->kind != 0) {
-        if (d->cur->snap.reserve(nscr * d->snap_stride + 8)) return -1;
-        a.snap = d->cur->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
-    }
-    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF>), dim3(grid), dim3(NT), d->lds_total, st, a);
-    SWD_HIP(hipGetLastError());
-    return 0;
-}
 
 // Static check-to-thread map of the full-graph BP phase for variants that share heavy checks among threads
 // (same rule as cn_assign on the device: smallest T <= cap such that one thread per check of degree <= T,
 // two up to 2T, four up to 4T fit nt threads; lanes are already sorted by decreasing degree).
-static bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map) {
+bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map) {
     static const int cand[8] = {3, 4, 6, 8, 12, 16, 24, 32};
     for (int ci = 0; ci < 8; ++ci) {
         const int T = cand[ci];
@@ -325,25 +94,21 @@ static bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *ma
     return false;
 }
 
+#define SWD_IF_0(...)
+#define SWD_IF_1(...) __VA_ARGS__
+#define SWD_IF(c, ...) SWD_IF_##c(__VA_ARGS__)
+#define SWD_PTR_0(kind, nt, vf, dm, kg, sf) nullptr
+#define SWD_PTR_1(kind, nt, vf, dm, kg, sf) SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)
+#define X(nt, vf, dm, kg, sf, k1, k2) SWD_DECLARE_LAUNCHER(0, nt, vf, dm, kg, sf) SWD_IF(k1, SWD_DECLARE_LAUNCHER(1, nt, vf, dm, kg, sf)) SWD_IF(k2, SWD_DECLARE_LAUNCHER(2, nt, vf, dm, kg, sf))
+SWD_VARIANTS(X)
+#undef X
 static const Variant kVariants[] = {
-#ifndef SWD_HEADLINE_ONLY // development builds: -DSWD_HEADLINE_ONLY compiles only the [[144,12,12]] kernel
-    {64, 4, 4, 2, 0, launch_nt<64, 4, 4, 2, 0>, launch_nt<64, 4, 4, 2, 1>},        // small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6)
-    {64, 4, 8, 16, 0, launch_nt<64, 4, 8, 16, 0>, launch_nt<64, 4, 8, 16, 1>},
-    {256, 2, 8, 16, 0, launch_nt<256, 2, 8, 16, 0>, launch_nt<256, 2, 8, 16, 1>},
-    {256, 4, 8, 16, 0, launch_nt<256, 4, 8, 16, 0>, launch_nt<256, 4, 8, 16, 1>},
-    {256, 2, 10, 12, 0, launch_nt<256, 2, 10, 12, 0>, launch_nt<256, 2, 10, 12, 1>},  // SHYPS r=3 circuit-level windows (63 x 476, column weight <= 9)
-#endif
-    {256, 7, 6, 9, 0, launch_nt<256, 7, 6, 9, 0>, launch_nt<256, 7, 6, 9, 1>},      // [[144,12,12]] circuit-level windows
-#ifndef SWD_HEADLINE_ONLY
-    {256, 7, 8, 16, 0, launch_nt<256, 7, 8, 16, 0>, launch_nt<256, 7, 8, 16, 1>},
-    {1024, 5, 6, 6, 1, launch_nt<1024, 5, 6, 6, 0, true>, nullptr},                   // [[288,12,18]] circuit-level windows, osd_window
-    {1024, 5, 6, 9, 0, launch_nt<1024, 5, 6, 9, 0>, launch_nt<1024, 5, 6, 9, 1>},    // [[288,12,18]] circuit-level windows
-    {1024, 3, 10, 12, 0, launch_nt<1024, 3, 10, 12, 0>, launch_nt<1024, 3, 10, 12, 1>}, // SHYPS r=3 twelve-round windows (252 x 2240, column weight 9, row weight 44)
-    {1024, 8, 8, 16, 0, launch_nt<1024, 8, 8, 16, 0>, launch_nt<1024, 8, 8, 16, 1>},
-#endif
+#define X(nt, vf, dm, kg, sf, k1, k2) {nt, vf, dm, kg, sf, SWD_PTR_1(0, nt, vf, dm, kg, sf), SWD_PTR_##k1(1, nt, vf, dm, kg, sf), SWD_PTR_##k2(2, nt, vf, dm, kg, sf)},
+    SWD_VARIANTS(X)
+#undef X
 };
 
-static const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind) {
+const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind) {
     for (const Variant &v : kVariants) {
         if (!(kind == 0 ? v.launch != nullptr : v.launch_gdg != nullptr)) continue;
         if (!(v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm)) continue;
@@ -378,7 +143,11 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         SWD_HIP(hipEventRecord(d->ev0, st));
     }
     int rc;
-    rc = (d->kind == 0) ? d->variant->launch(d, a, st) : d->variant->launch_gdg(d, a, st);
+    // guessing decoders: the parallel form (side branches as work items) shortens the critical path of a batch that
+    // cannot fill the device with whole shots; large batches keep the serial walk (no speculation, no queue traffic)
+    static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 6144;
+    const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots;
+    rc = (d->kind == 0) ? d->variant->launch(d, a, st) : (par ? d->variant->launch_par(d, a, st) : d->variant->launch_gdg(d, a, st));
     if (rc) return rc;
     SWD_HIP(hipEventRecord(sl.done, st));
     if (d->timing) {
@@ -663,6 +432,18 @@ extern "C" int swd_pipeline_status(swd_pipeline *h, uint32_t *flags) {
     SWD_HIP(hipDeviceSynchronize());
     SWD_HIP(hipMemcpy(flags, d->status.p, 4, hipMemcpyDeviceToHost));
     if (*flags) SWD_HIP(hipMemset(d->status.p, 0, 4)); // read-and-clear
+    return 0;
+}
+
+// diagnostics (development builds with -DSWD_GDG_DEBUG): the 16 status words, read and cleared
+extern "C" int swd_pipeline_debug_counters(swd_pipeline *h, uint32_t *out16) {
+    Plan *d = (Plan *)h;
+    if (!d || !out16) { set_error("null argument"); return -1; }
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
+    SWD_HIP(hipSetDevice(d->device));
+    SWD_HIP(hipDeviceSynchronize());
+    SWD_HIP(hipMemcpy(out16, d->status.p, 64, hipMemcpyDeviceToHost));
+    SWD_HIP(hipMemset((char *)d->status.p + 4, 0, 60));
     return 0;
 }
 

@@ -57,6 +57,25 @@ struct SwdWindowDev {
 
 
 
+// Parallel form of the guessing decoder's tree search (swd_gdg_kernel.h): task queue + per-owner contexts in HBM
+struct SwdGdgPar {
+    uint32_t *q;          // null: serial form.  Work-item ring: [0] head [1] tail [2] window units completed [3] -, then u64 entries
+    uint32_t qmask;       // ring capacity - 1
+    uint32_t *fq;         // ring of free context ids
+    uint32_t fmask;
+    int32_t ensemble;     // every hypothesis counts (multi_thread=True): no pruning / capacity in the replay
+    int32_t inflight_max; // side branches of one tree queued or running at a time
+    uint8_t *ctx;         // [nctx][ctx_stride] contexts of parked trees
+    int64_t ctx_stride;
+    int32_t off_pos, off_rec, off_err, err_stride;
+    uint8_t *csnap;       // [nctx][csnap_stride] their snapshot areas
+    int64_t csnap_stride;
+    int32_t nctx;
+    int32_t shots_inflight; // shots admitted at a time (a finished shot admits the next)
+    int32_t static_bound; // diagnostics (SWD_GDG_STATIC_BOUND): side branches prune against the main branch's min_converge_depth only
+    uint32_t *chk_status; // diagnostic builds (SWD_GDG_CHECKS): invariant violations, bits 8..
+};
+
 struct SwdPipeArgs {
     const SwdWindowDev *wins;
     int32_t W, B;
@@ -88,6 +107,7 @@ struct SwdPipeArgs {
     uint8_t *state;           // [B][state_stride]: residual syndrome + accumulators handed to the next window
     int64_t state_stride;
     int32_t slot_scratch;     // hist / snap are private to the workgroup (indexed by blockIdx.x), not to the shot
+    SwdGdgPar gdgp;
 };
 
 namespace swd {
@@ -1699,14 +1719,58 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
     const uint32_t nunits = (uint32_t)a.B * (uint32_t)a.W;
     Lds s;
     swd_wave_roles<NT>(s, acc + 2);
+    bool queued = false; // parallel form of the guessing decoders: work items instead of window-major tickets
+    if constexpr (KIND == 2) queued = a.gdgp.q != nullptr;
+    uint32_t shots0 = 0; // parallel form: shots admitted at the start; a finished shot admits the next one
+    if constexpr (KIND == 2) {
+        if (queued) {
+            shots0 = (uint32_t)min(a.B, a.gdgp.shots_inflight);
+            if (tid == 0)
+                for (uint32_t b0 = blockIdx.x; b0 < shots0; b0 += gridDim.x) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit((int)b0, 0));
+        }
+    }
     for (;;) {
     const long long t_unit0 = wall_clock64();
+    int wi, b, final_ctx = -1;
+#ifdef SWD_GDG_DEBUG
+    long long dbg_ta = 0, dbg_tb = 0, dbg_tc = 0;
+#endif
+    if (queued) {
+        // Work items (swd_gdg_kernel.h) from one FIFO ring: windows of admitted shots (a window is queued when its
+        // predecessor has committed), side branches and results of parked decimation trees.  No item waits for
+        // another one, so a hard tree never blocks a workgroup that could do other work; the number of shots in
+        // flight is bounded so that a continuation never queues behind the whole batch.
+        uint32_t item = 0;
+        if constexpr (KIND == 2) {
+            __syncthreads();
+            if (tid == 0) { acc[2] = ring_pop_wait(a.gdgp.q, a.gdgp.qmask, a.status); acc[3] = 0u; }
+            __syncthreads();
+            item = acc[2];
+        }
+#ifdef SWD_GDG_DEBUG
+        asm volatile("" ::: "memory"); dbg_ta = wall_clock64(); asm volatile("" ::: "memory");
+        if (tid == 0) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(7, 1); GDG_COUNT(8, dbg_ta - t_unit0); }
+#endif
+        if (item == SWD_ITEM_EXIT) break;
+        const uint32_t type = item >> 30;
+        if (type == SWD_ITEM_SIDE) {
+            if constexpr (KIND == 2) gdg_run_task<NT, VF, DM, KG>(a, smem, item, s.ctid, s.vtid);
+            continue;
+        }
+        if (type == SWD_ITEM_FINAL) {
+            final_ctx = (int)(item & 0x3FFFFFFFu);
+            uint32_t *h = (uint32_t *)(a.gdgp.ctx + (int64_t)final_ctx * a.gdgp.ctx_stride);
+            wi = (int)__hip_atomic_load(&h[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = (int)__hip_atomic_load(&h[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { wi = (int)((item >> 22) & 0xFFu); b = (int)(item & 0x3FFFFFu); }
+    } else {
     __syncthreads();
     if (tid == 0) { acc[2] = atomicAdd(a.sched, 1u); acc[3] = 0u; }
     __syncthreads();
     const uint32_t ticket = acc[2];
     if (ticket >= nunits) break;
-    const int wi = (int)(ticket / (uint32_t)a.B), b = (int)(ticket % (uint32_t)a.B);
+    wi = (int)(ticket / (uint32_t)a.B); b = (int)(ticket % (uint32_t)a.B);
+    }
     __syncthreads();
     uint8_t *sdet = (uint8_t *)(smem + a.off_det);
     uint8_t *state_b = a.state + (int64_t)b * a.state_stride;
@@ -1720,7 +1784,8 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
         // FENCE at agent scope would write back / invalidate a whole L2 per window and costs more than the
         // window's own tail.  Order: data stores complete (workgroup fence = wait for their acknowledgement),
         // then the counter; the reader sees the counter, then loads the data the same way.
-        if (tid == 0) {
+        // (work items of the parallel guessing-decoder form are only queued once their predecessor has committed)
+        if (!queued && tid == 0) {
             const long long t_wait0 = wall_clock64();
             while (__hip_atomic_load(&a.sched[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)wi) {
                 __builtin_amdgcn_s_sleep(8);
@@ -1745,6 +1810,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
     double *hist_b = a.hist + (int64_t)sidx * a.hist_stride;
     s.fpar = 0;
     __syncthreads();
+#ifdef SWD_GDG_DEBUG
+    asm volatile("" ::: "memory"); dbg_tb = wall_clock64(); asm volatile("" ::: "memory");
+    if (queued && tid == 0) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(13, dbg_tb - t_unit0); GDG_COUNT(14, 1); }
+#endif
     {
         const SwdWindowDev &w = a.wins[wi];
         const SwdGraphDev &g = w.g;
@@ -1761,9 +1830,49 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
         } else if constexpr (KIND == 0)
             decode_window<NT, VF, DM, KG, SF>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
                                               a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
-        else
-            decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, a.snap + (int64_t)sidx * a.snap_stride, R);
+        else {
+            uint8_t *snap_b = a.snap + (int64_t)sidx * a.snap_stride;
+            bool redo = false;
+            if (final_ctx >= 0) { // the result of a parked tree
+                const GdgCtx c = gdg_ctx(a.gdgp, final_ctx);
+#ifdef SWD_GDG_CHECKS
+                if (tid == 0) {
+                    uint32_t *chk_status = a.gdgp.chk_status;
+                    GDG_CHECK(final_ctx < a.gdgp.nctx, 9);
+                    GDG_CHECK(atomicExch(&c.hdr[1], 2u) == 1u, 10);   // exactly one FINAL per parked tree
+                    GDG_CHECK(ag_ld(&c.hdr[22]) == 1u && ag_ld(&c.hdr[18]) == ag_ld(&c.hdr[19]), 11);
+                    GDG_CHECK(wi < a.W && b < a.B, 12);
+                }
+#endif
+                redo = !gdg_finalize<NT>(g, a.P, s, c, R); // its snapshot area overflowed: the whole unit again, serially
+                if (tid == 0) {
+                    while (ag_ld(&c.hdr[0]) != 0u) __builtin_amdgcn_s_sleep(2); // the scheduler run that queued this item has left
+                    ring_push(a.gdgp.fq, a.gdgp.fmask, (uint32_t)final_ctx);
+                }
+                __syncthreads();
+            }
+            if (final_ctx < 0 || redo) {
+#ifdef SWD_GDG_DEBUG
+                asm volatile("" ::: "memory"); dbg_tc = wall_clock64(); asm volatile("" ::: "memory");
+#endif
+                s.fpar = 0;
+                decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
+#ifdef SWD_GDG_DEBUG
+                if (tid == 0 && queued) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(R.exit_class == -2 ? 9 : 10, 1); GDG_COUNT(R.exit_class == -2 ? 11 : 12, wall_clock64() - t_unit0); }
+#endif
+                if (R.exit_class == -2) continue; // parked: a FINAL item brings the result
+            }
+        }
         __syncthreads();
+#ifdef SWD_GDG_DEBUG // diagnostic build: checksums of the unit's input syndrome and of its result vector (statistics words 5, 6)
+        if (tid == 0) {
+            uint32_t hi = 2166136261u, ho = 2166136261u;
+            for (int r = 0; r < g.m; ++r) hi = (hi ^ sdet[w.row0 + r]) * 16777619u;
+            for (int v = 0; v < g.n; ++v) ho = (ho ^ s.hard[v]) * 16777619u;
+            R.live_cn = (int)hi; R.live_e = (int)ho;
+        }
+        __syncthreads();
+#endif
         if (a.total) {
             uint8_t *tot_b = a.total + (int64_t)b * a.total_stride + w.col0;
             uint32_t *sdet_w = (uint32_t *)sdet;
@@ -1789,7 +1898,12 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                 int32_t *st = a.stats + ((int64_t)b * a.W + wi) * SWD_STAT_WORDS;
                 st[0] = R.exit_class | (R.conv ? SWD_STATUS_CONVERGE : 0);
                 st[1] = R.total_it; st[2] = R.pre_it; st[3] = R.post_it;
-                st[4] = R.live_vn; st[5] = R.live_cn; st[6] = R.live_e; st[7] = R.osd_rowadds;
+                st[4] = R.live_vn; st[5] = R.live_cn; st[6] = R.live_e;
+#ifdef SWD_GDG_DEBUG // diagnostic build: word 7 counts how often the unit was committed (the caller zeroes the array)
+                atomicAdd(&st[7], 1);
+#else
+                st[7] = R.osd_rowadds;
+#endif
 #ifdef SWD_BPPROF
                 if (R.post_it > 0) st[7] = s.scal[28];
 #endif
@@ -1806,7 +1920,11 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                     prev = cur;
                 }
                 pr[7] = tend - prev;
+#ifdef SWD_GDG_DEBUG
+                pr[6] = R.t[0] - t_unit0; pr[2] = dbg_ta - t_unit0; pr[3] = dbg_tb - t_unit0; pr[4] = dbg_tc - t_unit0;
+#else
                 pr[0] += R.t[0] - t_unit0; // ticket, wait for the previous window, state load
+#endif
 #ifdef SWD_TSPROF
                 pr[5] = t_unit0; pr[6] = tend; // absolute ticks of the unit (diagnostic build)
 #endif
@@ -1837,7 +1955,20 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
 #endif
-            if (tid == 0) __hip_atomic_store(&a.sched[1 + b], (uint32_t)(wi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(&a.sched[1 + b], (uint32_t)(wi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (KIND == 2) { if (queued) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit(b, wi + 1)); } // the shot's next window is ready
+            }
+        }
+        if constexpr (KIND == 2) {
+            if (queued && tid == 0) {
+                if (wi == a.W - 1) { // the shot is finished: admit the next one
+                    const uint32_t nb = shots0 + atomicAdd(a.sched, 1u);
+                    if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit((int)nb, 0));
+                }
+                if (atomicAdd(&a.gdgp.q[2], 1u) + 1u == nunits) // the launch's last unit: release every workgroup
+                    for (uint32_t k = 0; k < gridDim.x; ++k) ring_push(a.gdgp.q, a.gdgp.qmask, SWD_ITEM_EXIT);
+            }
         }
     }
     if (a.shot_result && wi == a.W - 1) {

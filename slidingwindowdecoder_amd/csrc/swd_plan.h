@@ -1,0 +1,299 @@
+// Host-side plan of a decode launch (shared by the translation units that instantiate the kernels):
+// the windows of a plan, the launch-slot ring, and launch_nt, which sizes the persistent grid and launches one
+// instantiation of swd::pipeline_kernel.  The kernels are instantiated in swd_kernels_*.hip (one file per kind, so
+// that they compile in parallel); swd_osdw.hip holds the C ABI and the variant table.
+#pragma once
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include <stdlib.h>
+
+#include "swd_host.h"
+#include "swd_osdw_kernel.h"
+
+namespace swd {
+
+inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L);
+
+struct WindowHost {
+    std::shared_ptr<Graph> g;
+    int new_n = 0, row0 = 0, col0 = 0, commit = 0;
+    SwdLdsLayout L{};
+};
+
+struct Plan;
+// Kernel variants: threads per shot, VNs per thread, column-degree bound, groups of four row positions.
+// A plan uses the first variant with NT >= m, NT*VF >= n, DM >= D, 4*KG >= K over all its windows.
+struct Variant {
+    int nt, vf, dm, kg;
+    int sf; // full-graph phase shares heavy checks among threads (needs the host-built map): 4 * kg may be < K
+    int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);      // osd_window kernels (kind 0)
+    int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing decoders, serial tree walk (kind 1)
+    int (*launch_par)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing decoders, side branches as work items (kind 2)
+};
+const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
+bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);
+
+
+
+struct Plan {
+    std::vector<WindowHost> wins;
+    swd_osdw_params p{};
+    swd_gdg_params gp{};
+    int kind = 0;           // 0 osd_window, 1 bpgdg, 2 bpgd, 3 bp_history
+    bool gdg_parallel = false; // bpgdg: side branches of the decimation tree run as work items on the persistent grid
+    DevBuf gfree_tmpl;         // a full free-context ring, copied into the launch slot's ring per launch
+    int gfree_n = 0;
+    int new_n_max = 0;
+    int max_guess = 0;
+    int64_t snap_stride = 0;
+    DevBuf snap;
+    int device = 0, nt = 256, vf = 7, dm = 8;
+    const Variant *variant = nullptr;
+    int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
+    DevBuf d_wins, d_chk, d_obs, d_cnmap;
+    DevBuf shot;
+    const uint32_t *d_colptr = nullptr;
+    const uint16_t *d_rows = nullptr;
+    // host-pointer staging (the host-buffer entry points hold `mu` for their whole duration)
+    DevBuf synd, out, stats, pm, hist, osd0, total;
+    DevBuf prof, io;
+    PinnedBuf stage;
+    // Scratch a launch writes and reads back -- ticket counter + per-shot progress, the window hand-over
+    // records, the per-workgroup history ring and snapshot stack -- comes from a small ring of launch slots, so
+    // launches of one decoder on different streams (or from different host threads) never share it: a launch
+    // that re-uses a slot first makes its stream wait for the slot's previous launch (hipStreamWaitEvent).
+    struct LaunchSlot {
+        DevBuf sched, state, hist, snap, gq, gfq, gctx, gsnap;
+        hipEvent_t done = nullptr;
+    };
+    static constexpr int kSlots = 4;
+    LaunchSlot slot[kSlots];
+    LaunchSlot *cur = nullptr; // slot of the launch being prepared (valid under mu)
+    int next_slot = 0;
+    std::recursive_mutex mu;
+    DevBuf status;             // one word, never reset by a launch: scheduling faults (swd_pipeline_status)
+    bool profiling = false;
+    bool timing = false;
+    double t_total_ms = 0;
+    int64_t t_launches = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    ~Plan() {
+        if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+        for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+
+    int add_window(const swd_graph_desc *gd, int row0, int col0, int commit,
+                   std::map<std::string, std::shared_ptr<Graph>> &cache) {
+        // identical window matrices (the mid windows of a memory experiment are translates of one
+        // another) share one device graph so the hot read-only data stays small in L2
+        std::string key((const char *)gd->row_ptr, (size_t)(gd->m + 1) * 4);
+        key.append((const char *)gd->col_idx, (size_t)gd->nnz * 4);
+        key.append((const char *)gd->channel_probs, (size_t)gd->n * 8);
+        WindowHost w;
+        auto itc = cache.find(key);
+        if (itc != cache.end()) w.g = itc->second;
+        else {
+            w.g = std::make_shared<Graph>();
+            if (w.g->build(gd)) return -1;
+            if (w.g->D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", w.g->D, SWD_DMAX); return -1; }
+            if (w.g->upload()) return -1;
+            cache[key] = w.g;
+        }
+        const int m = w.g->m, n = w.g->n;
+        const int req_new_n = (kind == 0) ? p.new_n : gp.new_n;
+        w.new_n = (req_new_n <= 0) ? std::min(n, 2 * m) : std::min(req_new_n, n); // osd_window.pyx:60-63
+        if (kind == 0 && p.osd_order > w.new_n - w.g->rank) {                              // osd_window.pyx:88-92
+            set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", w.new_n - w.g->rank);
+            return -1;
+        }
+        if (commit < 0 || commit > n || row0 < 0 || col0 < 0) { // osd.py:140,170-173: e_hat[:commit] is a slice of the window's estimate
+            set_error("invalid window placement: row0 %d col0 %d commit %d for a window with %d columns", row0, col0, commit, n);
+            return -1;
+        }
+        w.row0 = row0; w.col0 = col0; w.commit = commit;
+        wins.push_back(w);
+        return 0;
+    }
+
+    int finalize(const swd_graph_desc *chk) {
+        if (kind == 0 && p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
+        if (kind != 0) {
+            max_guess = ((1 << gp.max_tree_depth) - 1) * 2 + gp.max_side_depth - gp.max_tree_depth; // bp_guessing_decoder.pyx:181
+            if (max_guess < 0) max_guess = 0;
+            if (max_guess > 64) { set_error("max_guess=%d exceeds the device limit of 64 snapshots", max_guess); return -1; }
+            // parallel form of the tree search (swd_gdg_kernel.h): needs its record formats to hold the parameters
+            gdg_parallel = kind == 1 && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
+                           !getenv("SWD_GDG_SERIAL");
+            snap_stride = 0;
+            for (auto &w : wins) {
+                const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
+                snap_stride = std::max(snap_stride, rec * (gdg_parallel ? SWD_GDG_SLOTS : std::max(max_guess, 1)));
+                new_n_max = std::max(new_n_max, w.new_n);
+            }
+        }
+        nmax = 0;
+        int lmax = 0, mmax = 0;
+        dm = 0;
+        for (auto &w : wins) { nmax = std::max(nmax, w.g->n); dm = std::max(dm, w.g->D); }
+        int kmax = 0;
+        mmax = 0;
+        for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
+        variant = select_variant(wins, mmax, nmax, dm, kmax, kind);
+        if (!variant) {
+            set_error("no kernel variant for m=%d n=%d column weight %d row weight %d", mmax, nmax, dm, kmax);
+            return -1;
+        }
+        nt = variant->nt; vf = variant->vf;
+        mmax = 0;
+        for (auto &w : wins) {
+            make_layout(*w.g, w.new_n, nt, kind, w.L);
+            lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
+        }
+        if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
+        if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
+        off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
+        lds_total = off_det + align_up(num_det, 16);
+        if (lds_total > 160 * 1024) {
+            set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
+            return -1;
+        }
+        if (status.reserve(64)) return -1; // word 0: fault flags; words 1..15: counters of diagnostic builds
+        SWD_HIP(hipMemset(status.p, 0, 64));
+        std::vector<SwdWindowDev> hw(wins.size());
+        if (variant->sf) {
+            std::vector<uint32_t> all, one;
+            for (auto &w : wins) { split_map(*w.g, nt, 4 * variant->kg, &one); all.insert(all.end(), one.begin(), one.end()); }
+            if (d_cnmap.reserve(all.size() * 4)) return -1;
+            SWD_HIP(hipMemcpy(d_cnmap.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+        }
+        for (size_t i = 0; i < wins.size(); ++i) {
+            hw[i].cn_map = variant->sf ? d_cnmap.as<uint32_t>() + i * (size_t)nt : nullptr;
+            hw[i].g = wins[i].g->d;
+            hw[i].g.new_n = wins[i].new_n;
+            hw[i].L = wins[i].L;
+            hw[i].row0 = wins[i].row0; hw[i].col0 = wins[i].col0; hw[i].commit = wins[i].commit; hw[i].pad = 0;
+        }
+        if (d_wins.reserve(hw.size() * sizeof(SwdWindowDev))) return -1;
+        SWD_HIP(hipMemcpy(d_wins.p, hw.data(), hw.size() * sizeof(SwdWindowDev), hipMemcpyHostToDevice));
+        if (chk) {
+            // CSC of the global check matrix for the residual-syndrome update (osd.py:178)
+            if (chk->m > 65535) { set_error("more than 65535 detectors"); return -1; }
+            std::vector<uint32_t> cp(chk->n + 1, 0);
+            for (int e = 0; e < chk->nnz; ++e) {
+                if (chk->col_idx[e] < 0 || chk->col_idx[e] >= chk->n) { set_error("global check matrix: column out of range"); return -1; }
+                cp[chk->col_idx[e] + 1]++;
+            }
+            for (int c = 0; c < chk->n; ++c) cp[c + 1] += cp[c];
+            std::vector<uint16_t> rows(chk->nnz);
+            std::vector<uint32_t> fill(cp.begin(), cp.end() - 1);
+            for (int r = 0; r < chk->m; ++r)
+                for (int e = chk->row_ptr[r]; e < chk->row_ptr[r + 1]; ++e) rows[fill[chk->col_idx[e]]++] = (uint16_t)r;
+            size_t o_rows = align_up((int)(cp.size() * 4), 256);
+            if (d_chk.reserve(o_rows + rows.size() * 2)) return -1;
+            SWD_HIP(hipMemcpy(d_chk.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+            SWD_HIP(hipMemcpy((char *)d_chk.p + o_rows, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
+            d_colptr = (const uint32_t *)d_chk.p;
+            d_rows = (const uint16_t *)((char *)d_chk.p + o_rows);
+            for (auto &w : wins)
+                if (w.col0 + w.commit > num_col) { set_error("commit range exceeds the global column count"); return -1; }
+            for (auto &w : wins)
+                if (w.row0 + w.g->m > chk->m) { set_error("invalid window placement: rows %d..%d exceed the %d detectors", w.row0, w.row0 + w.g->m, chk->m); return -1; }
+        }
+        return 0;
+    }
+};
+
+
+
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
+int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
+    SwdPipeArgs a = a0;
+    static std::mutex fn_mu; // the attribute and the occupancy answer belong to the function, not to a decoder
+    std::lock_guard<std::mutex> fn_lock(fn_mu);
+    static int lds_limit[64] = {0}; // per device, monotone
+    if (d->lds_total > lds_limit[d->device & 63]) {
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        lds_limit[d->device & 63] = d->lds_total;
+    }
+    // persistent grid: as many workgroups as fit the device at once (they draw work units until none is left)
+    static int slots[64] = {0};
+    static int slots_lds[64] = {0};
+    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->lds_total) {
+        int per_cu = 0, cus = 0;
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF>, NT, (size_t)d->lds_total));
+        SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
+        slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
+        slots_lds[d->device & 63] = d->lds_total;
+        if (getenv("SWD_DEBUG")) fprintf(stderr, "[swd] pipeline_kernel<%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs, %d B LDS\n", NT, VF, DM, KG, KIND, per_cu, cus, d->lds_total);
+    }
+    const long long units = (long long)a.B * a.W;
+    const unsigned grid = (unsigned)std::min<long long>(units, slots[d->device & 63]);
+    if constexpr (KIND == 2) { // work-item ring + contexts of parked trees (swd_gdg_kernel.h); items need per-workgroup scratch
+        a.slot_scratch = 1;
+        static const int inflight = getenv("SWD_GDG_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_INFLIGHT"))) : 6;
+        unsigned nctx = 64;
+        while (nctx < 2u * grid) nctx <<= 1;
+        static const int shots_mult = getenv("SWD_GDG_SHOTS_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_SHOTS_INFLIGHT"))) : 4;
+        a.gdgp.shots_inflight = (int)std::min<long long>(a.B, (long long)grid * shots_mult);
+        unsigned cap = 1024;
+        while (cap < (unsigned)a.gdgp.shots_inflight + nctx * (unsigned)(inflight + 2) + 2u * grid + 1024u) cap <<= 1; // more than can ever be queued at once
+        const size_t qbytes = 16 + (size_t)cap * 8, fbytes = 16 + (size_t)nctx * 8;
+        const int pos_b = align_up(d->new_n_max * 2, 16), err_b = align_up(d->new_n_max, 16);
+        a.gdgp.off_pos = SWD_GDG_HDR_BYTES; a.gdgp.off_rec = a.gdgp.off_pos + pos_b; a.gdgp.off_err = a.gdgp.off_rec + SWD_GDG_SLOTS * SWD_GDG_REC_BYTES;
+        a.gdgp.err_stride = err_b;
+        a.gdgp.ctx_stride = align_up(a.gdgp.off_err + (SWD_GDG_SLOTS + 1) * err_b, 256);
+        a.gdgp.csnap_stride = (d->snap_stride + 255) & ~(int64_t)255;
+        Plan::LaunchSlot &sl = *d->cur;
+        if (sl.gq.reserve(qbytes) || sl.gfq.reserve(fbytes) || sl.gctx.reserve((size_t)nctx * a.gdgp.ctx_stride) ||
+            sl.gsnap.reserve((size_t)nctx * a.gdgp.csnap_stride))
+            return -1;
+        if (d->gfree_n != (int)nctx) { // template of the full free ring: ids 0..nctx-1 in order
+            std::vector<uint64_t> tmpl(2 + nctx);
+            const unsigned navail = getenv("SWD_GDG_NCTX") ? std::min<unsigned>(nctx, (unsigned)atoi(getenv("SWD_GDG_NCTX"))) : nctx; // diagnostics
+            tmpl[0] = (uint64_t)navail << 32; tmpl[1] = 0; // head 0, tail = contexts available
+            for (unsigned t = 0; t < nctx; ++t) tmpl[2 + t] = ((uint64_t)(t + 1) << 32) | t;
+            if (d->gfree_tmpl.reserve(fbytes)) return -1;
+            SWD_HIP(hipMemcpy(d->gfree_tmpl.p, tmpl.data(), fbytes, hipMemcpyHostToDevice));
+            d->gfree_n = (int)nctx;
+        }
+        a.gdgp.q = sl.gq.as<uint32_t>(); a.gdgp.qmask = cap - 1;
+        a.gdgp.fq = sl.gfq.as<uint32_t>(); a.gdgp.fmask = nctx - 1;
+        a.gdgp.ctx = sl.gctx.as<uint8_t>(); a.gdgp.csnap = sl.gsnap.as<uint8_t>();
+        a.gdgp.ensemble = d->gp.multi_thread ? 1 : 0;
+        a.gdgp.inflight_max = inflight;
+        a.gdgp.nctx = (int)nctx; a.gdgp.chk_status = d->status.as<uint32_t>();
+        a.gdgp.static_bound = getenv("SWD_GDG_STATIC_BOUND") ? 1 : 0;
+        SWD_HIP(hipMemsetAsync(a.gdgp.q, 0, qbytes, st));
+        SWD_HIP(hipMemcpyAsync(a.gdgp.fq, d->gfree_tmpl.p, fbytes, hipMemcpyDeviceToDevice, st));
+    }
+    // history ring and (guessing decoders) snapshot stack: per workgroup for sliding-window plans, per shot
+    // otherwise; a caller-provided history buffer (single-window calls) is used as it is
+    const size_t nscr = a.slot_scratch ? (size_t)grid : (size_t)a.B;
+    if (!a.hist) {
+        if (d->cur->hist.reserve(nscr * a.hist_stride * sizeof(double))) return -1;
+        a.hist = d->cur->hist.as<double>();
+    }
+    if (d->kind != 0) {
+        if (d->cur->snap.reserve(nscr * d->snap_stride + 8)) return -1;
+        a.snap = d->cur->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
+    }
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF>), dim3(grid), dim3(NT), d->lds_total, st, a);
+    SWD_HIP(hipGetLastError());
+    return 0;
+}
+
+// one launcher per kernel instantiation, defined in swd_kernels_*.hip
+#define SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf) swd_launch_k##kind##_##nt##_##vf##_##dm##_##kg##_##sf
+#define SWD_DECLARE_LAUNCHER(kind, nt, vf, dm, kg, sf) int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *, const SwdPipeArgs &, hipStream_t);
+#define SWD_DEFINE_LAUNCHER(kind, nt, vf, dm, kg, sf) \
+    int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, kind, (sf) != 0>(d, a, st); }
+
+} // namespace swd

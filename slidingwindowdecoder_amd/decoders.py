@@ -219,20 +219,31 @@ class osd_window:
 
 
 def _gdg_params(kwargs, mode):
+    """kwargs of bp_guessing_decoder.pyx:7-9, 162-171, 475-478.  ``hypotheses=64`` (not a reference kwarg) picks the tree
+    shape that fills 64 hypotheses per shot -- leaves = 1 + (S - D) + 2 (2^D - 1) with D = 5, S = 6 (bpgd.cpp:576-577) --
+    and the ensemble semantics of ``multi_thread=True``."""
+    kwargs = dict(kwargs)
+    hyp = kwargs.pop("hypotheses", None)
+    if hyp is not None:
+        if int(hyp) != 64:
+            raise ValueError("hypotheses: only 64 is provided (max_tree_depth=5, max_side_depth=6)")
+        kwargs.update(max_tree_depth=5, max_side_depth=6, multi_thread=True)
     new_n = kwargs.get("new_n", None)
     return _lib.GdgParams(int(kwargs.get("max_iter", 50)), float(kwargs.get("ms_scaling_factor", 1.0)),
                           int(kwargs.get("max_iter_per_step", 6)), int(kwargs.get("max_step", 25)),
                           int(kwargs.get("max_tree_depth", 3)), int(kwargs.get("max_side_depth", 10)),
                           int(kwargs.get("max_tree_branch_step", 10)), int(kwargs.get("max_side_branch_step", 10)),
                           float(kwargs.get("gdg_factor", kwargs.get("gd_factor", 1.0))),
-                          int(new_n) if new_n else 0, int(bool(kwargs.get("low_error_mode", False))), mode)
+                          int(new_n) if new_n else 0, int(bool(kwargs.get("low_error_mode", False))), mode,
+                          int(bool(kwargs.get("multi_thread", False))) if mode == 0 else 0)
 
 
 class bp_history_decoder:
     """Plain min-sum BP with a 4-deep posterior history (reference: src/bp_guessing_decoder.pyx:5-158)
-    and base class of the guessing decoders.  ``multi_thread=True`` is accepted for call
-    compatibility but the deterministic single-thread search is what runs (the reference's threaded
-    ensemble is not reproducible run to run)."""
+    and base class of the guessing decoders.  ``bpgdg_decoder``: the side branches of a shot's decimation tree run
+    concurrently on different workgroups; with ``multi_thread=False`` (default) the result is that of the reference's
+    deterministic single-thread ``gdg()`` bit for bit, with ``multi_thread=True`` every hypothesis counts like in the
+    reference's threaded ensemble (which is racy: that mode is deterministic here but no parity target)."""
     _mode = 2
 
     def __init__(self, parity_check_matrix, **kwargs):

