@@ -1,4 +1,4 @@
-// Instantiations of swd::pipeline_kernel for kind 0 (osd_window windows) and
+// Instantiations of swd::pipeline_kernel for kind 3 (osd_window windows, posterior history accumulated in registers) and
 // their launchers (swd_plan.h); one translation unit per kind so that the kernels compile in parallel.
 #include "swd_plan.h"
 #include "swd_variants.h"
@@ -7,7 +7,7 @@ namespace swd {
 #define SWD_IF_0(...)
 #define SWD_IF_1(...) __VA_ARGS__
 #define SWD_IF(c, ...) SWD_IF_##c(__VA_ARGS__)
-#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_IF(1, SWD_DEFINE_LAUNCHER(0, nt, vf, dm, kg, sf))
+#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_IF(k3, SWD_DEFINE_LAUNCHER(3, nt, vf, dm, kg, sf))
 SWD_VARIANTS(X)
 #undef X
 } // namespace swd

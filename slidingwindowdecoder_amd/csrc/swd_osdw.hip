@@ -31,6 +31,8 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     L.off_rc = align_up(std::max(L.off_cord + 66 * 4 + m * 2, L.off_aux + 3 * 256 * 4), 16); // clear of the select histograms
     L.off_bak = align_up(L.off_rc + E * 2, 16);
     scratch = std::max(scratch, L.off_bak + 10 * m + 2 * n + 8);
+    L.off_hs = align_up(L.off_aux + n * 2, 16); // behind the decided-0 list of the OSD ordering, used before the elimination sets up
+    scratch = std::max(scratch, L.off_hs + n * 8);
     scratch = align_up(scratch, 16);
     int o = scratch;
     L.off_livemask = o; o += m * 8;
@@ -99,11 +101,11 @@ bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map) {
 #define SWD_IF(c, ...) SWD_IF_##c(__VA_ARGS__)
 #define SWD_PTR_0(kind, nt, vf, dm, kg, sf) nullptr
 #define SWD_PTR_1(kind, nt, vf, dm, kg, sf) SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)
-#define X(nt, vf, dm, kg, sf, k1, k2) SWD_DECLARE_LAUNCHER(0, nt, vf, dm, kg, sf) SWD_IF(k1, SWD_DECLARE_LAUNCHER(1, nt, vf, dm, kg, sf)) SWD_IF(k2, SWD_DECLARE_LAUNCHER(2, nt, vf, dm, kg, sf))
+#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_DECLARE_LAUNCHER(0, nt, vf, dm, kg, sf) SWD_IF(k1, SWD_DECLARE_LAUNCHER(1, nt, vf, dm, kg, sf)) SWD_IF(k2, SWD_DECLARE_LAUNCHER(2, nt, vf, dm, kg, sf)) SWD_IF(k3, SWD_DECLARE_LAUNCHER(3, nt, vf, dm, kg, sf))
 SWD_VARIANTS(X)
 #undef X
 static const Variant kVariants[] = {
-#define X(nt, vf, dm, kg, sf, k1, k2) {nt, vf, dm, kg, sf, SWD_PTR_1(0, nt, vf, dm, kg, sf), SWD_PTR_##k1(1, nt, vf, dm, kg, sf), SWD_PTR_##k2(2, nt, vf, dm, kg, sf)},
+#define X(nt, vf, dm, kg, sf, k1, k2, k3) {nt, vf, dm, kg, sf, SWD_PTR_1(0, nt, vf, dm, kg, sf), SWD_PTR_##k1(1, nt, vf, dm, kg, sf), SWD_PTR_##k2(2, nt, vf, dm, kg, sf), SWD_PTR_##k3(3, nt, vf, dm, kg, sf)},
     SWD_VARIANTS(X)
 #undef X
 };
@@ -147,7 +149,12 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // cannot fill the device with whole shots; large batches keep the serial walk (no speculation, no queue traffic)
     static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 6144;
     const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots;
-    rc = (d->kind == 0) ? d->variant->launch(d, a, st) : (par ? d->variant->launch_par(d, a, st) : d->variant->launch_gdg(d, a, st));
+    // osd_window: when the posterior history is only consumed as its slot-order sum (no history in or out, both
+    // iteration caps multiples of four) the kernel that accumulates the sum in registers runs: no 4 x n ring in HBM
+    const bool acc = d->kind == 0 && d->variant->launch_acc && !a.hist && !a.P.record_all && !a.P.hist_is_state && !a.P.zero_hist &&
+                     a.P.pre_iter >= 4 && a.P.pre_iter % 4 == 0 && a.P.post_iter >= 4 && a.P.post_iter % 4 == 0 && !getenv("SWD_NO_HACC");
+    rc = (d->kind == 0) ? (acc ? d->variant->launch_acc(d, a, st) : d->variant->launch(d, a, st))
+                        : (par ? d->variant->launch_par(d, a, st) : d->variant->launch_gdg(d, a, st));
     if (rc) return rc;
     SWD_HIP(hipEventRecord(sl.done, st));
     if (d->timing) {

@@ -27,6 +27,7 @@ struct SwdLdsLayout {
     int32_t off_cord;  // inside scratch: degree histogram + check order of the post phase (clear of lslot and the keys' tail)
     int32_t off_rc;    // inside scratch: u16 row_col[E] staged for the shortening step
     int32_t off_bak;   // inside scratch: state backup of the parallel peel (10 m + 2 n bytes)
+    int32_t off_hs;    // inside scratch: f64 hs[n], summed posterior history of the live VNs after a failed post phase (HACC kernels)
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -425,10 +426,14 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
     lc = (cidx < nl) ? (int)cord[cidx] : -1;
 }
 
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false>
+// ACC: the posterior history is only ever consumed as ((h0 + h1) + h2) + h3 in slot order after a run of ALL
+// max_iter iterations, and with max_iter a multiple of four slot order is chronological order of the last four
+// iterations: the sum is accumulated in registers (hs[i] for the i-th variable node of the thread) in exactly
+// that order and the 4 x n ring in HBM is neither written nor read.
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
-                      double alpha, bool force_unsat = false) {
+                      double alpha, bool force_unsat = false, double *hs = nullptr) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
     const bool record_all = P.record_all != 0;
@@ -577,7 +582,11 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 double temp = c.llr[i];
 #pragma unroll
                 for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
-                if (record && valid) hist_b[slot_h * n + v] = temp;
+                if constexpr (ACC) {
+                    if (it >= max_iter - 4) hs[i] = (it == max_iter - 4) ? temp : hs[i] + temp; // wave-uniform conditions
+                } else {
+                    if (record && valid) hist_b[slot_h * n + v] = temp;
+                }
                 const bool hd = valid && (temp <= 0);
                 ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
                 double suf = 0.0;
@@ -1366,7 +1375,7 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 
 // osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
 // order).  On return s.hard[0..n) is the vector decode() returns.
-template <int NT, int VF, int DM, int KG, bool SF>
+template <int NT, int VF, int DM, int KG, bool SF, bool HACC>
 __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                               const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map) {
     const int tid = threadIdx.x;
@@ -1408,7 +1417,10 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     uint16_t *list0 = (uint16_t *)s.scratch;
     R.t[1] = wall_clock64();
 
-    R.conv = bp_run<NT, VF, DM, KG, true, SF>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha);
+    double hs[VF]; // HACC: summed posterior history of this thread's variable nodes
+#pragma unroll
+    for (int i = 0; i < VF; ++i) hs[i] = 0.0;
+    R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs);
     R.pre_it = it;
     R.t[2] = wall_clock64();
     if (R.conv) {
@@ -1422,12 +1434,21 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     uint64_t *key = (uint64_t *)s.scratch;
     uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
     __syncthreads();
-    for (int v = tid; v < L.npad; v += NT) {
-        if (v < n) {
-            const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
-            key[v] = f2key(sum);
-            idx[v] = (uint16_t)v;
-        } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+    if constexpr (HACC) {
+#pragma unroll
+        for (int i = 0; i < VF; ++i) { // the keys come straight from the accumulators of the owning thread
+            const int v = s.vtid + i * NT;
+            if (v < n) { key[v] = f2key(hs[i]); idx[v] = (uint16_t)v; }
+        }
+        for (int v = n + tid; v < L.npad; v += NT) { key[v] = ~0ull; idx[v] = 0xFFFF; }
+    } else {
+        for (int v = tid; v < L.npad; v += NT) {
+            if (v < n) {
+                const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+                key[v] = f2key(sum);
+                idx[v] = (uint16_t)v;
+            } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
+        }
     }
     // columns of the edges, by slot: the shortening step walks them several times
     uint16_t *rc = (uint16_t *)(s.scratch + L.off_rc);
@@ -1597,7 +1618,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 #ifdef SWD_SHPROF
     if (tid == 0) { s.scal[20] = (int)(sh0 - R.t[3]); s.scal[21] = (int)(sh1 - sh0); s.scal[22] = (int)(sh2 - sh1); s.scal[23] = (int)(R.t[4] - sh2); }
 #endif
-    R.conv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it, P.alpha);
+    R.conv = bp_run<NT, VF, DM, KG, false, false, HACC>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it, P.alpha, false, hs);
     R.post_it = it;
     R.t[5] = wall_clock64();
     R.total_it = R.pre_it + R.post_it;
@@ -1607,6 +1628,15 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         return;
     }
     if (P.osd_order < 0) { R.exit_class = SWD_EXIT_NO_OSD; return; }
+    double *hsl = (double *)(s.scratch + L.off_hs); // HACC: history sums of the live VNs by column (the messages are dead now)
+    if constexpr (HACC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VF; ++i) {
+            const int li = s.vtid + i * NT;
+            if (li < nlive) hsl[s.lv[li]] = hs[i];
+        }
+    }
     // osd_window.bp_decoding after an OSD exit = the post-phase BP decisions incl. the decided values (osd_window.pyx:499-501)
     if (bpdec_b)
         for (int v = tid; v < n; v += NT) bpdec_b[v] = s.hard[v];
@@ -1631,7 +1661,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         for (int v = v0; v < v1; ++v) {
             const int vv = s.vn_val[v];
             if (vv == 0) { zlist[pz++] = (uint16_t)v; continue; }
-            const uint64_t k = f2key(vv == 1 ? -1000.0 : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v]);
+            const uint64_t k = f2key(vv == 1 ? -1000.0 : (HACC ? hsl[v] : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v]));
             key[ps] = k; idx[ps] = (uint16_t)v; ++ps;
             nlt += (k < k1000) ? 1 : 0;
             eq |= (k == k1000);
@@ -1665,7 +1695,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
                 const int vv = s.vn_val[v];
                 if (vv == 1) sum = -1000.0;
                 else if (vv == 0) sum = 1000.0;
-                else sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
+                else sum = HACC ? hsl[v] : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
                 key[v] = f2key(sum);
                 idx[v] = (uint16_t)v;
             } else { key[v] = ~0ull; idx[v] = 0xFFFF; }
@@ -1827,9 +1857,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(cons
             for (int v = tid; v < g.n; v += NT) s.hard[v] = 0;
             R = WinResult{};
             R.exit_class = SWD_EXIT_SCHED_FAULT;
-        } else if constexpr (KIND == 0)
-            decode_window<NT, VF, DM, KG, SF>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
-                                              a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
+        } else if constexpr (KIND == 0 || KIND == 3) // 3: osd_window with the posterior history accumulated in registers (bp_run, ACC)
+            decode_window<NT, VF, DM, KG, SF, KIND == 3>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
+                                                         a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
         else {
             uint8_t *snap_b = a.snap + (int64_t)sidx * a.snap_stride;
             bool redo = false;

@@ -36,6 +36,7 @@ struct Variant {
     int (*launch)(Plan *, const SwdPipeArgs &, hipStream_t);      // osd_window kernels (kind 0)
     int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing decoders, serial tree walk (kind 1)
     int (*launch_par)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing decoders, side branches as work items (kind 2)
+    int (*launch_acc)(Plan *, const SwdPipeArgs &, hipStream_t);  // osd_window, posterior history accumulated in registers (kind 3)
 };
 const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
 bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);

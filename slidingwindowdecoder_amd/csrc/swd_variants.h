@@ -1,22 +1,23 @@
 // Kernel variants: threads per shot, variable nodes per thread, column-degree bound, groups of four row positions,
 // sf (the full-graph phase shares heavy checks among threads: needs the host-built map, 4 * kg may be < K),
-// then which guessing-decoder kernels exist for the variant: serial form (kind 1), parallel form (kind 2).
+// then which further kernels exist for the variant: guessing decoders in serial form (kind 1) and parallel form
+// (kind 2), osd_window with the posterior history accumulated in registers (kind 3).
 // A plan uses the first variant with NT >= m, NT * VF >= n, DM >= D, 4 * KG >= K over all its windows.
-// X(nt, vf, dm, kg, sf, has_k1, has_k2)
+// X(nt, vf, dm, kg, sf, has_k1, has_k2, has_k3)
 #pragma once
 #ifdef SWD_HEADLINE_ONLY // development builds: only the [[144,12,12]] kernels
-#define SWD_VARIANTS(X) X(256, 7, 6, 9, 0, 1, 1)
+#define SWD_VARIANTS(X) X(256, 7, 6, 9, 0, 1, 1, 1)
 #else
 #define SWD_VARIANTS(X)                                                                                              \
-    X(64, 4, 4, 2, 0, 1, 1)      /* small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6) */                             \
-    X(64, 4, 8, 16, 0, 1, 1)                                                                                         \
-    X(256, 2, 8, 16, 0, 1, 1)                                                                                        \
-    X(256, 4, 8, 16, 0, 1, 1)                                                                                        \
-    X(256, 2, 10, 12, 0, 1, 1)   /* SHYPS r=3 circuit-level windows (63 x 476, column weight <= 9) */                \
-    X(256, 7, 6, 9, 0, 1, 1)     /* [[144,12,12]] circuit-level windows */                                           \
-    X(256, 7, 8, 16, 0, 1, 1)                                                                                        \
-    X(1024, 5, 6, 6, 1, 0, 0)    /* [[288,12,18]] circuit-level windows, osd_window */                               \
-    X(1024, 5, 6, 9, 0, 1, 0)    /* [[288,12,18]] circuit-level windows */                                           \
-    X(1024, 3, 10, 12, 0, 1, 0)  /* SHYPS r=3 twelve-round windows (252 x 2240, column weight 9, row weight 44) */   \
-    X(1024, 8, 8, 16, 0, 1, 0)
+    X(64, 4, 4, 2, 0, 1, 1, 0)      /* small codes, e.g. [[72,12,6]] hx (n=72, D=3, K=6) */                             \
+    X(64, 4, 8, 16, 0, 1, 1, 0)                                                                                         \
+    X(256, 2, 8, 16, 0, 1, 1, 0)                                                                                        \
+    X(256, 4, 8, 16, 0, 1, 1, 0)                                                                                        \
+    X(256, 2, 10, 12, 0, 1, 1, 1)   /* SHYPS r=3 circuit-level windows (63 x 476, column weight <= 9) */                \
+    X(256, 7, 6, 9, 0, 1, 1, 1)     /* [[144,12,12]] circuit-level windows */                                           \
+    X(256, 7, 8, 16, 0, 1, 1, 0)                                                                                        \
+    X(1024, 5, 6, 6, 1, 0, 0, 1)    /* [[288,12,18]] circuit-level windows, osd_window */                               \
+    X(1024, 5, 6, 9, 0, 1, 0, 1)    /* [[288,12,18]] circuit-level windows */                                           \
+    X(1024, 3, 10, 12, 0, 1, 0, 0)  /* SHYPS r=3 twelve-round windows (252 x 2240, column weight 9, row weight 44) */   \
+    X(1024, 8, 8, 16, 0, 1, 0, 0)
 #endif
