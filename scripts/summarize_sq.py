@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 vals = {}
 for d in ("pmc_sq1", "pmc_sq2"):
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", d, "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if "pipeline_kernel" in row["Kernel_Name"]:
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
