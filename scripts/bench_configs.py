@@ -16,7 +16,7 @@ from slidingwindowdecoder_amd import SlidingWindowDecoder, bp4_osd
 from slidingwindowdecoder_amd.windows import sample_dem
 from slidingwindowdecoder_amd.codes import bb_code
 
-which = sys.argv[1:] or ["3", "4", "5", "bp4", "order10"]
+which = sys.argv[1:] or ["3", "3small", "3ens", "4", "5", "5w12", "bp4", "bp4shyps", "order10"]
 
 
 def run_pipeline(name, plan, shots, reps, **kw):
@@ -42,6 +42,13 @@ if "3" in which:
     run_pipeline("configs[2]: [[144,12,12]] p=0.003 (3,1) bpgdg_decoder(max_iter=8, T=6, R=25, D=3, S=10)", bench.build_problem(), int(os.environ.get("SWD_GDG_SHOTS", "16384")), 2,
                  decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
                  max_tree_branch_step=10, max_side_branch_step=10)
+GDG_KW = dict(decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+              max_tree_branch_step=10, max_side_branch_step=10)
+if "3small" in which:  # small batch: side branches of a shot's decimation tree run as work items on many workgroups
+    run_pipeline("configs[2] at 2048 shots per launch (parallel tree search)", bench.build_problem(), 2048, 3, **GDG_KW)
+if "3ens" in which:    # the 64-hypothesis ensemble (multi_thread semantics, no parity target)
+    run_pipeline("configs[2], hypotheses=64 ensemble (D=5, S=6, every leaf scored), 2048 shots per launch", bench.build_problem(), 2048, 3,
+                 **dict(GDG_KW, hypotheses=64))
 if "4" in which:
     run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 4096, 2,
                  **dict(bench.DECODER_KW, osd_order=0))
@@ -52,6 +59,12 @@ if "5" in which:
     run_pipeline("configs[4] circuit: SHYPS r=3 p=0.001, 12 rounds, (3,1) windows 63x476, osd_window(pre=8, post=200, osd_cs 0) "
                  "(binary BP+OSD like SHYPS.ipynb; BP4 has no circuit-level reference)",
                  plan_windows(dem.chk, dem.obs, dem.priors, 21, 3, 1, method=1), 8192, 3, **dict(bench.DECODER_KW, osd_order=0))
+if "5w12" in which:
+    from slidingwindowdecoder_amd import shyps
+    from slidingwindowdecoder_amd.windows import plan_windows
+    dem = shyps.shyps_dem(3, 0.001, 14)
+    run_pipeline("configs[4] circuit with twelve-round windows: SHYPS r=3 p=0.001, 14 rounds, (12,1) windows 252x2240, osd_window(pre=8, post=200, osd_cs 0)",
+                 plan_windows(dem.chk, dem.obs, dem.priors, 21, 12, 1, method=1), 4096, 3, **dict(bench.DECODER_KW, osd_order=0))
 if "order10" in which:
     run_pipeline("configs[1] with osd_cs order 10", bench.build_problem(), 4096, 3, **dict(bench.DECODER_KW, osd_order=10))
 if "bp4" in which:
@@ -70,3 +83,22 @@ if "bp4" in which:
     t0 = time.perf_counter(); out = dec.decode_batch(sx, sz); dt = time.perf_counter() - t0
     print(json.dumps({"config": "bp4_osd [[144,12,12]] depolarizing p=0.02, max_iter=100, osd_cs 10 (host buffers, PCIe included)",
                       "decodes": B, "decodes_per_s": B / dt, "converged_fraction": float(((dec.last_status & 0x100) != 0).mean())}), flush=True)
+
+if "bp4shyps" in which:  # BASELINE config 5's decoder on config 5's code (code capacity: the setting the reference can run BP4 in)
+    from slidingwindowdecoder_amd import shyps
+    SX, SZ = shyps.shyps_stabilizers(3)
+    n = SX.shape[1]
+    p = 0.02
+    pr = np.full(n, p / 3)
+    dec = bp4_osd(SX, SZ, channel_probs_x=pr, channel_probs_y=pr, channel_probs_z=pr, max_iter=32, ms_scaling_factor=0.625,
+                  osd_method="osd_cs", osd_order=10)
+    rng = np.random.default_rng(6)
+    B = 65536
+    pauli = rng.choice(4, size=(B, n), p=[1 - p, p / 3, p / 3, p / 3])
+    ex, ez = ((pauli == 1) | (pauli == 2)).astype(np.uint8), ((pauli == 3) | (pauli == 2)).astype(np.uint8)
+    sx = (ez @ SX.T % 2).astype(np.uint8); sz = (ex @ SZ.T % 2).astype(np.uint8)
+    dec.decode_batch(sx[:256], sz[:256])
+    t0 = time.perf_counter(); out = dec.decode_batch(sx, sz); dt = time.perf_counter() - t0
+    print(json.dumps({"config": "configs[4] decoder: bp4_osd on the SHYPS r=3 stabiliser matrices (21x49 each), depolarizing p=0.02, max_iter=32, osd_cs 10 "
+                                "(host buffers, PCIe included)", "decodes": B, "decodes_per_s": B / dt,
+                      "converged_fraction": float(((dec.last_status & 0x100) != 0).mean())}), flush=True)
