@@ -31,6 +31,13 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     L.off_rc = align_up(std::max(L.off_cord + 66 * 4 + m * 2, L.off_aux + 3 * 256 * 4), 16); // clear of the select histograms
     L.off_bak = align_up(L.off_rc + E * 2, 16);
     scratch = std::max(scratch, L.off_bak + 10 * m + 2 * n + 8);
+    // exchange slots of the column-form elimination (osd0_cols: 1024 threads, 256 < m <= 576): tail of the sort keys,
+    // the staged row lists of the sorted columns end before it
+    L.off_oslot = -1;
+    if (wm > 4 && wm <= 9 && nt >= 1024) {
+        const int nbc = nt / 16, sb = align_up(2 * nbc * 9 * 8 + 2 * nbc * 4 + 2 * (nt / 64) + 16, 16);
+        if (sb <= npad * 4) L.off_oslot = npad * 8 - sb;
+    }
     L.off_hs = align_up(L.off_aux + n * 2, 16); // behind the decided-0 list of the OSD ordering, used before the elimination sets up
     scratch = std::max(scratch, L.off_hs + n * 8);
     scratch = align_up(scratch, 16);

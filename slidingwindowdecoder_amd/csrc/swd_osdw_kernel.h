@@ -28,6 +28,7 @@ struct SwdLdsLayout {
     int32_t off_rc;    // inside scratch: u16 row_col[E] staged for the shortening step
     int32_t off_bak;   // inside scratch: state backup of the parallel peel (10 m + 2 n bytes)
     int32_t off_hs;    // inside scratch: f64 hs[n], summed posterior history of the live VNs after a failed post phase (HACC kernels)
+    int32_t off_oslot; // inside scratch (tail of the sort keys): exchange slots of the column-form elimination (osd0_cols), -1 if unused
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -936,6 +937,231 @@ __device__ __forceinline__ int osd0_block(const SwdGraphDev &g, Lds &s, const ui
     return rowadds;
 }
 
+__device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // srclane wave-uniform
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, srclane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), srclane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// General m in column form (256 < m <= 64 * WMC, 1024 threads).  The transform matrix lives in registers, one column
+// per thread of nine "column waves"; LDS holds a mirror that only the column evaluations read.  Wave 0 (the resolver)
+// evaluates a batch of 64 sorted columns against the mirror, one per lane, and then resolves every pivot among them on
+// its own, without a barrier: first column with a one in an unpivoted row, lowest such row r, S = its reduced vector
+// without bit r; the batch's later columns get the row operation "rows i != r with u[i] = 1 get row r added" right
+// there (y ^= S if y[r] -- what re-evaluating them against the updated T would give; columns before the pivot column
+// were dependent and stay so), and (S, r) goes into a ring in LDS.  The column waves follow the ring at their own pace
+// (col ^= S if col[r]); two barriers per batch of 64 columns bracket the refresh of the mirror.  The resolver and the
+// column waves sit on different SIMDs (waves 1-3, 5-7, 9-11 hold the columns), so the serial part -- about 70 vector
+// instructions per pivot -- overlaps the 9 x 40 of the update.  (osd0_block below: 3.4k cycles per pivot, wave 0
+// evaluating against T in LDS while 15 waves wait, then all threads rewriting T in LDS, two barriers per pivot.)
+#define SWD_LDS_AS __attribute__((address_space(3)))
+// bit `rbit` of word `rw` (both wave-uniform) of a register-resident bit vector: a scalar branch per word instead of a select chain
+template <int WMC>
+__device__ __forceinline__ uint32_t osd_vec_bit(const uint64_t (&v)[WMC], int rw, int rbit) {
+    uint32_t h = 0;
+    switch (rw) {
+#define SWD_CASE(x) case x: if constexpr (x < WMC) h = (rbit < 32) ? (uint32_t)v[x < WMC ? x : 0] : (uint32_t)(v[x < WMC ? x : 0] >> 32); break;
+        SWD_CASE(0) SWD_CASE(1) SWD_CASE(2) SWD_CASE(3) SWD_CASE(4) SWD_CASE(5) SWD_CASE(6) SWD_CASE(7) SWD_CASE(8)
+        SWD_CASE(9) SWD_CASE(10) SWD_CASE(11) SWD_CASE(12) SWD_CASE(13) SWD_CASE(14) SWD_CASE(15)
+#undef SWD_CASE
+    default: break;
+    }
+    return (h >> (rbit & 31)) & 1u;
+}
+
+template <int NT, int DM, int WMC>
+__device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
+                                         uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
+                                         int *npiv_out, char *slotmem) {
+    constexpr int NBC = 64;
+    static_assert(NT >= 768 && WMC <= 16, "wave 0 resolves, nine of the waves 1..11 hold the columns");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
+    constexpr int ES = (WMC + 2) & ~1; // words per ring entry: S, then pivot row | column within the batch << 16 (16-byte multiples)
+    SWD_LDS_AS uint64_t *ringS = (SWD_LDS_AS uint64_t *)slotmem;                  // [NBC][ES] the batch's row operations
+    SWD_LDS_AS uint64_t *Pl = ringS + NBC * ES;                                   // [WMC] pivoted rows
+    SWD_LDS_AS int *ctl = (SWD_LDS_AS int *)(Pl + WMC + 1); // 0: published, 1: batch closed, 2: elimination finished, 3: pivots so far, 4: row additions
+    volatile SWD_LDS_AS int *vctl = ctl;
+    const bool colwave = (wave & 3) != 0 && wave < 12;
+    const int jc = colwave ? (wave - 1 - (wave >> 2)) * 64 + lane : m; // the column of T this thread keeps
+    uint64_t col[WMC];
+#pragma unroll
+    for (int x = 0; x < WMC; ++x) col[x] = (jc < m && x == (jc >> 6)) ? (1ull << (jc & 63)) : 0ull;
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; }
+    if (tid < WMC) Pl[tid] = 0ull;
+    __syncthreads();
+    // resolver state: lane x < WMC keeps word x of the pivoted-row mask and counts the unpivoted ones of the pivot columns there
+    // (a single wave issues one instruction of any kind per four cycles: the pivot search runs word-per-lane, not as scalar code)
+    uint64_t Pmine = 0;
+    int racc = 0;
+    int npiv = 0, p = 0;
+#ifdef SWD_OSDPROF // diagnostic build: cycles of the resolver (evaluation, pivots), of a column wave (applying, waiting) and between the barriers
+    long long q_eval = 0, q_res = 0, q_app = 0, q_wait = 0, q_sync = 0, q0_;
+    int q_batches = 0;
+#endif
+    for (;;) {
+        const int npiv0 = npiv, p0 = p;
+#ifdef SWD_OSDPROF
+        q0_ = clock64(); ++q_batches;
+#endif
+        if (wave == 0) {
+            const int pc = p + lane;
+            const bool cval = pc < n;
+            int rows[DM];
+            if (p + NBC <= nst) { // uniform: whole batch inside the staged prefix
+#pragma unroll
+                for (int kk = 0; kk < DM; ++kk) rows[kk] = crows[pc * DM + kk];
+            } else {
+                const int v = cval ? (int)order[pc] : 0;
+                const int deg = cval ? (int)g.col_deg[v] : 0;
+#pragma unroll
+                for (int kk = 0; kk < DM; ++kk) rows[kk] = (kk < deg) ? (int)g.vn_row[kk * n + v] : 0xFFFF;
+            }
+            uint64_t red[WMC];
+#pragma unroll
+            for (int x = 0; x < WMC; ++x) {
+                red[x] = 0ull;
+                if (x < wm) { // uniform
+#pragma unroll
+                    for (int kk = 0; kk < DM; ++kk) red[x] ^= (rows[kk] == 0xFFFF) ? 0ull : Tw[osd_tidx(rows[kk] == 0xFFFF ? 0 : rows[kk], x, m)];
+                }
+            }
+            bool alive = cval;
+            int nb = 0; // pivots of this batch
+#ifdef SWD_OSDPROF
+            q_eval += clock64() - q0_; q0_ = clock64();
+#endif
+            while (npiv < rank) {
+                uint32_t nz = 0;
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) {
+                    const uint64_t pb = Pl[x]; // broadcast read
+                    nz |= (uint32_t)red[x] & ~(uint32_t)pb;
+                    nz |= (uint32_t)(red[x] >> 32) & ~(uint32_t)(pb >> 32);
+                }
+                const unsigned long long bal = __ballot(alive && nz != 0u);
+                if (bal == 0ull) break; // every remaining column of the batch is dependent
+                const int cs = __ffsll((long long)bal) - 1;
+                uint32_t lz = 0;
+                asm volatile("" : "+v"(lz)); // the lane number, recomputed here: kept across the loop it is spilled and reloaded per pivot
+                const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, lz));
+                SWD_LDS_AS uint64_t *ent = ringS + nb * ES;
+                if (ln == cs) { // the pivot column's lane publishes its reduced vector (LDS operations of a wave execute in order)
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) ent[x] = red[x];
+                }
+                asm volatile("" ::: "memory");
+                const uint64_t wv = ent[ln < WMC ? ln : 0];
+                const uint64_t c = (ln < WMC) ? (wv & ~Pmine) : 0ull; // its ones in unpivoted rows, a word per lane
+                const unsigned long long balc = __ballot(c != 0ull);
+                const int fx = __ffsll((long long)balc) - 1;
+                const int bit = __builtin_amdgcn_readlane(__ffsll((long long)c) - 1, fx);
+                racc += __popcll(c); // row additions the reference's LU would apply: unpivoted rows with a one in this column (the pivot itself is taken off at the end)
+                if (ln == fx) {
+                    __hip_atomic_fetch_and(&ent[fx], ~(1ull << bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(&Pl[fx], 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    Pmine |= 1ull << bit;
+                }
+                if (ln == 0) ent[WMC] = (uint64_t)(uint32_t)((fx * 64 + bit) | (cs << 16));
+                asm volatile("" ::: "memory"); // a wave's LDS operations execute in order: the count follows the entry
+                if (ln == 0) ctl[0] = nb + 1;
+                // the batch's later columns under the same row operation
+                const uint32_t ybit = osd_vec_bit<WMC>(red, fx, bit);
+                if (ln <= cs) alive = false;
+                else if (alive && ybit) {
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) red[x] ^= ent[x];
+                }
+                ++npiv; ++nb;
+            }
+            p += NBC;
+#ifdef SWD_OSDPROF
+            q_res += clock64() - q0_; q0_ = clock64();
+#endif
+            int rsum = racc;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) rsum += __shfl_xor(rsum, d, 64);
+            if (lane == 0) {
+                ctl[3] = npiv; ctl[4] = rsum - npiv;
+                ctl[2] = (p < n && npiv < rank) ? 0 : 1;
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) ctl[1] = 1;
+        } else if (colwave) {
+            int done_ops = 0;
+            for (;;) {
+                const int closed = vctl[1]; // read before the count: a closed batch's count is final
+                const int avail = vctl[0];
+#ifdef SWD_OSDPROF
+                q_wait += clock64() - q0_; q0_ = clock64();
+#endif
+                while (done_ops < avail) {
+                    SWD_LDS_AS const uint64_t *ent = ringS + done_ops * ES;
+                    uint64_t S[WMC];
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) S[x] = ent[x];
+                    const int r = __builtin_amdgcn_readfirstlane((int)(uint32_t)ent[WMC]) & 0xFFFF;
+                    const int rw = r >> 6, rbit = r & 63;
+                    if (osd_vec_bit<WMC>(col, rw, rbit)) {
+#pragma unroll
+                        for (int x = 0; x < WMC; ++x) col[x] ^= S[x];
+                    }
+                    ++done_ops;
+                }
+#ifdef SWD_OSDPROF
+                q_app += clock64() - q0_; q0_ = clock64();
+#endif
+                if (closed) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads(); // the batch's row operations are in every column; ctl[] is final
+        const int fin = ctl[2];
+        npiv = ctl[3];
+        p = p0 + NBC;
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; } // nobody reads these two between the barriers
+        if (tid >= 64 && tid - 64 < npiv - npiv0) { // the batch's pivots (another wave than the resolver looks the columns up)
+            const int e = (int)(uint32_t)ringS[(tid - 64) * ES + WMC];
+            piv_col[npiv0 + tid - 64] = order[p0 + (e >> 16)];
+            piv_row[npiv0 + tid - 64] = (uint16_t)(e & 0xFFFF);
+        }
+        if (jc < m) {
+#pragma unroll
+            for (int x = 0; x < WMC; ++x)
+                if (x < wm) Tw[osd_tidx(jc, x, m)] = col[x]; // the mirror (after the last batch: what the higher-order sweep reads)
+        }
+        if (tid < wm) Sbuf[tid] = 0ull; // (used after the last batch)
+        __syncthreads();
+#ifdef SWD_OSDPROF
+        q_sync += clock64() - q0_;
+        if (fin && (tid == 0 || tid == 64) && (blockIdx.x & 63) == 0)
+            printf("osdprof cols thread %d: batches %d pivots %d | resolver: evaluation %lld resolve %lld | column wave: apply %lld wait %lld | rest of the batch %lld cycles\n",
+                   tid, q_batches, npiv, q_eval, q_res, q_app, q_wait, q_sync);
+#endif
+        if (fin) break;
+    }
+    // y = T * s (s in original row order)
+    const bool on = jc < m && synd_b[jc < m ? jc : 0] != 0;
+    if (colwave) {
+#pragma unroll
+        for (int x = 0; x < WMC; ++x) {
+            if (x < wm) { // uniform
+                uint64_t acc = on ? col[x] : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+                if (lane == 0 && acc) atomicXor((unsigned long long *)&Sbuf[x], (unsigned long long)acc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npiv; i += NT) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+    }
+    *npiv_out = npiv;
+    return ctl[4];
+}
+
 // osd0_wave for m <= 256 (wm <= 4): the transform matrix lives in registers -- lane l owns columns
 // l, l+64, l+128, l+192 of T, four words each -- and LDS only holds a mirror that the column
 // evaluations read.  A step evaluates 16 sorted columns against the mirror and then resolves every
@@ -970,12 +1196,6 @@ __device__ __forceinline__ void osd_treg_update(uint64_t (&t)[4][4], int bit, co
             t[q][x] = ((uint64_t)hi << 32) | lo;
         }
     }
-}
-
-__device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // srclane wave-uniform
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, srclane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), srclane);
-    return ((uint64_t)hi << 32) | lo;
 }
 
 template <int DM>
@@ -1297,7 +1517,7 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
 // sort keys (key[v], idx[v] = v, padding ~0 / 0xFFFF) at the start of the scratch region.  Sorts, runs the
 // OSD-0 elimination on wave 0, then the higher-order sweep.  On return s.hard[0..n) holds the OSD
 // solution; the return value is its path metric (sum of g.llr over the solution in column order).
-template <int NT, int DM>
+template <int NT, int DM, bool COLFORM = false> // COLFORM: the caller's kernel can afford osd0_cols (osd_window kernels of 1024 threads)
 __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                           const uint8_t *synd, uint8_t *osd0_b, int &rowadds, long long &t_sorted,
                                           long long &t_elim, bool presorted = false) {
@@ -1318,7 +1538,9 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
     for (int v = tid; v < n; v += NT) s.hard[v] = 0;
     // stage the row lists of the leading sorted columns over the (dead) sort keys
     uint16_t *crows = (uint16_t *)s.scratch;
-    const int nst = min(n, (L.npad * 8) / (DM * 2));
+    bool cols = false; // column-form elimination: 256 < m <= 576 on the 1024-thread variants
+    if constexpr (COLFORM && NT >= 1024) cols = g.wm > 4 && g.wm <= 9 && L.off_oslot >= 0;
+    const int nst = min(n, (cols ? L.off_oslot : L.npad * 8) / (DM * 2));
     for (int p = tid; p < nst; p += NT) {
         const int v = idx[p];
         const int deg = g.col_deg[v];
@@ -1333,8 +1555,12 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
             if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
         }
     } else {
-        int npiv = 0;
-        const int ra = osd0_block<NT, DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
+        int npiv = 0, ra = 0;
+        bool done = false;
+        if constexpr (COLFORM && NT >= 1024) {
+            if (cols) { ra = osd0_cols<NT, DM, 9>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv, s.scratch + L.off_oslot); done = true; }
+        }
+        if (!done) ra = osd0_block<NT, DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
         if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
     }
     __syncthreads();
@@ -1702,7 +1928,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         }
         __syncthreads();
     }
-    R.pm = osd_run<NT, DM>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted);
+    R.pm = osd_run<NT, DM, true>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted);
     R.exit_class = SWD_EXIT_OSD;
 }
 
