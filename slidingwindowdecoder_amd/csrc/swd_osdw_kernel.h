@@ -1960,8 +1960,11 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 // (gfx950's sc1 accesses; the guide lists "sc1 payload -> asm vmcnt(0) -> sc1 flag" as a valid form).
 // A wait that exceeds its 10 s bound sets bit 0 of *status, records exit class SWD_EXIT_SCHED_FAULT for the unit
 // and commits nothing for it: the caller sees the fault (swd_pipeline_status) instead of a plausible wrong answer.
+#ifndef SWD_WAVES_PER_SIMD
+#define SWD_WAVES_PER_SIMD 2 // register budget of the variants below 1024 threads: 256 VGPRs (3: 168, experiments)
+#endif
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
-__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : 2)) pipeline_kernel(const SwdPipeArgs a) {
+__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     // One workgroup decodes ONE window of one shot.  Units are handed out by an atomic ticket in
