@@ -1539,7 +1539,10 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
     // stage the row lists of the leading sorted columns over the (dead) sort keys
     uint16_t *crows = (uint16_t *)s.scratch;
     bool cols = false; // column-form elimination: 256 < m <= 576 on the 1024-thread variants
-    if constexpr (COLFORM && NT >= 1024) cols = g.wm > 4 && g.wm <= 9 && L.off_oslot >= 0;
+    // (not in the column-weight-10 variant: its windows -- SHYPS twelve-round, 252 checks -- never need it, and the mere presence
+    // of the routine in that kernel cost its BP loops registers: 0.61 -> 0.51 M windows/s)
+    constexpr bool kColForm = COLFORM && NT >= 1024 && DM <= 8;
+    if constexpr (kColForm) cols = g.wm > 4 && g.wm <= 9 && L.off_oslot >= 0;
     const int nst = min(n, (cols ? L.off_oslot : L.npad * 8) / (DM * 2));
     for (int p = tid; p < nst; p += NT) {
         const int v = idx[p];
@@ -1557,7 +1560,7 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
     } else {
         int npiv = 0, ra = 0;
         bool done = false;
-        if constexpr (COLFORM && NT >= 1024) {
+        if constexpr (kColForm) {
             if (cols) { ra = osd0_cols<NT, DM, 9>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv, s.scratch + L.off_oslot); done = true; }
         }
         if (!done) ra = osd0_block<NT, DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
