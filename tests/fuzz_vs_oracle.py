@@ -16,10 +16,12 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 mlo, mhi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6, 120)
 mode = sys.argv[5] if len(sys.argv) > 5 else "osdw"  # osdw | gdg | gd | bp
+nlo, nhi = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (0, 2000)  # column range (default: m + 4 .. min(6 m, 2000))
 bad = 0
+ran, threads_seen, osd_shots = 0, set(), 0
 for t in range(trials):
     m = int(rng.integers(mlo, mhi))
-    n = int(rng.integers(m + 4, min(6 * m, 2000)))
+    n = int(rng.integers(max(m + 4, nlo), max(min(6 * m, nhi), max(m + 4, nlo) + 1)))
     dens = rng.uniform(1.5, 4.0) / m
     H = (rng.random((m, n)) < dens).astype(np.uint8)
     for c in range(n):
@@ -73,6 +75,7 @@ for t in range(trials):
     synd[B // 2:] = (rng.random((B - B // 2, m)) < 0.3).astype(np.uint8)  # inconsistent half
     out = dev.decode_batch(synd)
     want, res = ora.decode_batch(synd)
+    ran += 1; threads_seen.add(getattr(dev, "threads", None)); osd_shots += int((res["exit_class"] == 2).sum())
     ok = (out == want).all() and np.array_equal(dev.last_iterations, res["bp_iteration"]) and \
         np.array_equal(dev.last_min_pm, res["min_pm"]) and np.array_equal(dev.last_status & 0xFF, res["exit_class"])
     if not ok:
@@ -83,5 +86,5 @@ for t in range(trials):
               f"classes dev {(dev.last_status[d[:5]] & 0xFF).tolist()} ora {res['exit_class'][d[:5]].tolist()} "
               f"its dev {dev.last_iterations[d[:5]].tolist()} ora {res['bp_iteration'][d[:5]].tolist()} "
               f"vector differs {(out[d[:5]] != want[d[:5]]).sum(axis=1).tolist()} threads {getattr(dev, 'threads', None)}")
-print(f"{trials} trials, {bad} mismatching")
+print(f"{trials} trials ({ran} osd_window comparisons, threads per shot {sorted(x for x in threads_seen if x)}, {osd_shots} shots through OSD), {bad} mismatching")
 sys.exit(1 if bad else 0)

@@ -223,6 +223,19 @@ def test_fuzz_medium_codes_vs_oracle():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_fuzz_large_m_column_form_elimination_vs_oracle():
+    """Randomised matrices with 260..575 checks and 2100..3000 columns: the 1024-thread variants, whose OSD elimination
+    runs in column form (`osd0_cols`: transform matrix in registers of nine waves, pivots resolved by wave 0, row
+    operations through an LDS ring) -- rank-deficient matrices, inconsistent syndromes, all OSD methods."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_vs_oracle.py"), "24", "5", "260", "576", "osdw", "2100", "3000"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("mode", ["gd", "gdg", "bp"])
 def test_fuzz_guessing_decoders_vs_oracle(mode):
     """Randomised matrices and parameters for bpgd_decoder / bpgdg_decoder / bp_history_decoder, including
