@@ -2007,7 +2007,15 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
         uint32_t item = 0;
         if constexpr (KIND == 2) {
             __syncthreads();
-            if (tid == 0) { acc[2] = ring_pop_wait(a.gdgp.q, a.gdgp.qmask, a.status); acc[3] = 0u; }
+            if (tid == 0) {
+                // nothing unclaimed in the ring: admit one more shot instead of waiting (the number of shots under way grows
+                // to what keeps the grid busy and no further -- every queued item waits behind the whole ring)
+                if ((int32_t)(ag_ld(&a.gdgp.q[1]) - ag_ld(&a.gdgp.q[0])) <= 0) {
+                    const uint32_t nb = shots0 + atomicAdd(a.sched, 1u);
+                    if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit((int)nb, 0));
+                }
+                acc[2] = ring_pop_wait(a.gdgp.q, a.gdgp.qmask, a.status); acc[3] = 0u;
+            }
             __syncthreads();
             item = acc[2];
         }
