@@ -237,6 +237,12 @@ def roofline(alg_bytes, avg_kernel_s, shots, plan):
             busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
             fr["valu_issue"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
                                 "counter": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz)", "source": sq_src}
+        if "SQ_ACTIVE_INST_ANY" in c:   # quad-cycles in which a wave has an instruction of any kind in issue, summed over all waves
+            busy = c["SQ_ACTIVE_INST_ANY"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
+            fr["wave_issue"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
+                                "issue_stall_share_of_wave_cycles": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                                "counter": "SQ_ACTIVE_INST_ANY x 4 / (1024 SIMDs x 2.4 GHz): share of a SIMD's quad-cycles with an instruction "
+                                           "of one of its (two) waves in issue", "source": sq_src}
         if "SQ_LDS_IDX_ACTIVE" in c:    # LDS-array cycles summed over the CUs
             busy = c["SQ_LDS_IDX_ACTIVE"] / NUM_CU / PEAK_CLOCK_HZ
             fr["lds"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
@@ -255,10 +261,12 @@ def roofline(alg_bytes, avg_kernel_s, shots, plan):
            "fractions": fr,
            "note": "messages never leave LDS, so SURVEY 8(d)'s algorithmic bytes (40E+17n+2m per executed BP iteration + "
                    "sort + OSD row adds + I/O) exceed what HBM could carry; frac = the highest measured utilisation among "
-                   "VALU issue, LDS array and HBM (counters from profiles/, time measured here with HIP events)"}
+                   "instruction issue of the SIMDs (all instruction kinds), VALU issue alone, LDS array and HBM (counters from "
+                   "profiles/, time measured here with HIP events).  The launch scales 1.76x from one to two workgroups per CU "
+                   "and not at all from two to three (DESIGN.md section 4): what saturates is a SIMD's instruction issue"}
     if fr:
         bound = max(fr, key=lambda k: fr[k]["frac"])
-        out.update({"bound": {"valu_issue": "valu", "lds": "lds", "hbm_measured": "hbm"}[bound], "frac": fr[bound]["frac"]})
+        out.update({"bound": {"wave_issue": "issue", "valu_issue": "valu", "lds": "lds", "hbm_measured": "hbm"}[bound], "frac": fr[bound]["frac"]})
         if bound == "hbm_measured":
             out.update({"achieved": fr[bound]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"})
         else:

@@ -236,7 +236,8 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         if (getenv("SWD_DEBUG")) fprintf(stderr, "[swd] pipeline_kernel<%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs, %d B LDS\n", NT, VF, DM, KG, KIND, per_cu, cus, d->lds_total);
     }
     const long long units = (long long)a.B * a.W;
-    const unsigned grid = (unsigned)std::min<long long>(units, slots[d->device & 63]);
+    static const int grid_pct = getenv("SWD_GRID_PCT") ? std::max(1, atoi(getenv("SWD_GRID_PCT"))) : 100; // diagnostics: how does the launch scale with the workgroups per CU?
+    const unsigned grid = (unsigned)std::min<long long>(units, std::max(1, slots[d->device & 63] * grid_pct / 100));
     if constexpr (KIND == 2) { // work-item ring + contexts of parked trees (swd_gdg_kernel.h); items need per-workgroup scratch
         a.slot_scratch = 1;
         static const int inflight = getenv("SWD_GDG_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_INFLIGHT"))) : 6;
