@@ -61,3 +61,18 @@ def test_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_roofline_is_a_measured_utilisation():
+    """`roofline.frac` is the largest of the measured utilisations (committed counters / a kernel time), never the
+    algorithmic-bytes figure of round 1, and stays below 1 for the committed profile at the committed kernel time."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    line = json.load(open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_TAG}_bench.json")))
+    r = bench.roofline(1.49e11, line["roofline"]["avg_kernel_ms"] * 1e-3, 4096, bench.build_problem())
+    assert r["bound"] in ("issue", "valu", "lds", "hbm") and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - max(v["frac"] for v in r["fractions"].values())) < 1e-12
+    assert r["achieved_algorithmic_over_hbm_peak"] > 1.0  # reported, but not as `frac`
+    assert r["traffic"] >= r["irreducible_hbm_bytes"] > 0
+    assert abs(r["frac"] - line["roofline"]["frac"]) < 0.02 and r["bound"] == line["roofline"]["bound"]
