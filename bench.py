@@ -18,7 +18,7 @@ total split contiguously); one RCCL all_gather of the per-shot decisions (observ
 slidingwindowdecoder_amd.distributed.gather_decisions) closes the job inside the timed region.
 
 Rank 0 prints ONE JSON line.  `roofline`: the kernel keeps its messages in LDS, so HBM is not what bounds it;
-`frac` is the largest of three measured utilisations (VALU issue, LDS array, HBM), each = busy time at the 2.4 GHz
+`frac` is the largest of the measured utilisations (the CU's LDS instruction path, LDS array, VALU issue, HBM), each = busy time at the 2.4 GHz
 peak clock from the committed rocprofv3 counters (profiles/) / the kernel time measured live with HIP events --
 at most 1 by construction.  SURVEY 8(d)'s algorithmic-bytes figure is reported next to it as `achieved_algorithmic`
 (it exceeds the HBM peak: that is the traffic the LDS-resident design avoids, not a utilisation).
@@ -237,12 +237,12 @@ def roofline(alg_bytes, avg_kernel_s, shots, plan):
             busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
             fr["valu_issue"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
                                 "counter": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz)", "source": sq_src}
-        if "SQ_ACTIVE_INST_ANY" in c:   # quad-cycles in which a wave has an instruction of any kind in issue, summed over all waves
-            busy = c["SQ_ACTIVE_INST_ANY"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
-            fr["wave_issue"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
-                                "issue_stall_share_of_wave_cycles": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
-                                "counter": "SQ_ACTIVE_INST_ANY x 4 / (1024 SIMDs x 2.4 GHz): share of a SIMD's quad-cycles with an instruction "
-                                           "of one of its (two) waves in issue", "source": sq_src}
+        if "SQ_ACTIVE_INST_LDS" in c:   # quad-cycles a wave spends issuing LDS instructions, summed over all waves: the LDS unit is one per CU
+            busy = c["SQ_ACTIVE_INST_LDS"] * 4.0 / NUM_CU / PEAK_CLOCK_HZ
+            fr["lds_pipe"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
+                              "counter": "SQ_ACTIVE_INST_LDS x 4 / (256 CUs x 2.4 GHz): time the waves of a CU spend issuing LDS instructions "
+                                         "(a ds_write_b64 occupies the CU's LDS path ~6 cycles, a ds_read_b64 ~2: scripts/ubench/issue_rates.hip)",
+                              "source": sq_src}
         if "SQ_LDS_IDX_ACTIVE" in c:    # LDS-array cycles summed over the CUs
             busy = c["SQ_LDS_IDX_ACTIVE"] / NUM_CU / PEAK_CLOCK_HZ
             fr["lds"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
@@ -261,12 +261,17 @@ def roofline(alg_bytes, avg_kernel_s, shots, plan):
            "fractions": fr,
            "note": "messages never leave LDS, so SURVEY 8(d)'s algorithmic bytes (40E+17n+2m per executed BP iteration + "
                    "sort + OSD row adds + I/O) exceed what HBM could carry; frac = the highest measured utilisation among "
-                   "instruction issue of the SIMDs (all instruction kinds), VALU issue alone, LDS array and HBM (counters from "
-                   "profiles/, time measured here with HIP events).  The launch scales 1.76x from one to two workgroups per CU "
-                   "and not at all from two to three (DESIGN.md section 4): what saturates is a SIMD's instruction issue"}
+                   "the CU's LDS instruction path, the LDS array, VALU issue and HBM (counters from profiles/, time measured "
+                   "here with HIP events).  The launch scales 1.76x from one to two workgroups per CU and not at all from two "
+                   "to three (DESIGN.md section 4)"}
+    if sq and "SQ_ACTIVE_INST_ANY" in sq["per_launch_mean"] and sq["per_launch_mean"].get("SQ_WAVE_CYCLES"):
+        c = sq["per_launch_mean"]  # how the waves spend their cycles (not a capacity: two waves of a SIMD can issue different kinds together)
+        out["wave_cycles"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "parked_waitcnt_or_barrier": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                              "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]}
+    out = dict(out)
     if fr:
         bound = max(fr, key=lambda k: fr[k]["frac"])
-        out.update({"bound": {"wave_issue": "issue", "valu_issue": "valu", "lds": "lds", "hbm_measured": "hbm"}[bound], "frac": fr[bound]["frac"]})
+        out.update({"bound": {"lds_pipe": "lds", "valu_issue": "valu", "lds": "lds", "hbm_measured": "hbm"}[bound], "frac": fr[bound]["frac"]})
         if bound == "hbm_measured":
             out.update({"achieved": fr[bound]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"})
         else:

@@ -71,7 +71,7 @@ def test_roofline_is_a_measured_utilisation():
     import bench
     line = json.load(open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_TAG}_bench.json")))
     r = bench.roofline(1.49e11, line["roofline"]["avg_kernel_ms"] * 1e-3, 4096, bench.build_problem())
-    assert r["bound"] in ("issue", "valu", "lds", "hbm") and 0.0 < r["frac"] < 1.0
+    assert r["bound"] in ("valu", "lds", "hbm") and 0.0 < r["frac"] < 1.0
     assert abs(r["frac"] - max(v["frac"] for v in r["fractions"].values())) < 1e-12
     assert r["achieved_algorithmic_over_hbm_peak"] > 1.0  # reported, but not as `frac`
     assert r["traffic"] >= r["irreducible_hbm_bytes"] > 0
