@@ -136,8 +136,8 @@ def cpu_baseline(order, shots_per_core=192):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shots", type=int, default=4096, help="shots per GPU per step (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-shots", type=int, default=4096 * 8, help="shots per step over all GPUs (strong scaling)")
