@@ -39,6 +39,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 DECODER_KW = dict(pre_max_iter=8, post_max_iter=200, ms_scaling_factor=1.0, new_n=None, osd_method="osd_cs")
+GDG_KW = dict(decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+              max_tree_branch_step=10, max_side_branch_step=10)  # `Sliding Window GDG.ipynb` cell 3
+# --workload: the headline (BASELINE configs[1], what the driver measures) or one of the other circuit-level configurations
+# under the same launcher / sharding / gather (north star: "reported at 1, 2, 4 and 8 GPUs")
+WORKLOADS = {
+    "headline": dict(problem=dict(), metric="sliding windows decoded/s, [[144,12,12]] BB p=0.003",
+                     desc="configs[1]: [[144,12,12]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(3,1) -> 11 windows/shot, "
+                          "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d)"),
+    "gdg": dict(problem=dict(), metric="sliding windows decoded/s, [[144,12,12]] BB p=0.003, bpgdg_decoder",
+                desc="configs[2]: [[144,12,12]] BB, circuit-level p=0.003, (3,1) windows, bpgdg_decoder(max_iter=8, T=6, R=25, D=3, S=10)"),
+    "bb288": dict(problem=dict(N=288, W=4, F=1), metric="sliding windows decoded/s, [[288,12,18]] BB p=0.003",
+                  desc="configs[3]: [[288,12,18]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(4,1), "
+                       "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d)"),
+}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9   # same guide: max clock
 NUM_CU, SIMD_PER_CU = 256, 4
@@ -140,6 +154,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shots", type=int, default=4096, help="shots per GPU per step (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline",
+                    help="headline = BASELINE configs[1] (default; the only one with roofline / cpu_baseline); gdg, bb288 = configs[2], [3]")
     ap.add_argument("--total-shots", type=int, default=4096 * 8, help="shots per step over all GPUs (strong scaling)")
     ap.add_argument("--osd-order", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,13 +204,14 @@ class StubEngine:
 
 
 class GpuEngine:
-    def __init__(self, args, rank, local_rank, lo, hi, plan, order):
+    def __init__(self, args, rank, local_rank, lo, hi, plan, order, workload="headline"):
         import torch
         from slidingwindowdecoder_amd import DemSampler, SlidingWindowDecoder
         self.torch = torch
         self.dev = torch.device("cuda", local_rank)
         self.plan, self.W = plan, len(plan.windows)
-        self.dec = SlidingWindowDecoder(plan, device=local_rank, **dict(DECODER_KW, osd_order=order))
+        kw = dict(GDG_KW) if workload == "gdg" else dict(DECODER_KW, osd_order=order)
+        self.dec = SlidingWindowDecoder(plan, device=local_rank, **kw)
         shots = hi - lo
         self.nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
         # synthetic shots sampled from the DEM on the device: Philox stream keyed by the global shot number, so the
@@ -319,7 +336,7 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} but the job has WORLD_SIZE={world}")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and args.workload == "headline":
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)
 
     import torch
@@ -341,8 +358,10 @@ def main():
 
     total_shots = args.shots * world if args.scaling == "weak" else args.total_shots
     lo, hi = shard_bounds(total_shots, rank, world)
-    plan = None if STUB else build_problem()
-    engine = StubEngine(args, rank, lo, hi) if STUB else GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order)
+    wl = WORKLOADS[args.workload]
+    headline = args.workload == "headline"
+    plan = None if STUB else build_problem(**wl["problem"])
+    engine = StubEngine(args, rank, lo, hi) if STUB else GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload)
     W = engine.W
     if not STUB:
         engine.dec.set_timing(True)  # HIP events around every kernel launch, on the launch stream
@@ -350,7 +369,7 @@ def main():
     assert gathered.shape[0] == total_shots, (gathered.shape, total_shots)
 
     line = {
-        "metric": "sliding windows decoded/s, [[144,12,12]] BB p=0.003",
+        "metric": wl["metric"],
         "value": total_shots * W * args.steps / elapsed,
         "unit": "windows/s",
         "n_gpus": world,
@@ -385,12 +404,12 @@ def main():
     last = (args.warmup + args.steps - 1) % engine.nb
     sr = engine.shot.cpu().numpy()
     logical = (sr[:, 0].astype(np.int64) != engine.obs_true[last]) | (sr[:, 1] != 0)
-    alg_bytes = algorithmic_bytes(plan, st, DECODER_KW["pre_max_iter"])
+    alg_bytes = algorithmic_bytes(plan, st, DECODER_KW["pre_max_iter"]) if headline else None
     cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
     avg_kernel_s = kern_ms / max(launches, 1) / 1e3
 
     order10 = None
-    if rank == 0 and world == 1 and not args.no_order10 and args.osd_order != 10:
+    if rank == 0 and world == 1 and headline and not args.no_order10 and args.osd_order != 10:
         # the notebooks' default OSD-CS order 10 on the same batches (a second, untimed-by-the-driver loop)
         e10 = GpuEngine(args, rank, local_rank, lo, hi, plan, 10)
         k10 = max(1, min(args.steps, 5))
@@ -404,10 +423,8 @@ def main():
 
     if rank == 0:
         line["config"] = {
-            "workload": "configs[1]: [[144,12,12]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(3,1) -> 11 windows/shot, "
-                        "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d), %s"
-                        % (args.osd_order, f"{args.shots} shots per GPU per step" if args.scaling == "weak"
-                           else f"{total_shots} shots per step split over the GPUs"),
+            "workload": (wl["desc"] % args.osd_order if "%d" in wl["desc"] else wl["desc"]) + ", "
+                        + (f"{args.shots} shots per GPU per step" if args.scaling == "weak" else f"{total_shots} shots per step split over the GPUs"),
             "world_size": world, "shots_total": total_shots, "shots_rank0": hi - lo, "windows_per_shot": W,
             "parallelism": f"shots sharded over {world} GPU(s), no data-path collective; one all_gather of 8 B per shot",
             "exit_classes_pre_post_osd_rank0": [int(cls[0]), int(cls[1]), int(cls[2])],
@@ -415,8 +432,9 @@ def main():
             "logical_errors_last_step_rank0": int(logical.sum()),
             "osd_cs_order10_windows_per_s": order10,
         }
-        line["roofline"] = roofline(alg_bytes, avg_kernel_s, hi - lo, plan)
-        line["cpu_baseline"] = cpu
+        # roofline and CPU baseline belong to the headline kernel and its committed counter profile
+        line["roofline"] = roofline(alg_bytes, avg_kernel_s, hi - lo, plan) if headline else None
+        line["cpu_baseline"] = cpu if headline else None
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -76,3 +76,14 @@ def test_roofline_is_a_measured_utilisation():
     assert r["achieved_algorithmic_over_hbm_peak"] > 1.0  # reported, but not as `frac`
     assert r["traffic"] >= r["irreducible_hbm_bytes"] > 0
     assert abs(r["frac"] - line["roofline"]["frac"]) < 0.02 and r["bound"] == line["roofline"]["bound"]
+
+
+def test_other_workloads_share_the_launcher():
+    """`--workload gdg|bb288` runs configs[2] / configs[3] under the same launcher, sharding and gather (stub: CPU)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert set(bench.WORKLOADS) == {"headline", "gdg", "bb288"}
+    assert bench.parse_args(["--workload", "bb288"]).workload == "bb288" and bench.parse_args([]).workload == "headline"
+    r, lines = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--shots", "37", "--workload", "gdg")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["gather_ok"] is True and "bpgdg_decoder" in lines[0]["metric"]
