@@ -42,8 +42,8 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     scratch = std::max(scratch, L.off_hs + n * 8);
     scratch = align_up(scratch, 16);
     int o = scratch;
-    L.off_livemask = o; o += m * 8;
-    L.off_par = o; o += (m + 1) * 4; // par[m]: sink for the dead positions' parity flips
+    L.off_livemask = o; o += (kind == 0 && g.K <= 48) ? align_up(m * 6, 4) : m * 8; // osd_window layouts: 32 + 16 bits per check when the row weight allows
+    L.off_par = o; o += align_up(m + 1, 4); // one parity byte per check; byte m: sink for the dead positions' flips
     L.off_lv = o; o = align_up(o + new_n * 2, 4);
     L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
     // live-slot lists: osd_window stages them in the (then dead) scratch region; the guessing decoders
@@ -58,8 +58,16 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     }
     L.off_cnval = o; o += m;
     L.off_cndeg = o; o += m;
+#if 1 // the osd_window layout (kind 0) is the diet form: swd_osdw_kernel.h, SWD_VNBITS
+    L.off_cndeg0 = o; o += (kind == 0) ? 0 : m; // osd_window kernels read the original degrees from the graph
+#else
     L.off_cndeg0 = o; o += m;
+#endif
+#if 1 // the osd_window layout (kind 0) is the diet form: swd_osdw_kernel.h, SWD_VNBITS // osd_window kernels keep one "decided" bit per variable node (swd_osdw_kernel.h, vn_decided), the guessing decoders a byte
+    L.off_vnval = o = align_up(o, 4); o += (kind == 0) ? ((n + 31) / 32) * 4 : n;
+#else
     L.off_vnval = o; o += n;
+#endif
     L.off_hard = o; o = align_up(o + n + 1, 16); // +1: sink for threads without a VN
     L.off_misc = o; o += 640; // flags[32] scal[32] dbl[24] iaux[32]
     L.total = align_up(o, 16);
@@ -121,6 +129,15 @@ const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int
     for (const Variant &v : kVariants) {
         if (!(kind == 0 ? v.launch != nullptr : v.launch_gdg != nullptr)) continue;
         if (!(v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm)) continue;
+        if (kind == 0 && v.nt <= 256) { // these kernels keep LDS byte offsets in 16 bits (swd_osdw_kernel.h, P16)
+            bool fits = true;
+            for (auto &w : wins) {
+                SwdLdsLayout L{};
+                make_layout(*w.g, w.new_n, v.nt, kind, L);
+                if (L.total > 65536) { fits = false; break; }
+            }
+            if (!fits) continue;
+        }
         if (!v.sf) { if (4 * v.kg >= kmax) return &v; continue; }
         bool ok = true;
         for (auto &w : wins) {

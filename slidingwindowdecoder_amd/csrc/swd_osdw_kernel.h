@@ -15,6 +15,17 @@
 
 #define SWD_DMAX 10 // largest column degree any kernel variant of this build supports
 
+// Translation units of the osd_window kernels (swd_kernels_k0 / k3) set SWD_OSDW_TUNED: their kernels of up to 256 threads
+// keep the BP register caches packed (VnCache / CnCache, P16) and -- variants with at most twelve groups of check
+// positions -- are built for three waves per SIMD (168 VGPRs); together with the LDS diet of the osd_window layout
+// (SWD_VNBITS: decided-node bits, 48-bit live masks, parity bytes, residual syndrome of the window's rows only) three
+// workgroups of the <256, 7, 6, 9> kernel fit a CU (53 600 B of LDS each; the hardware's limit is 53 760, not the
+// 54 592 the occupancy API accepts: scripts/residency_check.py).
+#ifndef SWD_OSDW_TUNED
+#define SWD_OSDW_TUNED 0
+#endif
+#define SWD_P16(NT) (SWD_OSDW_TUNED && (NT) <= 256)
+
 struct SwdLdsLayout {
     int32_t off_livemask, off_par, off_lv, off_jptr, off_lslot, off_cnval, off_cndeg, off_cndeg0, off_vnval, off_hard,
         off_misc, total;
@@ -117,7 +128,8 @@ namespace swd {
 struct Lds {
     double *msg;        // scratch region start
     char *scratch;
-    uint64_t *livemask; // [m]
+    uint64_t *livemask; // [m]  (diet form: u32 [m] + u16 [m], see lm_get)
+    int lm_m;           // m (diet form)
     uint32_t *par;      // [m]
     uint16_t *lv;       // [new_n]
     uint16_t *jptr;     // [K+1]
@@ -245,10 +257,36 @@ __device__ __forceinline__ void wave_fence() {
 // ed = byte offset of the edge's message slot (a ready LDS address: nothing to recompute or to keep a
 // second copy of per iteration); par = index into par[] of the edge's check, two per word, m for
 // dead positions.
-template <int VF, int DM>
+// P16 (kernels whose LDS offsets fit 16 bits: the osd_window kernels of up to 256 threads): two offsets per register,
+// unpacked where they are used (sub-dword operand selects, no instruction) behind an asm statement that keeps the
+// unpacking inside the iteration loop -- hoisted out of it, the 32-bit copies would take the registers back.  With the
+// packed caches the <256, 7, 6, 9> kernel needs no spill at 248 VGPRs and one reload per BP loop at the 168 of three
+// waves per SIMD.
+template <int VF, int DM, bool P16 = false>
 struct VnCache {
     double llr[VF];
     uint32_t ed[VF][DM];
+    __device__ __forceinline__ void set_ed(int i, int k, uint32_t v) { ed[i][k] = v; }
+    __device__ __forceinline__ void get_ed(int i, uint32_t (&ad)[DM]) const {
+#pragma unroll
+        for (int k = 0; k < DM; ++k) ad[k] = ed[i][k];
+    }
+    uint32_t par[VF][(DM + 1) / 2];
+};
+template <int VF, int DM>
+struct VnCache<VF, DM, true> {
+    static_assert(DM % 2 == 0, "edge offsets are packed in pairs");
+    double llr[VF];
+    uint32_t edp[VF][DM / 2];
+    __device__ __forceinline__ void set_ed(int i, int k, uint32_t v) { edp[i][k >> 1] = (k & 1) ? ((edp[i][k >> 1] & 0xFFFFu) | (v << 16)) : ((edp[i][k >> 1] & 0xFFFF0000u) | v); }
+    __device__ __forceinline__ void get_ed(int i, uint32_t (&ad)[DM]) const {
+#pragma unroll
+        for (int k = 0; k < DM; k += 2) {
+            uint32_t w = edp[i][k >> 1];
+            asm volatile("" : "+v"(w));
+            ad[k] = w & 0xFFFFu; ad[k + 1] = w >> 16;
+        }
+    }
     uint32_t par[VF][(DM + 1) / 2];
 };
 
@@ -256,8 +294,8 @@ __device__ __forceinline__ int swd_slot_far(const SwdGraphDev &g) { return g.E +
 template <int NT>
 __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E + 1 + NT / 64 + (int)(threadIdx.x >> 6); }
 
-template <int NT, int VF, int DM, bool FULL>
-__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCache<VF, DM> &c) {
+template <int NT, int VF, int DM, bool FULL, class VC>
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VC &c) {
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
 #pragma unroll
@@ -265,7 +303,7 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
         const int idx = s.vtid + i * NT;
         c.llr[i] = 0.0;
 #pragma unroll
-        for (int k = 0; k < DM; ++k) c.ed[i][k] = dead;
+        for (int k = 0; k < DM; ++k) c.set_ed(i, k, dead);
 #pragma unroll
         for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
         if (idx < cnt) {
@@ -277,7 +315,7 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
                 if (k < deg) {
                     const uint32_t e = g.vn_edge[k * n + v];
                     if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
-                        c.ed[i][k] = swd_edge_slot(e) << 3;
+                        c.set_ed(i, k, swd_edge_slot(e) << 3);
                         c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
                                                    : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
                     }
@@ -290,12 +328,14 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
 __device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
-template <int VF, int DM>
-__device__ __forceinline__ void bp_init(Lds &s, const VnCache<VF, DM> &c) {
+template <int VF, int DM, class VC>
+__device__ __forceinline__ void bp_init(Lds &s, const VC &c) {
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
+        uint32_t ad[DM];
+        c.get_ed(i, ad);
 #pragma unroll
-        for (int k = 0; k < DM; ++k) swd_msg_at(s, c.ed[i][k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
+        for (int k = 0; k < DM; ++k) swd_msg_at(s, ad[k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
     }
 }
 
@@ -308,20 +348,48 @@ __device__ __forceinline__ int wave_max(int x) {
 // Per-thread register cache of the check a lane owns during one BP phase: the LDS slots of its
 // edges (u16, two per register) in walk order; unused / dead positions hold the wave's far slot.
 // KG = groups of four positions.
-template <int KG>
+template <int KG, bool P16 = false>
 struct CnCache {
     uint16_t sl[KG * 4];
+    __device__ __forceinline__ void set_slot(int k, int slot) { sl[k] = (uint16_t)slot; }
+    __device__ __forceinline__ void group(int gq, uint32_t (&ad)[4]) const { // byte offsets of positions 4 gq .. 4 gq + 3
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ad[u] = (uint32_t)sl[gq * 4 + u] << 3;
+    }
     int cnt;  // positions to walk (0 for lanes without a live check)
     int live; // live edges among them
     int l;    // the check (lane numbering of the graph) this thread serves, -1 for none
     int sub;  // which of the check's grp threads this is (it walks positions sub, sub + grp, ...)
     int grp;  // 1, 2 or 4 adjacent threads (lanes of one quad) share the check
-    __device__ __forceinline__ int slot(int k) const { return (int)sl[k]; }
+};
+template <int KG>
+struct CnCache<KG, true> {
+    uint32_t slp[KG * 2]; // byte offsets, two per register
+    __device__ __forceinline__ void set_slot(int k, int slot) { const uint32_t v = (uint32_t)slot << 3; slp[k >> 1] = (k & 1) ? ((slp[k >> 1] & 0xFFFFu) | (v << 16)) : ((slp[k >> 1] & 0xFFFF0000u) | v); }
+    __device__ __forceinline__ void group(int gq, uint32_t (&ad)[4]) const {
+        uint32_t w0 = slp[2 * gq], w1 = slp[2 * gq + 1];
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        ad[0] = w0 & 0xFFFFu; ad[1] = w0 >> 16; ad[2] = w1 & 0xFFFFu; ad[3] = w1 >> 16;
+    }
+    int cnt, live, l, sub, grp;
 };
 
+// Live-position masks of the checks: 64 bits per check, or -- osd_window layouts of graphs with row weight <= 48 (s.lm_m != 0) --
+// 32 + 16 bits in two arrays.
+__device__ __forceinline__ uint64_t lm_get(const Lds &s, int l) {
+    if (s.lm_m == 0) return s.livemask[l];
+    const uint32_t *lo = (const uint32_t *)s.livemask; const uint16_t *hi = (const uint16_t *)(lo + s.lm_m);
+    return (uint64_t)lo[l] | ((uint64_t)hi[l] << 32);
+}
+__device__ __forceinline__ void lm_set(Lds &s, int l, uint64_t v) {
+    if (s.lm_m == 0) { s.livemask[l] = v; return; }
+    uint32_t *lo = (uint32_t *)s.livemask; uint16_t *hi = (uint16_t *)(lo + s.lm_m);
+    lo[l] = (uint32_t)v; hi[l] = (uint16_t)(v >> 32);
+}
+
 // grp = 1, 2 or 4 threads share a check (adjacent lanes of a quad): thread `sub` walks positions sub, sub + grp, ...
-template <int NT, int KG, bool FULL>
-__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCache<KG> &cc) {
+template <int NT, int KG, bool FULL, class CC>
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CC &cc) {
     const int m = g.m, dummy = swd_slot_far(g);
     const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
     const int l = act ? lc : 0;
@@ -330,8 +398,12 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
     cc.grp = grp;
     // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
     const bool bylist = !FULL && uselist;
+#ifdef SWD_VNBITS // (the LDS diet of the osd_window kernels: no copy of the original degrees either)
+    const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)g.row_deg[l]) : 0;
+#else
     const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
-    const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : s.livemask[l];
+#endif
+    const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : lm_get(s, l);
     cc.cnt = (cnt > sub) ? (cnt - sub + grp - 1) / grp : 0;
     cc.live = act ? (int)s.cn_deg[l] : 0;
 #pragma unroll
@@ -340,7 +412,7 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
         int sv = dummy;
         if (k < cnt && ((lmask >> (k & 63)) & 1ull))
             sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
-        cc.sl[kk] = (uint16_t)sv;
+        cc.set_slot(kk, sv);
     }
 }
 
@@ -431,9 +503,9 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // max_iter iterations, and with max_iter a multiple of four slot order is chronological order of the last four
 // iterations: the sum is accumulated in registers (hs[i] for the i-th variable node of the thread) in exactly
 // that order and the 4 x n ring in HBM is neither written nor read.
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false>
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, class VC, class CC>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
-                      const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
+                      const VC &c, const CC &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
@@ -468,8 +540,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         BPT(tc0);
         {
             if (cv >= 0 && cn.sub == 0) {
-                if (it > 0 && s.par[l] != 0u) unsat = true;
-                s.par[l] = (uint32_t)cv;
+                if (it > 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
+                ((uint8_t *)s.par)[l] = (uint8_t)cv; // one parity byte per check, flipped by word atomics (bit 8 (l & 3) of word l >> 2)
             }
             // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
             // group of four are independent.  The two-minimum update
@@ -478,7 +550,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             // (A hand-made software pipeline over the groups was faster with the default machine scheduler and
             // is slower with iterative-ilp, which overlaps the reads of the next group by itself.)
             double min1 = 1e308, min2 = 1e308;
-            int argslot = farslot;
+            uint32_t argslot = (uint32_t)farslot << 3; // byte offset of the first position holding the minimum
             uint32_t neg[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) neg[r] = 0;
@@ -486,13 +558,15 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             for (int gq = 0; gq < KG; ++gq) {
                 if (gq * 4 < wmax) { // wave-uniform
                     double xs[4];
+                    uint32_t ad[4];
+                    cn.group(gq, ad);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xs[u] = s.msg[cn.slot(gq * 4 + u)];
+                    for (int u = 0; u < 4; ++u) xs[u] = swd_msg_at(s, ad[u]);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = gq * 4 + u;
                         const double ax = vminabs64(xs[u], 50.0);
-                        argslot = (ax < min1) ? cn.slot(k) : argslot;
+                        argslot = (ax < min1) ? ad[u] : argslot;
                         min2 = vmin64(min2, vmax64(min1, ax));
                         min1 = vmin64(min1, ax);
                         neg_shift_in(neg[k >> 5], xs[u]);
@@ -513,7 +587,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 // as "first minimum" does not change any value written below.
                 {
                     const double o1 = quad_xor<1>(min1), o2 = quad_xor<1>(min2);
-                    const int oa = quad_xor<1>(argslot), op = quad_xor<1>(npar);
+                    const uint32_t oa = (uint32_t)quad_xor<1>((int)argslot); const int op = quad_xor<1>(npar);
                     if (cn.grp >= 2) {
                         npar += op;
                         argslot = (o1 < min1) ? oa : argslot;
@@ -523,7 +597,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 }
                 {
                     const double o1 = quad_xor<2>(min1), o2 = quad_xor<2>(min2);
-                    const int oa = quad_xor<2>(argslot), op = quad_xor<2>(npar);
+                    const uint32_t oa = (uint32_t)quad_xor<2>((int)argslot); const int op = quad_xor<2>(npar);
                     if (cn.grp == 4) {
                         npar += op;
                         argslot = (o1 < min1) ? oa : argslot;
@@ -535,26 +609,28 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
             // the first position holding the minimum gets the second minimum (ties: both equal).
             // Its own sign is re-read before the slots are overwritten.
-            const double xarg = s.msg[argslot];
+            const double xarg = swd_msg_at(s, argslot);
             if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
             const double p1 = min1 * alpha, p2 = min2 * alpha;
             const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
 #pragma unroll
             for (int gq = 0; gq < KG; ++gq) {
                 if (gq * 4 < wmax) {
+                    uint32_t ad[4];
+                    cn.group(gq, ad);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = gq * 4 + u;
                         const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
                         const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
-                        s.msg[cn.slot(k)] = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
+                        swd_msg_at(s, ad[u]) = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
                     }
                 }
             }
             {
                 const uint32_t sb = (((xarg <= 0) ? 0xFFFFFFFFu : 0u) ^ flip) & 0x80000000u;
                 const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
-                s.msg[argslot] = __longlong_as_double((long long)b2);
+                swd_msg_at(s, argslot) = __longlong_as_double((long long)b2);
                 s.msg[farslot] = 64.0; // re-arm
             }
         }
@@ -578,8 +654,10 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 const bool valid = idx < vcnt;
                 const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
                 double cc[DM], pre[DM];
+                uint32_t ad[DM];
+                c.get_ed(i, ad);
 #pragma unroll
-                for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, c.ed[i][k]);
+                for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, ad[k]);
                 double temp = c.llr[i];
 #pragma unroll
                 for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
@@ -593,7 +671,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 double suf = 0.0;
 #pragma unroll
                 for (int k = DM - 1; k >= 0; --k) {
-                    swd_msg_at(s, c.ed[i][k]) = pre[k] + suf;
+                    swd_msg_at(s, ad[k]) = pre[k] + suf;
                     suf = suf + cc[k];
                 }
                 s.msg[zeroslot] = 0.0; // re-arm
@@ -602,8 +680,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
                         uint32_t pw = c.par[i][k2];
                         asm volatile("" : "+v"(pw));
-                        atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u);
-                        if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
+                        atomicXor((uint32_t *)(parb + (pw & 0xFFFCu)), 1u << ((pw & 3u) << 3));
+                        if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
                     }
                 }
             }
@@ -619,7 +697,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #endif
     bool unsat = force_unsat;
     for (int l = tid; l < m; l += NT)
-        if (s.cn_val[l] >= 0 && s.par[l] != 0u) unsat = true;
+        if (s.cn_val[l] >= 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
     const bool any = block_any<NT>(unsat, s);
     iters_done = max_iter;
     return any ? 0 : 1;
@@ -645,6 +723,43 @@ __device__ __forceinline__ void sort_pairs(uint64_t *key, uint16_t *idx, int npa
         }
     }
 }
+
+// Decided variable nodes.  Byte form (guessing decoders): vn_val[v] = -1 live / decided value.  Bit form (SWD_VNBITS, the
+// osd_window kernels: 1.7 KB of LDS less per [[144]] window, which is what lets a third workgroup onto the CU): one
+// "decided" bit per node in the same array, the decided value is what hard[v] holds -- nothing writes hard[v] of a
+// decided node afterwards (the post phase only stores decisions of live nodes).
+#ifdef SWD_VNBITS
+__device__ __forceinline__ bool vn_decided(const Lds &s, int v) { return (((const uint32_t *)s.vn_val)[v >> 5] >> (v & 31)) & 1u; }
+__device__ __forceinline__ int vn_value(const Lds &s, int v) { return vn_decided(s, v) ? (int)s.hard[v] : -1; }
+__device__ __forceinline__ void vn_mark0(Lds &s, int v) { atomicOr(&((uint32_t *)s.vn_val)[v >> 5], 1u << (v & 31)); } // decided 0; hard[v] follows before anybody asks for the value
+__device__ __forceinline__ void vn_decide(Lds &s, int v, int val) { atomicOr(&((uint32_t *)s.vn_val)[v >> 5], 1u << (v & 31)); s.hard[v] = (uint8_t)val; }
+template <int NT> __device__ __forceinline__ void vn_reset(Lds &s, int n) {
+    for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)s.vn_val)[i] = 0u;
+    for (int v = threadIdx.x; v < n; v += NT) s.hard[v] = 0;
+}
+template <int NT> __device__ __forceinline__ void vn_backup(const Lds &s, int n, char *bak) { // bak: n bytes for the marks, n for hard
+    for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)bak)[i] = ((const uint32_t *)s.vn_val)[i];
+    for (int i = threadIdx.x; i < n; i += NT) bak[n + i] = (char)s.hard[i];
+}
+template <int NT> __device__ __forceinline__ void vn_restore(Lds &s, int n, const char *bak) {
+    for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)s.vn_val)[i] = ((const uint32_t *)bak)[i];
+    for (int i = threadIdx.x; i < n; i += NT) s.hard[i] = (uint8_t)bak[n + i];
+}
+#else
+__device__ __forceinline__ bool vn_decided(const Lds &s, int v) { return s.vn_val[v] >= 0; }
+__device__ __forceinline__ int vn_value(const Lds &s, int v) { return s.vn_val[v]; }
+__device__ __forceinline__ void vn_mark0(Lds &s, int v) { s.vn_val[v] = 0; }
+__device__ __forceinline__ void vn_decide(Lds &s, int v, int val) { s.vn_val[v] = (int8_t)val; s.hard[v] = (uint8_t)val; }
+template <int NT> __device__ __forceinline__ void vn_reset(Lds &s, int n) {
+    for (int v = threadIdx.x; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
+}
+template <int NT> __device__ __forceinline__ void vn_backup(const Lds &s, int n, char *bak) {
+    for (int i = threadIdx.x; i < n; i += NT) { bak[i] = (char)s.vn_val[i]; bak[n + i] = (char)s.hard[i]; }
+}
+template <int NT> __device__ __forceinline__ void vn_restore(Lds &s, int n, const char *bak) {
+    for (int i = threadIdx.x; i < n; i += NT) { s.vn_val[i] = (int8_t)bak[i]; s.hard[i] = (uint8_t)bak[n + i]; }
+}
+#endif
 
 // Marks everything but the `keep` smallest (key, index) pairs: vn_val[v] = 0 for the columns the
 // reference's stable argsort (index_sort, bpgd.cpp:384-389) puts at positions keep.. (osd_window.pyx:
@@ -696,7 +811,7 @@ __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int 
     const int v0 = tid * ch, v1 = min(n, v0 + ch);
     if (exact) {
         for (int v = tid; v < n; v += NT)
-            if ((key[v] & pmask) > prefix) s.vn_val[v] = 0;
+            if ((key[v] & pmask) > prefix) vn_mark0(s, v);
         __syncthreads();
         return;
     }
@@ -706,8 +821,8 @@ __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int 
     int rank = block_exscan<NT>(eq, s, tot);
     for (int v = v0; v < v1; ++v) {
         const uint64_t k = key[v];
-        if (k > prefix) s.vn_val[v] = 0;
-        else if (k == prefix) { if (rank >= need) s.vn_val[v] = 0; ++rank; }
+        if (k > prefix) vn_mark0(s, v);
+        else if (k == prefix) { if (rank >= need) vn_mark0(s, v); ++rank; }
     }
     __syncthreads();
 }
@@ -742,7 +857,7 @@ __device__ __forceinline__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint1
 __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, int vn, int value) {
     const int lane = threadIdx.x & 63;
     const int deg = g.col_deg[vn];
-    if (lane == 0) { s.vn_val[vn] = (int8_t)value; s.hard[vn] = (uint8_t)value; }
+    if (lane == 0) vn_decide(s, vn, value);
     bool bad = false;
     if (lane < deg) {
         const uint32_t e = g.vn_edge[lane * g.n + vn];
@@ -751,7 +866,7 @@ __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, 
         if (cv >= 0) {
             const int d = (int)s.cn_deg[l] - 1;
             if (value) cv ^= 1;
-            s.livemask[l] &= ~(1ull << j);
+            lm_set(s, l, lm_get(s, l) & ~(1ull << j));
             if (d == 0) {
                 if (cv != 0) bad = true;
                 cv = -1;
@@ -787,7 +902,7 @@ __device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
         if (best_all == 0x7fffffff) return false;
         const int c = (best_ge != 0x7fffffff) ? best_ge : best_all;
         const int l = g.iperm[c];
-        const uint64_t mk = s.livemask[l];
+        const uint64_t mk = lm_get(s, l);
         const int j = __ffsll((long long)mk) - 1;
         const int vn = g.row_col[s.jptr[j] + l];
         const int val = s.cn_val[l];
@@ -1587,6 +1702,7 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
     s.scratch = smem;
     s.msg = (double *)smem;
     s.livemask = (uint64_t *)(smem + L.off_livemask);
+    s.lm_m = (L.off_par - L.off_livemask < 8 * (L.off_cndeg - L.off_cnval)) ? (L.off_cndeg - L.off_cnval) : 0; // m if the masks are stored in the 48-bit form
     s.par = (uint32_t *)(smem + L.off_par);
     s.lv = (uint16_t *)(smem + L.off_lv);
     s.jptr = (uint16_t *)(smem + L.off_jptr);
@@ -1618,20 +1734,22 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         const int d = g.row_deg[l];
         s.cn_val[l] = (int8_t)(synd[g.perm[l]] ? 1 : 0);
         s.cn_deg[l] = (uint8_t)d;
+#ifndef SWD_VNBITS
         s.cn_deg0[l] = (uint8_t)d;
-        s.livemask[l] = (d >= 64) ? ~0ull : ((1ull << d) - 1ull);
+#endif
+        lm_set(s, l, (d >= 64) ? ~0ull : ((1ull << d) - 1ull));
     }
-    for (int v = tid; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
+    vn_reset<NT>(s, n);
     for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
     if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
-    VnCache<VF, DM> vc;
+    VnCache<VF, DM, SWD_P16(NT)> vc;
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     // the check state and jptr written above are read below by OTHER threads (a check is served by the thread
     // whose ctid equals its lane number, which need not be the thread that initialised it)
     __syncthreads();
     bp_init<VF, DM>(s, vc);
-    CnCache<KG> cn;
+    CnCache<KG, SWD_P16(NT)> cn;
     if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)
         const uint32_t e = cn_map[s.ctid];
         cn_cache_load<NT, KG, true>(g, s, false, (e & 0xFFFFu) == 0xFFFFu ? -1 : (int)(e & 0xFFFFu), (int)((e >> 16) & 3u), (int)(e >> 18), cn);
@@ -1693,9 +1811,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         int cntl = 0;
         for (int j = 0; j < d; ++j) {
             const int v = rc[s.jptr[j] + l];
-            if (s.vn_val[v] < 0) { mk |= 1ull << j; ++cntl; }
+            if (!vn_decided(s, v)) { mk |= 1ull << j; ++cntl; }
         }
-        s.livemask[l] = mk;
+        lm_set(s, l, mk);
         s.cn_deg[l] = (uint8_t)cntl;
         if (cntl == 0) {
             if (s.cn_val[l] != 0) contra = true;
@@ -1731,7 +1849,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         return;
     }
     for (int v = tid; v < n; v += NT)
-        if (s.vn_val[v] == 0) s.hard[v] = 0;
+        if (vn_decided(s, v)) s.hard[v] = 0; // (every decided node so far was decided 0)
     __syncthreads();
     // ---- peel (osd_window.pyx:184-186).  Degree-1 checks force their last VN; the closure of these
     // forced values does not depend on the order they are applied in, and a contradiction shows up
@@ -1740,20 +1858,20 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // partial result the reference leaves behind depends on that order).
     {
         char *bak = s.scratch + L.off_bak;
-        for (int i = tid; i < n; i += NT) { bak[i] = (char)s.vn_val[i]; bak[n + i] = (char)s.hard[i]; }
+        vn_backup<NT>(s, n, bak);
         for (int i = tid; i < m; i += NT) {
             bak[2 * n + i] = (char)s.cn_val[i]; bak[2 * n + m + i] = (char)s.cn_deg[i];
-            ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i] = s.livemask[i];
+            ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i] = lm_get(s, i);
         }
         bool bad = false;
         for (;;) {
             bool fired = false;
             for (int l = tid; l < m; l += NT) {
                 if (s.cn_val[l] >= 0 && s.cn_deg[l] == 1) {
-                    const int j = __ffsll((long long)s.livemask[l]) - 1;
+                    const int j = __ffsll((long long)lm_get(s, l)) - 1;
                     const int v = rc[s.jptr[j] + l];
                     const int8_t val = s.cn_val[l];
-                    s.vn_val[v] = val; s.hard[v] = (uint8_t)val;
+                    vn_decide(s, v, val);
                     fired = true;
                 }
             }
@@ -1761,24 +1879,24 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
             for (int l = tid; l < m; l += NT) {
                 int cv = s.cn_val[l];
                 if (cv < 0) continue;
-                uint64_t mk = s.livemask[l], left = mk;
+                uint64_t mk = lm_get(s, l), left = mk;
                 int deg = s.cn_deg[l];
                 while (left) {
                     const int j = __ffsll((long long)left) - 1;
                     left &= left - 1;
-                    const int vv = s.vn_val[rc[s.jptr[j] + l]];
+                    const int vv = vn_value(s, rc[s.jptr[j] + l]);
                     if (vv >= 0) { mk &= ~(1ull << j); --deg; cv ^= vv; }
                 }
                 if (deg == 0) { if (cv != 0) bad = true; cv = -1; }
-                s.livemask[l] = mk; s.cn_deg[l] = (uint8_t)deg; s.cn_val[l] = (int8_t)cv;
+                lm_set(s, l, mk); s.cn_deg[l] = (uint8_t)deg; s.cn_val[l] = (int8_t)cv;
             }
             if (block_any<NT>(bad, s)) { bad = true; break; }
         }
         if (bad) {
-            for (int i = tid; i < n; i += NT) { s.vn_val[i] = (int8_t)bak[i]; s.hard[i] = (uint8_t)bak[n + i]; }
+            vn_restore<NT>(s, n, bak);
             for (int i = tid; i < m; i += NT) {
                 s.cn_val[i] = (int8_t)bak[2 * n + i]; s.cn_deg[i] = (uint8_t)bak[2 * n + m + i];
-                s.livemask[i] = ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i];
+                lm_set(s, i, ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i]);
             }
             __syncthreads();
             if (tid < 64) {
@@ -1809,18 +1927,18 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         const int ch = (n + NT - 1) / NT;
         const int v0 = tid * ch, v1 = min(n, v0 + ch);
         int cnt = 0;
-        for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] < 0) ? 1 : 0;
+        for (int v = v0; v < v1; ++v) cnt += vn_decided(s, v) ? 0 : 1;
         int pos = block_exscan<NT>(cnt, s, nlive);
         for (int v = v0; v < v1; ++v)
-            if (s.vn_val[v] < 0) s.lv[pos++] = (uint16_t)v;
+            if (!vn_decided(s, v)) s.lv[pos++] = (uint16_t)v;
         int lc = 0, le = 0;
         for (int l = tid; l < m; l += NT)
             if (s.cn_val[l] >= 0) {
                 ++lc;
-                le += __popcll(s.livemask[l]);
+                le += __popcll(lm_get(s, l));
                 atomicAdd(&dhist[min((int)s.cn_deg[l], 64)], 1);
                 // compact list of the live edge slots of this check (post-phase CN pass)
-                uint64_t mk = uselist ? s.livemask[l] : 0ull;
+                uint64_t mk = uselist ? lm_get(s, l) : 0ull;
                 int k = 0;
                 while (mk) {
                     const int j = __ffsll((long long)mk) - 1;
@@ -1882,13 +2000,13 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         const int ch = (n + NT - 1) / NT;
         const int v0 = tid * ch, v1 = min(n, v0 + ch);
         int cnt = 0; // rest count | zero count << 16
-        for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] == 0) ? 0x10000 : 1;
+        for (int v = v0; v < v1; ++v) cnt += (vn_value(s, v) == 0) ? 0x10000 : 1;
         int tot;
         const int pos = block_exscan<NT>(cnt, s, tot);
         int ps = pos & 0xFFFF, pz = pos >> 16, nlt = 0;
         bool eq = false;
         for (int v = v0; v < v1; ++v) {
-            const int vv = s.vn_val[v];
+            const int vv = vn_value(s, v);
             if (vv == 0) { zlist[pz++] = (uint16_t)v; continue; }
             const uint64_t k = f2key(vv == 1 ? -1000.0 : (HACC ? hsl[v] : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v]));
             key[ps] = k; idx[ps] = (uint16_t)v; ++ps;
@@ -1921,7 +2039,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         for (int v = tid; v < L.npad; v += NT) {
             if (v < n) {
                 double sum;
-                const int vv = s.vn_val[v];
+                const int vv = vn_value(s, v);
                 if (vv == 1) sum = -1000.0;
                 else if (vv == 0) sum = 1000.0;
                 else sum = HACC ? hsl[v] : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
@@ -1963,11 +2081,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 // (gfx950's sc1 accesses; the guide lists "sc1 payload -> asm vmcnt(0) -> sc1 flag" as a valid form).
 // A wait that exceeds its 10 s bound sets bit 0 of *status, records exit class SWD_EXIT_SCHED_FAULT for the unit
 // and commits nothing for it: the caller sees the fault (swd_pipeline_status) instead of a plausible wrong answer.
-#ifndef SWD_WAVES_PER_SIMD
-#define SWD_WAVES_PER_SIMD 2 // register budget of the variants below 1024 threads: 256 VGPRs (3: 168, experiments)
-#endif
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
-__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pipeline_kernel(const SwdPipeArgs a) {
+__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2))) pipeline_kernel(const SwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     // One workgroup decodes ONE window of one shot.  Units are handed out by an atomic ticket in
@@ -1983,6 +2098,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
     const uint32_t nunits = (uint32_t)a.B * (uint32_t)a.W;
     Lds s;
     swd_wave_roles<NT>(s, acc + 2);
+#ifdef SWD_RESIDENCY // diagnostics: how many workgroups of this launch are resident at the same time? (status words 4: now, 5: most, 6: with >= 1 unit)
+    if (tid == 0) { const uint32_t now = atomicAdd(&a.status[4], 1u) + 1u; atomicMax(&a.status[5], now); }
+    uint32_t res_units = 0;
+#endif
     bool queued = false; // parallel form of the guessing decoders: work items instead of window-major tickets
     if constexpr (KIND == 2) queued = a.gdgp.q != nullptr;
     uint32_t shots0 = 0; // parallel form: shots admitted at the start; a finished shot admits the next one
@@ -2044,11 +2163,23 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
     wi = (int)(ticket / (uint32_t)a.B); b = (int)(ticket % (uint32_t)a.B);
     }
     __syncthreads();
+    // LDS holds the residual syndrome of the window's own rows only (whole words: [dbase, dbase + dlen)); the rest of
+    // the shot's residual syndrome stays in the state record in HBM
     uint8_t *sdet = (uint8_t *)(smem + a.off_det);
     uint8_t *state_b = a.state + (int64_t)b * a.state_stride;
+    const int dbase = a.wins[wi].row0 & ~3, dlen = min((a.wins[wi].row0 + a.wins[wi].g.m + 3) & ~3, (a.num_det + 3) & ~3) - dbase;
     if (wi == 0) {
         const uint8_t *det_b = a.det + (int64_t)b * a.det_stride;
-        for (int r = tid; r < a.num_det; r += NT) sdet[r] = det_b[r] ? 1 : 0;
+        for (int r = tid; r < dlen; r += NT) sdet[r] = (dbase + r < a.num_det && det_b[dbase + r]) ? 1 : 0;
+        if (a.W > 1) { // the rows of the later windows go into the state record right away
+            uint32_t *st32 = (uint32_t *)state_b;
+            for (int q = tid; q < (a.num_det + 3) / 4; q += NT) {
+                if (4 * q >= dbase && 4 * q < dbase + dlen) continue;
+                uint32_t x = 0;
+                for (int k = 0; k < 4; ++k) x |= (4 * q + k < a.num_det && det_b[4 * q + k]) ? (1u << (8 * k)) : 0u;
+                __hip_atomic_store(&st32[4 + q], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (tid == 0) { acc[0] = 0; acc[1] = 0; }
     } else {
         // Hand-over without cache maintenance: the state words and the progress counter are written and read
@@ -2072,8 +2203,8 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
         __syncthreads();
         const uint32_t *st32 = (const uint32_t *)state_b;
         uint32_t *sdet32 = (uint32_t *)sdet;
-        for (int r = tid; r < (a.num_det + 3) / 4; r += NT)
-            sdet32[r] = __hip_atomic_load(&st32[4 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = tid; r < dlen / 4; r += NT)
+            sdet32[r] = __hip_atomic_load(&st32[4 + dbase / 4 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) { acc[0] = __hip_atomic_load(&st32[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[1] = 0; }
     }
     // Scratch that one window writes and reads back lives with the workgroup, not with the shot: consecutive
@@ -2100,7 +2231,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
             R = WinResult{};
             R.exit_class = SWD_EXIT_SCHED_FAULT;
         } else if constexpr (KIND == 0 || KIND == 3) // 3: osd_window with the posterior history accumulated in registers (bp_run, ACC)
-            decode_window<NT, VF, DM, KG, SF, KIND == 3>(g, L, a.P, s, sdet + w.row0, hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
+            decode_window<NT, VF, DM, KG, SF, KIND == 3>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
                                                          a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
         else {
             uint8_t *snap_b = a.snap + (int64_t)sidx * a.snap_stride;
@@ -2128,7 +2259,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
                 asm volatile("" ::: "memory"); dbg_tc = wall_clock64(); asm volatile("" ::: "memory");
 #endif
                 s.fpar = 0;
-                decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + w.row0, hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
+                decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
 #ifdef SWD_GDG_DEBUG
                 if (tid == 0 && queued) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(R.exit_class == -2 ? 9 : 10, 1); GDG_COUNT(R.exit_class == -2 ? 11 : 12, wall_clock64() - t_unit0); }
 #endif
@@ -2139,7 +2270,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
 #ifdef SWD_GDG_DEBUG // diagnostic build: checksums of the unit's input syndrome and of its result vector (statistics words 5, 6)
         if (tid == 0) {
             uint32_t hi = 2166136261u, ho = 2166136261u;
-            for (int r = 0; r < g.m; ++r) hi = (hi ^ sdet[w.row0 + r]) * 16777619u;
+            for (int r = 0; r < g.m; ++r) hi = (hi ^ sdet[w.row0 - dbase + r]) * 16777619u;
             for (int v = 0; v < g.n; ++v) ho = (ho ^ s.hard[v]) * 16777619u;
             R.live_cn = (int)hi; R.live_e = (int)ho;
         }
@@ -2155,8 +2286,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
                     const int c = w.col0 + i;
                     if (a.obs_mask) { const uint32_t om = a.obs_mask[c]; if (om) atomicXor(&acc[0], om); }
                     for (uint32_t e = a.chk_colptr[c]; e < a.chk_colptr[c + 1]; ++e) {
-                        const int r = a.chk_rows[e];
-                        atomicXor(&sdet_w[r >> 2], 1u << ((r & 3) * 8));
+                        const int r = a.chk_rows[e], rl = r - dbase;
+                        if (rl >= 0 && rl < dlen) atomicXor(&sdet_w[rl >> 2], 1u << ((r & 3) * 8));
+                        else __hip_atomic_fetch_xor(&((uint32_t *)state_b)[4 + (r >> 2)], 1u << ((r & 3) * 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // a row of another window (not in the reference's circuits)
                     }
                 }
             }
@@ -2215,8 +2347,8 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
             // hand the shot to its next window: state, then an agent-scope release of the window count
             uint32_t *st32 = (uint32_t *)state_b;
             const uint32_t *sdet32 = (const uint32_t *)sdet;
-            for (int r = tid; r < (a.num_det + 3) / 4; r += NT)
-                __hip_atomic_store(&st32[4 + r], sdet32[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = tid; r < dlen / 4; r += NT)
+                __hip_atomic_store(&st32[4 + dbase / 4 + r], sdet32[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid == 0) __hip_atomic_store(&st32[0], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state stores are acknowledged ...
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2247,11 +2379,22 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : SWD_WAVES_PER_SIMD)) pip
         // osd.py:184-187: flagged = residual syndrome of the whole run non-zero; observable flips
         // predicted by the committed faults (compared with the sampled ones by the caller)
         bool nz = false;
-        for (int r = tid; r < a.num_det; r += NT) nz |= (sdet[r] != 0);
+        for (int r = tid; r < dlen; r += NT) nz |= (sdet[r] != 0);
+        if (a.W > 1) { // the rows of the earlier windows: from the state record
+            const uint32_t *st32 = (const uint32_t *)state_b;
+            for (int q = tid; q < (a.num_det + 3) / 4; q += NT)
+                if (4 * q < dbase || 4 * q >= dbase + dlen) nz |= __hip_atomic_load(&st32[4 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        }
         const bool any = block_any<NT>(nz, s);
         if (tid == 0) { a.shot_result[2 * b] = (int32_t)acc[0]; a.shot_result[2 * b + 1] = any ? 1 : 0; }
     }
+#ifdef SWD_RESIDENCY
+    ++res_units;
+#endif
     } // next unit
+#ifdef SWD_RESIDENCY
+    if (tid == 0) { atomicSub(&a.status[4], 1u); if (res_units) atomicAdd(&a.status[6], 1u); atomicMax(&a.status[7], res_units); }
+#endif
 }
 
 } // namespace swd
