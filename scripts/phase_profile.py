@@ -10,7 +10,13 @@ from slidingwindowdecoder_amd import SlidingWindowDecoder
 from slidingwindowdecoder_amd.windows import sample_dem
 shots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 order = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-plan = bench.build_problem(N=288, W=4, F=1) if os.environ.get('SWD_CONFIG') == '288' else bench.build_problem()
+if os.environ.get('SWD_CONFIG') == 'shyps12':  # SHYPS r=3, twelve-round windows (252 x 2240)
+    from slidingwindowdecoder_amd import shyps
+    from slidingwindowdecoder_amd.windows import plan_windows
+    _dem = shyps.shyps_dem(3, 0.001, 14)
+    plan = plan_windows(_dem.chk, _dem.obs, _dem.priors, 21, 12, 1, method=1)
+else:
+    plan = bench.build_problem(N=288, W=4, F=1) if os.environ.get('SWD_CONFIG') == '288' else bench.build_problem()
 dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=order))
 det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=1)
 d = torch.from_numpy(det).cuda()

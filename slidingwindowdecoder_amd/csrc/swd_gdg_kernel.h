@@ -334,7 +334,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
                 for (int k = 0; k < deg; ++k) {
                     const uint32_t e = g.vn_edge[k * n + v];
                     const int l = swd_edge_lane(e);
-                    if (s.cn_val[l] >= 0 && ((const uint8_t *)s.par)[l] != 0) ++num_flip;
+                    if (s.cn_val[l] >= 0 && s.par[l] != 0u) ++num_flip;
                 }
                 bool smaller_A = true, all_neg = true, larger_C = true, larger_D = true;
                 double hsum = 0.0;

@@ -1,7 +1,6 @@
 // Instantiations of swd::pipeline_kernel for kind 0 (osd_window windows) and
 // their launchers (swd_plan.h); one translation unit per kind so that the kernels compile in parallel.
 #define SWD_OSDW_TUNED 1 // packed register caches, three waves per SIMD where they fit (swd_osdw_kernel.h)
-#define SWD_VNBITS 1     // the osd_window LDS layout
 #include "swd_plan.h"
 #include "swd_variants.h"
 

@@ -1,6 +1,5 @@
 // Instantiations of swd::pipeline_kernel for kind 1 (guessing decoders, serial tree walk) and
 // their launchers (swd_plan.h); one translation unit per kind so that the kernels compile in parallel.
-#undef SWD_VNBITS // the guessing decoders keep the byte form of the decided-node array
 #include "swd_plan.h"
 #include "swd_variants.h"
 

@@ -42,8 +42,12 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     scratch = std::max(scratch, L.off_hs + n * 8);
     scratch = align_up(scratch, 16);
     int o = scratch;
-    L.off_livemask = o; o += (kind == 0 && g.K <= 48) ? align_up(m * 6, 4) : m * 8; // osd_window layouts: 32 + 16 bits per check when the row weight allows
-    L.off_par = o; o += align_up(m + 1, 4); // one parity byte per check; byte m: sink for the dead positions' flips
+    // The tuned osd_window kernels (up to 256 threads, swd_osdw_kernel.h: SWD_P16 / DIET) keep a smaller state: 32 + 16 bits of
+    // live mask per check (row weight <= 48), one parity byte per check, no copy of the original check degrees, one
+    // "decided" bit per variable node.  Every other kernel: the classic arrays.
+    const bool diet = kind == 0 && nt <= 256;
+    L.off_livemask = o; o += (diet && g.K <= 48) ? align_up(m * 6, 4) : m * 8;
+    L.off_par = o; o += diet ? align_up(m + 1, 4) : (m + 1) * 4; // parities; index m: sink for the dead positions' flips
     L.off_lv = o; o = align_up(o + new_n * 2, 4);
     L.off_jptr = o; o = align_up(o + (g.K + 1) * 2, 4);
     // live-slot lists: osd_window stages them in the (then dead) scratch region; the guessing decoders
@@ -58,16 +62,8 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     }
     L.off_cnval = o; o += m;
     L.off_cndeg = o; o += m;
-#if 1 // the osd_window layout (kind 0) is the diet form: swd_osdw_kernel.h, SWD_VNBITS
-    L.off_cndeg0 = o; o += (kind == 0) ? 0 : m; // osd_window kernels read the original degrees from the graph
-#else
-    L.off_cndeg0 = o; o += m;
-#endif
-#if 1 // the osd_window layout (kind 0) is the diet form: swd_osdw_kernel.h, SWD_VNBITS // osd_window kernels keep one "decided" bit per variable node (swd_osdw_kernel.h, vn_decided), the guessing decoders a byte
-    L.off_vnval = o = align_up(o, 4); o += (kind == 0) ? ((n + 31) / 32) * 4 : n;
-#else
-    L.off_vnval = o; o += n;
-#endif
+    L.off_cndeg0 = o; o += diet ? 0 : m;
+    L.off_vnval = o = align_up(o, 4); o += diet ? ((n + 31) / 32) * 4 : n;
     L.off_hard = o; o = align_up(o + n + 1, 16); // +1: sink for threads without a VN
     L.off_misc = o; o += 640; // flags[32] scal[32] dbl[24] iaux[32]
     L.total = align_up(o, 16);

@@ -7,6 +7,7 @@
 // Numerics: fp64, no FMA contraction (build with -ffp-contract=off), every sum in the
 // reference's order, so hard decisions, iteration counts and min_pm are bit-identical.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -18,7 +19,7 @@
 // Translation units of the osd_window kernels (swd_kernels_k0 / k3) set SWD_OSDW_TUNED: their kernels of up to 256 threads
 // keep the BP register caches packed (VnCache / CnCache, P16) and -- variants with at most twelve groups of check
 // positions -- are built for three waves per SIMD (168 VGPRs); together with the LDS diet of the osd_window layout
-// (SWD_VNBITS: decided-node bits, 48-bit live masks, parity bytes, residual syndrome of the window's rows only) three
+// (decided-node bits, 48-bit live masks, parity bytes, residual syndrome of the window's rows only; DIET below) three
 // workgroups of the <256, 7, 6, 9> kernel fit a CU (53 600 B of LDS each; the hardware's limit is 53 760, not the
 // 54 592 the occupancy API accepts: scripts/residency_check.py).
 #ifndef SWD_OSDW_TUNED
@@ -262,19 +263,16 @@ __device__ __forceinline__ void wave_fence() {
 // unpacking inside the iteration loop -- hoisted out of it, the 32-bit copies would take the registers back.  With the
 // packed caches the <256, 7, 6, 9> kernel needs no spill at 248 VGPRs and one reload per BP loop at the 168 of three
 // waves per SIMD.
-template <int VF, int DM, bool P16 = false>
+template <int VF, int DM>
 struct VnCache {
     double llr[VF];
     uint32_t ed[VF][DM];
-    __device__ __forceinline__ void set_ed(int i, int k, uint32_t v) { ed[i][k] = v; }
-    __device__ __forceinline__ void get_ed(int i, uint32_t (&ad)[DM]) const {
-#pragma unroll
-        for (int k = 0; k < DM; ++k) ad[k] = ed[i][k];
-    }
     uint32_t par[VF][(DM + 1) / 2];
 };
+
+// The same cache with two offsets per register (the tuned osd_window kernels, whose LDS offsets fit 16 bits).
 template <int VF, int DM>
-struct VnCache<VF, DM, true> {
+struct VnCacheP {
     static_assert(DM % 2 == 0, "edge offsets are packed in pairs");
     double llr[VF];
     uint32_t edp[VF][DM / 2];
@@ -294,8 +292,39 @@ __device__ __forceinline__ int swd_slot_far(const SwdGraphDev &g) { return g.E +
 template <int NT>
 __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E + 1 + NT / 64 + (int)(threadIdx.x >> 6); }
 
-template <int NT, int VF, int DM, bool FULL, class VC>
-__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VC &c) {
+template <int NT, int VF, int DM, bool FULL>
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCache<VF, DM> &c) {
+    const int n = g.n, cnt = FULL ? n : nlive;
+    const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        c.llr[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) c.ed[i][k] = dead;
+#pragma unroll
+        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
+        if (idx < cnt) {
+            const int v = FULL ? idx : (int)s.lv[idx];
+            const int deg = g.col_deg[v];
+            c.llr[i] = g.llr[v];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                if (k < deg) {
+                    const uint32_t e = g.vn_edge[k * n + v];
+                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
+                        c.ed[i][k] = swd_edge_slot(e) << 3;
+                        c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
+                                                   : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int VF, int DM, bool FULL>
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM> &c) {
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
 #pragma unroll
@@ -328,8 +357,17 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
 __device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
-template <int VF, int DM, class VC>
-__device__ __forceinline__ void bp_init(Lds &s, const VC &c) {
+template <int VF, int DM>
+__device__ __forceinline__ void bp_init(Lds &s, const VnCache<VF, DM> &c) {
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+#pragma unroll
+        for (int k = 0; k < DM; ++k) swd_msg_at(s, c.ed[i][k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
+    }
+}
+
+template <int VF, int DM>
+__device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM> &c) {
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         uint32_t ad[DM];
@@ -348,25 +386,23 @@ __device__ __forceinline__ int wave_max(int x) {
 // Per-thread register cache of the check a lane owns during one BP phase: the LDS slots of its
 // edges (u16, two per register) in walk order; unused / dead positions hold the wave's far slot.
 // KG = groups of four positions.
-template <int KG, bool P16 = false>
+template <int KG>
 struct CnCache {
     uint16_t sl[KG * 4];
-    __device__ __forceinline__ void set_slot(int k, int slot) { sl[k] = (uint16_t)slot; }
-    __device__ __forceinline__ void group(int gq, uint32_t (&ad)[4]) const { // byte offsets of positions 4 gq .. 4 gq + 3
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ad[u] = (uint32_t)sl[gq * 4 + u] << 3;
-    }
     int cnt;  // positions to walk (0 for lanes without a live check)
     int live; // live edges among them
     int l;    // the check (lane numbering of the graph) this thread serves, -1 for none
     int sub;  // which of the check's grp threads this is (it walks positions sub, sub + grp, ...)
     int grp;  // 1, 2 or 4 adjacent threads (lanes of one quad) share the check
+    __device__ __forceinline__ int slot(int k) const { return (int)sl[k]; }
 };
+
+// The same cache with byte offsets, two per register (tuned osd_window kernels).
 template <int KG>
-struct CnCache<KG, true> {
-    uint32_t slp[KG * 2]; // byte offsets, two per register
+struct CnCacheP {
+    uint32_t slp[KG * 2];
     __device__ __forceinline__ void set_slot(int k, int slot) { const uint32_t v = (uint32_t)slot << 3; slp[k >> 1] = (k & 1) ? ((slp[k >> 1] & 0xFFFFu) | (v << 16)) : ((slp[k >> 1] & 0xFFFF0000u) | v); }
-    __device__ __forceinline__ void group(int gq, uint32_t (&ad)[4]) const {
+    __device__ __forceinline__ void group(int gq, uint32_t (&ad)[4]) const { // byte offsets of positions 4 gq .. 4 gq + 3
         uint32_t w0 = slp[2 * gq], w1 = slp[2 * gq + 1];
         asm volatile("" : "+v"(w0), "+v"(w1));
         ad[0] = w0 & 0xFFFFu; ad[1] = w0 >> 16; ad[2] = w1 & 0xFFFFu; ad[3] = w1 >> 16;
@@ -374,22 +410,31 @@ struct CnCache<KG, true> {
     int cnt, live, l, sub, grp;
 };
 
-// Live-position masks of the checks: 64 bits per check, or -- osd_window layouts of graphs with row weight <= 48 (s.lm_m != 0) --
-// 32 + 16 bits in two arrays.
-__device__ __forceinline__ uint64_t lm_get(const Lds &s, int l) {
-    if (s.lm_m == 0) return s.livemask[l];
-    const uint32_t *lo = (const uint32_t *)s.livemask; const uint16_t *hi = (const uint16_t *)(lo + s.lm_m);
-    return (uint64_t)lo[l] | ((uint64_t)hi[l] << 32);
+// Live-position masks of the checks: 64 bits per check, or -- tuned osd_window kernels (D) on graphs with row weight <= 48
+// (s.lm_m != 0) -- 32 + 16 bits in two arrays.
+template <bool D = false> __device__ __forceinline__ uint64_t lm_get(const Lds &s, int l) {
+    if constexpr (D) {
+        if (s.lm_m) {
+            const uint32_t *lo = (const uint32_t *)s.livemask; const uint16_t *hi = (const uint16_t *)(lo + s.lm_m);
+            return (uint64_t)lo[l] | ((uint64_t)hi[l] << 32);
+        }
+    }
+    return s.livemask[l];
 }
-__device__ __forceinline__ void lm_set(Lds &s, int l, uint64_t v) {
-    if (s.lm_m == 0) { s.livemask[l] = v; return; }
-    uint32_t *lo = (uint32_t *)s.livemask; uint16_t *hi = (uint16_t *)(lo + s.lm_m);
-    lo[l] = (uint32_t)v; hi[l] = (uint16_t)(v >> 32);
+template <bool D = false> __device__ __forceinline__ void lm_set(Lds &s, int l, uint64_t v) {
+    if constexpr (D) {
+        if (s.lm_m) {
+            uint32_t *lo = (uint32_t *)s.livemask; uint16_t *hi = (uint16_t *)(lo + s.lm_m);
+            lo[l] = (uint32_t)v; hi[l] = (uint16_t)(v >> 32);
+            return;
+        }
+    }
+    s.livemask[l] = v;
 }
 
 // grp = 1, 2 or 4 threads share a check (adjacent lanes of a quad): thread `sub` walks positions sub, sub + grp, ...
-template <int NT, int KG, bool FULL, class CC>
-__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CC &cc) {
+template <int NT, int KG, bool FULL>
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCache<KG> &cc) {
     const int m = g.m, dummy = swd_slot_far(g);
     const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
     const int l = act ? lc : 0;
@@ -398,11 +443,34 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
     cc.grp = grp;
     // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
     const bool bylist = !FULL && uselist;
-#ifdef SWD_VNBITS // (the LDS diet of the osd_window kernels: no copy of the original degrees either)
-    const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)g.row_deg[l]) : 0;
-#else
     const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
-#endif
+    const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : s.livemask[l];
+    cc.cnt = (cnt > sub) ? (cnt - sub + grp - 1) / grp : 0;
+    cc.live = act ? (int)s.cn_deg[l] : 0;
+#pragma unroll
+    for (int kk = 0; kk < KG * 4; ++kk) {
+        const int k = kk * grp + sub;
+        int sv = dummy;
+        if (k < cnt && ((lmask >> (k & 63)) & 1ull))
+            sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
+        cc.sl[kk] = (uint16_t)sv;
+    }
+}
+
+// (the same for the tuned kernels: packed offsets, 48-bit live masks, original degrees from the graph)
+template <int NT, int KG, bool FULL>
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCacheP<KG> &cc) {
+    constexpr bool DIET = SWD_P16(NT);
+    const int m = g.m, dummy = swd_slot_far(g);
+    const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
+    const int l = act ? lc : 0;
+    cc.l = act ? lc : -1;
+    cc.sub = sub;
+    cc.grp = grp;
+    // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
+    const bool bylist = !FULL && uselist;
+    // (tuned kernels keep no copy of the original degrees in LDS)
+    const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (DIET ? (int)g.row_deg[l] : (int)s.cn_deg0[l])) : 0;
     const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : lm_get(s, l);
     cc.cnt = (cnt > sub) ? (cnt - sub + grp - 1) / grp : 0;
     cc.live = act ? (int)s.cn_deg[l] : 0;
@@ -503,9 +571,9 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // max_iter iterations, and with max_iter a multiple of four slot order is chronological order of the last four
 // iterations: the sum is accumulated in registers (hs[i] for the i-th variable node of the thread) in exactly
 // that order and the 4 x n ring in HBM is neither written nor read.
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, class VC, class CC>
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
-                      const VC &c, const CC &cn, double *hist_b, int &iters_done,
+                      const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
@@ -540,8 +608,208 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         BPT(tc0);
         {
             if (cv >= 0 && cn.sub == 0) {
-                if (it > 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
-                ((uint8_t *)s.par)[l] = (uint8_t)cv; // one parity byte per check, flipped by word atomics (bit 8 (l & 3) of word l >> 2)
+                if (it > 0 && s.par[l] != 0u) unsat = true;
+                s.par[l] = (uint32_t)cv;
+            }
+            // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
+            // group of four are independent.  The two-minimum update
+            //   min2 = min(min2, max(min1, a)); min1 = min(min1, a)
+            // equals the reference's left/right running minima; |clip(x, -50, 50)| = min(|x|, 50).
+            // (A hand-made software pipeline over the groups was faster with the default machine scheduler and
+            // is slower with iterative-ilp, which overlaps the reads of the next group by itself.)
+            double min1 = 1e308, min2 = 1e308;
+            int argslot = farslot;
+            uint32_t neg[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) neg[r] = 0;
+#pragma unroll
+            for (int gq = 0; gq < KG; ++gq) {
+                if (gq * 4 < wmax) { // wave-uniform
+                    double xs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xs[u] = s.msg[cn.slot(gq * 4 + u)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = gq * 4 + u;
+                        const double ax = vminabs64(xs[u], 50.0);
+                        argslot = (ax < min1) ? cn.slot(k) : argslot;
+                        min2 = vmin64(min2, vmax64(min1, ax));
+                        min1 = vmin64(min1, ax);
+                        neg_shift_in(neg[k >> 5], xs[u]);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) neg[(gq * 4 + u) >> 5] <<= 1; // keep position k at bit (31 - k % 32) ...
+                }
+            }
+            // ... after this alignment of a partly filled last register
+            if (K4 & 31) neg[NR - 1] <<= (32 - (K4 & 31));
+            int npar = (cn.sub == 0) ? cv : 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) npar += __popc(neg[r]);
+            if constexpr (!FULL || SF) {
+                // merge the partial results of the check's threads (butterfly inside the quad).  On a tie
+                // of the minima the second minimum equals the first, so which side's position is kept
+                // as "first minimum" does not change any value written below.
+                {
+                    const double o1 = quad_xor<1>(min1), o2 = quad_xor<1>(min2);
+                    const int oa = quad_xor<1>(argslot), op = quad_xor<1>(npar);
+                    if (cn.grp >= 2) {
+                        npar += op;
+                        argslot = (o1 < min1) ? oa : argslot;
+                        min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
+                        min1 = vmin64(min1, o1);
+                    }
+                }
+                {
+                    const double o1 = quad_xor<2>(min1), o2 = quad_xor<2>(min2);
+                    const int oa = quad_xor<2>(argslot), op = quad_xor<2>(npar);
+                    if (cn.grp == 4) {
+                        npar += op;
+                        argslot = (o1 < min1) ? oa : argslot;
+                        min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
+                        min1 = vmin64(min1, o1);
+                    }
+                }
+            }
+            const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
+            // the first position holding the minimum gets the second minimum (ties: both equal).
+            // Its own sign is re-read before the slots are overwritten.
+            const double xarg = s.msg[argslot];
+            if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
+            const double p1 = min1 * alpha, p2 = min2 * alpha;
+            const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
+#pragma unroll
+            for (int gq = 0; gq < KG; ++gq) {
+                if (gq * 4 < wmax) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = gq * 4 + u;
+                        const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
+                        const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
+                        s.msg[cn.slot(k)] = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
+                    }
+                }
+            }
+            {
+                const uint32_t sb = (((xarg <= 0) ? 0xFFFFFFFFu : 0u) ^ flip) & 0x80000000u;
+                const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
+                s.msg[argslot] = __longlong_as_double((long long)b2);
+                s.msg[farslot] = 64.0; // re-arm
+            }
+        }
+        BPT(tc1);
+        const bool any = block_any<NT>(unsat, s);
+        BPT(tc2);
+#ifdef SWD_BPPROF
+        acc_cn += tc1 - tc0; acc_any += tc2 - tc1;
+        if (it > 0 && !any && !FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
+#endif
+        if (it > 0 && !any) { iters_done = it; return 1; }
+
+        const int slot_h = it & 3;
+        const bool record = record_all || it >= max_iter - 4;
+        // VN pass (osd_window.pyx:442-471).  (Reading the next VN's messages before this one's are written
+        // was tried and is slower.)
+#pragma unroll
+        for (int i = 0; i < VF; ++i) {
+            if (i < nch) { // wave-uniform
+                const int idx = s.vtid + i * NT;
+                const bool valid = idx < vcnt;
+                const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
+                double cc[DM], pre[DM];
+#pragma unroll
+                for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, c.ed[i][k]);
+                double temp = c.llr[i];
+#pragma unroll
+                for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
+                if constexpr (ACC) {
+                    if (it >= max_iter - 4) hs[i] = (it == max_iter - 4) ? temp : hs[i] + temp; // wave-uniform conditions
+                } else {
+                    if (record && valid) hist_b[slot_h * n + v] = temp;
+                }
+                const bool hd = valid && (temp <= 0);
+                ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
+                double suf = 0.0;
+#pragma unroll
+                for (int k = DM - 1; k >= 0; --k) {
+                    swd_msg_at(s, c.ed[i][k]) = pre[k] + suf;
+                    suf = suf + cc[k];
+                }
+                s.msg[zeroslot] = 0.0; // re-arm
+                if (hd) {
+#pragma unroll
+                    for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
+                        uint32_t pw = c.par[i][k2];
+                        asm volatile("" : "+v"(pw));
+                        atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u);
+                        if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
+                    }
+                }
+            }
+        }
+        BPT(tc3);
+        __syncthreads();
+#ifdef SWD_BPPROF
+        acc_vn += tc3 - tc2; acc_bar += clock64() - tc3;
+#endif
+    }
+#ifdef SWD_BPPROF
+    if (!FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
+#endif
+    bool unsat = force_unsat;
+    for (int l = tid; l < m; l += NT)
+        if (s.cn_val[l] >= 0 && s.par[l] != 0u) unsat = true;
+    const bool any = block_any<NT>(unsat, s);
+    iters_done = max_iter;
+    return any ? 0 : 1;
+}
+
+// bp_run for the tuned osd_window kernels: packed register caches (offsets unpacked where they are used), one parity byte per check
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false>
+__device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
+                      const VnCacheP<VF, DM> &c, const CnCacheP<KG> &cn, double *hist_b, int &iters_done,
+                      double alpha, bool force_unsat = false, double *hs = nullptr) {
+    const int tid = threadIdx.x, m = g.m, n = g.n;
+    const int vcnt = FULL ? n : nlive;
+    const bool record_all = P.record_all != 0;
+    const int l = cn.l >= 0 ? cn.l : 0;      // NT >= m: at most one check per thread
+    const int cv = (cn.l >= 0) ? (int)s.cn_val[l] : -1;
+    const int cnt = cn.cnt;
+    const int wmax = wave_max(cnt);
+    const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
+    constexpr int K4 = KG * 4;
+    constexpr int NR = (K4 + 31) / 32;       // sign shift registers
+    iters_done = 0;
+    if (max_iter <= 0) return 0;
+    // VNs this wave walks (wave-uniform): entries vtid + i*NT < vcnt for some lane
+    const int wbase = s.vtid & ~63;
+    const int nch = __builtin_amdgcn_readfirstlane((vcnt > wbase) ? min(VF, (vcnt - wbase + NT - 1) / NT) : 0);
+#ifdef SWD_BPPROF
+    if (!FULL && (tid & 63) == 0) ((uint8_t *)&s.scal[28])[tid >> 6] = (uint8_t)wmax;
+#endif
+    s.msg[farslot] = 64.0;
+    s.msg[zeroslot] = 0.0;
+    char *const parb = (char *)s.par;
+#ifdef SWD_BPPROF
+    long long tc0, tc1, tc2, tc3;
+    long long acc_cn = 0, acc_any = 0, acc_vn = 0, acc_bar = 0;
+#define BPT(x) x = clock64()
+#else
+#define BPT(x)
+#endif
+    for (int it = 0; it < max_iter; ++it) {
+        bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
+        BPT(tc0);
+        {
+            if (cv >= 0 && cn.sub == 0) {
+                if constexpr (true) { // tuned kernels: one parity byte per check, flipped by word atomics (bit 8 (l & 3) of word l >> 2)
+                    if (it > 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
+                    ((uint8_t *)s.par)[l] = (uint8_t)cv;
+                } else {
+                    if (it > 0 && s.par[l] != 0u) unsat = true;
+                    s.par[l] = (uint32_t)cv;
+                }
             }
             // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
             // group of four are independent.  The two-minimum update
@@ -680,8 +948,13 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
                         uint32_t pw = c.par[i][k2];
                         asm volatile("" : "+v"(pw));
-                        atomicXor((uint32_t *)(parb + (pw & 0xFFFCu)), 1u << ((pw & 3u) << 3));
-                        if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
+                        if constexpr (true) {
+                            atomicXor((uint32_t *)(parb + (pw & 0xFFFCu)), 1u << ((pw & 3u) << 3));
+                            if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
+                        } else {
+                            atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u);
+                            if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
+                        }
                     }
                 }
             }
@@ -697,7 +970,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #endif
     bool unsat = force_unsat;
     for (int l = tid; l < m; l += NT)
-        if (s.cn_val[l] >= 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
+        if (s.cn_val[l] >= 0 && (true ? ((const uint8_t *)s.par)[l] != 0 : s.par[l] != 0u)) unsat = true;
     const bool any = block_any<NT>(unsat, s);
     iters_done = max_iter;
     return any ? 0 : 1;
@@ -724,42 +997,51 @@ __device__ __forceinline__ void sort_pairs(uint64_t *key, uint16_t *idx, int npa
     }
 }
 
-// Decided variable nodes.  Byte form (guessing decoders): vn_val[v] = -1 live / decided value.  Bit form (SWD_VNBITS, the
-// osd_window kernels: 1.7 KB of LDS less per [[144]] window, which is what lets a third workgroup onto the CU): one
-// "decided" bit per node in the same array, the decided value is what hard[v] holds -- nothing writes hard[v] of a
-// decided node afterwards (the post phase only stores decisions of live nodes).
-#ifdef SWD_VNBITS
-__device__ __forceinline__ bool vn_decided(const Lds &s, int v) { return (((const uint32_t *)s.vn_val)[v >> 5] >> (v & 31)) & 1u; }
-__device__ __forceinline__ int vn_value(const Lds &s, int v) { return vn_decided(s, v) ? (int)s.hard[v] : -1; }
-__device__ __forceinline__ void vn_mark0(Lds &s, int v) { atomicOr(&((uint32_t *)s.vn_val)[v >> 5], 1u << (v & 31)); } // decided 0; hard[v] follows before anybody asks for the value
-__device__ __forceinline__ void vn_decide(Lds &s, int v, int val) { atomicOr(&((uint32_t *)s.vn_val)[v >> 5], 1u << (v & 31)); s.hard[v] = (uint8_t)val; }
-template <int NT> __device__ __forceinline__ void vn_reset(Lds &s, int n) {
-    for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)s.vn_val)[i] = 0u;
-    for (int v = threadIdx.x; v < n; v += NT) s.hard[v] = 0;
+// Decided variable nodes.  Byte form (D = false: every kernel but the tuned osd_window ones): vn_val[v] = -1 live / decided
+// value.  Bit form (D = true: 1.5 KB of LDS less per [[144]] window): one "decided" bit per node in the same array, the
+// decided value is what hard[v] holds -- nothing writes hard[v] of a decided node afterwards (the post phase only
+// stores decisions of live nodes).
+template <bool D = false> __device__ __forceinline__ bool vn_decided(const Lds &s, int v) {
+    if constexpr (D) return (((const uint32_t *)s.vn_val)[v >> 5] >> (v & 31)) & 1u;
+    else return s.vn_val[v] >= 0;
 }
-template <int NT> __device__ __forceinline__ void vn_backup(const Lds &s, int n, char *bak) { // bak: n bytes for the marks, n for hard
-    for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)bak)[i] = ((const uint32_t *)s.vn_val)[i];
-    for (int i = threadIdx.x; i < n; i += NT) bak[n + i] = (char)s.hard[i];
+template <bool D = false> __device__ __forceinline__ int vn_value(const Lds &s, int v) {
+    if constexpr (D) return vn_decided<true>(s, v) ? (int)s.hard[v] : -1;
+    else return s.vn_val[v];
 }
-template <int NT> __device__ __forceinline__ void vn_restore(Lds &s, int n, const char *bak) {
-    for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)s.vn_val)[i] = ((const uint32_t *)bak)[i];
-    for (int i = threadIdx.x; i < n; i += NT) s.hard[i] = (uint8_t)bak[n + i];
+template <bool D = false> __device__ __forceinline__ void vn_mark0(Lds &s, int v) { // decided 0; (bit form) hard[v] follows before anybody asks for the value
+    if constexpr (D) atomicOr(&((uint32_t *)s.vn_val)[v >> 5], 1u << (v & 31));
+    else s.vn_val[v] = 0;
 }
-#else
-__device__ __forceinline__ bool vn_decided(const Lds &s, int v) { return s.vn_val[v] >= 0; }
-__device__ __forceinline__ int vn_value(const Lds &s, int v) { return s.vn_val[v]; }
-__device__ __forceinline__ void vn_mark0(Lds &s, int v) { s.vn_val[v] = 0; }
-__device__ __forceinline__ void vn_decide(Lds &s, int v, int val) { s.vn_val[v] = (int8_t)val; s.hard[v] = (uint8_t)val; }
-template <int NT> __device__ __forceinline__ void vn_reset(Lds &s, int n) {
-    for (int v = threadIdx.x; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
+template <bool D = false> __device__ __forceinline__ void vn_decide(Lds &s, int v, int val) {
+    if constexpr (D) atomicOr(&((uint32_t *)s.vn_val)[v >> 5], 1u << (v & 31));
+    else s.vn_val[v] = (int8_t)val;
+    s.hard[v] = (uint8_t)val;
 }
-template <int NT> __device__ __forceinline__ void vn_backup(const Lds &s, int n, char *bak) {
-    for (int i = threadIdx.x; i < n; i += NT) { bak[i] = (char)s.vn_val[i]; bak[n + i] = (char)s.hard[i]; }
+template <int NT, bool D = false> __device__ __forceinline__ void vn_reset(Lds &s, int n) {
+    if constexpr (D) {
+        for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)s.vn_val)[i] = 0u;
+        for (int v = threadIdx.x; v < n; v += NT) s.hard[v] = 0;
+    } else {
+        for (int v = threadIdx.x; v < n; v += NT) { s.vn_val[v] = -1; s.hard[v] = 0; }
+    }
 }
-template <int NT> __device__ __forceinline__ void vn_restore(Lds &s, int n, const char *bak) {
-    for (int i = threadIdx.x; i < n; i += NT) { s.vn_val[i] = (int8_t)bak[i]; s.hard[i] = (uint8_t)bak[n + i]; }
+template <int NT, bool D = false> __device__ __forceinline__ void vn_backup(const Lds &s, int n, char *bak) { // bak: n bytes for the marks, n for hard
+    if constexpr (D) {
+        for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)bak)[i] = ((const uint32_t *)s.vn_val)[i];
+        for (int i = threadIdx.x; i < n; i += NT) bak[n + i] = (char)s.hard[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += NT) { bak[i] = (char)s.vn_val[i]; bak[n + i] = (char)s.hard[i]; }
+    }
 }
-#endif
+template <int NT, bool D = false> __device__ __forceinline__ void vn_restore(Lds &s, int n, const char *bak) {
+    if constexpr (D) {
+        for (int i = threadIdx.x; i < (n + 31) / 32; i += NT) ((uint32_t *)s.vn_val)[i] = ((const uint32_t *)bak)[i];
+        for (int i = threadIdx.x; i < n; i += NT) s.hard[i] = (uint8_t)bak[n + i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += NT) { s.vn_val[i] = (int8_t)bak[i]; s.hard[i] = (uint8_t)bak[n + i]; }
+    }
+}
 
 // Marks everything but the `keep` smallest (key, index) pairs: vn_val[v] = 0 for the columns the
 // reference's stable argsort (index_sort, bpgd.cpp:384-389) puts at positions keep.. (osd_window.pyx:
@@ -769,6 +1051,7 @@ template <int NT> __device__ __forceinline__ void vn_restore(Lds &s, int n, cons
 // hist: 3 x 256 ints of scratch.  Ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int keep, int *hist, Lds &s) {
+    constexpr bool DIET = SWD_P16(NT);
     const int tid = threadIdx.x, lane = tid & 63;
     uint64_t prefix = 0, pmask = 0;
     int need = keep;
@@ -811,7 +1094,7 @@ __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int 
     const int v0 = tid * ch, v1 = min(n, v0 + ch);
     if (exact) {
         for (int v = tid; v < n; v += NT)
-            if ((key[v] & pmask) > prefix) vn_mark0(s, v);
+            if ((key[v] & pmask) > prefix) vn_mark0<DIET>(s, v);
         __syncthreads();
         return;
     }
@@ -821,8 +1104,8 @@ __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int 
     int rank = block_exscan<NT>(eq, s, tot);
     for (int v = v0; v < v1; ++v) {
         const uint64_t k = key[v];
-        if (k > prefix) vn_mark0(s, v);
-        else if (k == prefix) { if (rank >= need) vn_mark0(s, v); ++rank; }
+        if (k > prefix) vn_mark0<DIET>(s, v);
+        else if (k == prefix) { if (rank >= need) vn_mark0<DIET>(s, v); ++rank; }
     }
     __syncthreads();
 }
@@ -854,10 +1137,11 @@ __device__ __forceinline__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint1
 // vn_set_value (osd_window.pyx:340-368) executed by wave 0: lane k takes the k-th neighbour
 // check of vn (distinct checks, so the updates are independent).  Returns true on
 // contradiction.
+template <bool D = false>
 __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, int vn, int value) {
     const int lane = threadIdx.x & 63;
     const int deg = g.col_deg[vn];
-    if (lane == 0) vn_decide(s, vn, value);
+    if (lane == 0) vn_decide<D>(s, vn, value);
     bool bad = false;
     if (lane < deg) {
         const uint32_t e = g.vn_edge[lane * g.n + vn];
@@ -866,7 +1150,7 @@ __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, 
         if (cv >= 0) {
             const int d = (int)s.cn_deg[l] - 1;
             if (value) cv ^= 1;
-            lm_set(s, l, lm_get(s, l) & ~(1ull << j));
+            lm_set<D>(s, l, lm_get<D>(s, l) & ~(1ull << j));
             if (d == 0) {
                 if (cv != 0) bad = true;
                 cv = -1;
@@ -882,6 +1166,7 @@ __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, 
 // peel (osd_window.pyx:306-338) on wave 0, reproducing the reference's sweep order: the next
 // check handled is the lowest original index >= sweep pointer with live degree 1, wrapping to
 // a new sweep when the current one is exhausted.  Returns true on contradiction.
+template <bool D = false>
 __device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
     const int lane = threadIdx.x & 63;
     int ptr = 0;
@@ -902,11 +1187,11 @@ __device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
         if (best_all == 0x7fffffff) return false;
         const int c = (best_ge != 0x7fffffff) ? best_ge : best_all;
         const int l = g.iperm[c];
-        const uint64_t mk = lm_get(s, l);
+        const uint64_t mk = lm_get<D>(s, l);
         const int j = __ffsll((long long)mk) - 1;
         const int vn = g.row_col[s.jptr[j] + l];
         const int val = s.cn_val[l];
-        if (vn_set_value_wave(g, s, vn, val)) return true;
+        if (vn_set_value_wave<D>(g, s, vn, val)) return true;
         ptr = c + 1;
     }
 }
@@ -1702,7 +1987,6 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
     s.scratch = smem;
     s.msg = (double *)smem;
     s.livemask = (uint64_t *)(smem + L.off_livemask);
-    s.lm_m = (L.off_par - L.off_livemask < 8 * (L.off_cndeg - L.off_cnval)) ? (L.off_cndeg - L.off_cnval) : 0; // m if the masks are stored in the 48-bit form
     s.par = (uint32_t *)(smem + L.off_par);
     s.lv = (uint16_t *)(smem + L.off_lv);
     s.jptr = (uint16_t *)(smem + L.off_jptr);
@@ -1723,6 +2007,8 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 template <int NT, int VF, int DM, int KG, bool SF, bool HACC>
 __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                               const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map) {
+    constexpr bool DIET = SWD_P16(NT); // the tuned kernels' LDS forms (decided-node bits, 48-bit live masks, no copy of the check degrees)
+    if constexpr (DIET) s.lm_m = (L.off_par - L.off_livemask < 8 * g.m) ? g.m : 0; // m if the masks are stored in the 48-bit form
     const int tid = threadIdx.x;
     const int m = g.m, n = g.n;
 #pragma unroll
@@ -1734,22 +2020,20 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         const int d = g.row_deg[l];
         s.cn_val[l] = (int8_t)(synd[g.perm[l]] ? 1 : 0);
         s.cn_deg[l] = (uint8_t)d;
-#ifndef SWD_VNBITS
-        s.cn_deg0[l] = (uint8_t)d;
-#endif
-        lm_set(s, l, (d >= 64) ? ~0ull : ((1ull << d) - 1ull));
+        if constexpr (!DIET) s.cn_deg0[l] = (uint8_t)d;
+        lm_set<DIET>(s, l, (d >= 64) ? ~0ull : ((1ull << d) - 1ull));
     }
-    vn_reset<NT>(s, n);
+    vn_reset<NT, DIET>(s, n);
     for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
     if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
-    VnCache<VF, DM, SWD_P16(NT)> vc;
+    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, VnCache<VF, DM>> vc; // the tuned kernels use the packed caches and their overloads of the BP routines
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     // the check state and jptr written above are read below by OTHER threads (a check is served by the thread
     // whose ctid equals its lane number, which need not be the thread that initialised it)
     __syncthreads();
     bp_init<VF, DM>(s, vc);
-    CnCache<KG, SWD_P16(NT)> cn;
+    std::conditional_t<SWD_P16(NT), CnCacheP<KG>, CnCache<KG>> cn;
     if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)
         const uint32_t e = cn_map[s.ctid];
         cn_cache_load<NT, KG, true>(g, s, false, (e & 0xFFFFu) == 0xFFFFu ? -1 : (int)(e & 0xFFFFu), (int)((e >> 16) & 3u), (int)(e >> 18), cn);
@@ -1811,9 +2095,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         int cntl = 0;
         for (int j = 0; j < d; ++j) {
             const int v = rc[s.jptr[j] + l];
-            if (!vn_decided(s, v)) { mk |= 1ull << j; ++cntl; }
+            if (!vn_decided<DIET>(s, v)) { mk |= 1ull << j; ++cntl; }
         }
-        lm_set(s, l, mk);
+        lm_set<DIET>(s, l, mk);
         s.cn_deg[l] = (uint8_t)cntl;
         if (cntl == 0) {
             if (s.cn_val[l] != 0) contra = true;
@@ -1849,7 +2133,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         return;
     }
     for (int v = tid; v < n; v += NT)
-        if (vn_decided(s, v)) s.hard[v] = 0; // (every decided node so far was decided 0)
+        if (vn_decided<DIET>(s, v)) s.hard[v] = 0; // (every decided node so far was decided 0)
     __syncthreads();
     // ---- peel (osd_window.pyx:184-186).  Degree-1 checks force their last VN; the closure of these
     // forced values does not depend on the order they are applied in, and a contradiction shows up
@@ -1858,20 +2142,20 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // partial result the reference leaves behind depends on that order).
     {
         char *bak = s.scratch + L.off_bak;
-        vn_backup<NT>(s, n, bak);
+        vn_backup<NT, DIET>(s, n, bak);
         for (int i = tid; i < m; i += NT) {
             bak[2 * n + i] = (char)s.cn_val[i]; bak[2 * n + m + i] = (char)s.cn_deg[i];
-            ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i] = lm_get(s, i);
+            ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i] = lm_get<DIET>(s, i);
         }
         bool bad = false;
         for (;;) {
             bool fired = false;
             for (int l = tid; l < m; l += NT) {
                 if (s.cn_val[l] >= 0 && s.cn_deg[l] == 1) {
-                    const int j = __ffsll((long long)lm_get(s, l)) - 1;
+                    const int j = __ffsll((long long)lm_get<DIET>(s, l)) - 1;
                     const int v = rc[s.jptr[j] + l];
                     const int8_t val = s.cn_val[l];
-                    vn_decide(s, v, val);
+                    vn_decide<DIET>(s, v, val);
                     fired = true;
                 }
             }
@@ -1879,28 +2163,28 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
             for (int l = tid; l < m; l += NT) {
                 int cv = s.cn_val[l];
                 if (cv < 0) continue;
-                uint64_t mk = lm_get(s, l), left = mk;
+                uint64_t mk = lm_get<DIET>(s, l), left = mk;
                 int deg = s.cn_deg[l];
                 while (left) {
                     const int j = __ffsll((long long)left) - 1;
                     left &= left - 1;
-                    const int vv = vn_value(s, rc[s.jptr[j] + l]);
+                    const int vv = vn_value<DIET>(s, rc[s.jptr[j] + l]);
                     if (vv >= 0) { mk &= ~(1ull << j); --deg; cv ^= vv; }
                 }
                 if (deg == 0) { if (cv != 0) bad = true; cv = -1; }
-                lm_set(s, l, mk); s.cn_deg[l] = (uint8_t)deg; s.cn_val[l] = (int8_t)cv;
+                lm_set<DIET>(s, l, mk); s.cn_deg[l] = (uint8_t)deg; s.cn_val[l] = (int8_t)cv;
             }
             if (block_any<NT>(bad, s)) { bad = true; break; }
         }
         if (bad) {
-            vn_restore<NT>(s, n, bak);
+            vn_restore<NT, DIET>(s, n, bak);
             for (int i = tid; i < m; i += NT) {
                 s.cn_val[i] = (int8_t)bak[2 * n + i]; s.cn_deg[i] = (uint8_t)bak[2 * n + m + i];
-                lm_set(s, i, ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i]);
+                lm_set<DIET>(s, i, ((uint64_t *)(bak + ((2 * n + 2 * m + 7) & ~7)))[i]);
             }
             __syncthreads();
             if (tid < 64) {
-                const bool b2 = peel_wave(g, s);
+                const bool b2 = peel_wave<DIET>(g, s);
                 if (tid == 0) s.scal[1] = b2 ? 1 : 0;
             }
         } else if (tid == 0) s.scal[1] = 0;
@@ -1927,18 +2211,18 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         const int ch = (n + NT - 1) / NT;
         const int v0 = tid * ch, v1 = min(n, v0 + ch);
         int cnt = 0;
-        for (int v = v0; v < v1; ++v) cnt += vn_decided(s, v) ? 0 : 1;
+        for (int v = v0; v < v1; ++v) cnt += vn_decided<DIET>(s, v) ? 0 : 1;
         int pos = block_exscan<NT>(cnt, s, nlive);
         for (int v = v0; v < v1; ++v)
-            if (!vn_decided(s, v)) s.lv[pos++] = (uint16_t)v;
+            if (!vn_decided<DIET>(s, v)) s.lv[pos++] = (uint16_t)v;
         int lc = 0, le = 0;
         for (int l = tid; l < m; l += NT)
             if (s.cn_val[l] >= 0) {
                 ++lc;
-                le += __popcll(lm_get(s, l));
+                le += __popcll(lm_get<DIET>(s, l));
                 atomicAdd(&dhist[min((int)s.cn_deg[l], 64)], 1);
                 // compact list of the live edge slots of this check (post-phase CN pass)
-                uint64_t mk = uselist ? lm_get(s, l) : 0ull;
+                uint64_t mk = uselist ? lm_get<DIET>(s, l) : 0ull;
                 int k = 0;
                 while (mk) {
                     const int j = __ffsll((long long)mk) - 1;
@@ -2000,13 +2284,13 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         const int ch = (n + NT - 1) / NT;
         const int v0 = tid * ch, v1 = min(n, v0 + ch);
         int cnt = 0; // rest count | zero count << 16
-        for (int v = v0; v < v1; ++v) cnt += (vn_value(s, v) == 0) ? 0x10000 : 1;
+        for (int v = v0; v < v1; ++v) cnt += (vn_value<DIET>(s, v) == 0) ? 0x10000 : 1;
         int tot;
         const int pos = block_exscan<NT>(cnt, s, tot);
         int ps = pos & 0xFFFF, pz = pos >> 16, nlt = 0;
         bool eq = false;
         for (int v = v0; v < v1; ++v) {
-            const int vv = vn_value(s, v);
+            const int vv = vn_value<DIET>(s, v);
             if (vv == 0) { zlist[pz++] = (uint16_t)v; continue; }
             const uint64_t k = f2key(vv == 1 ? -1000.0 : (HACC ? hsl[v] : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v]));
             key[ps] = k; idx[ps] = (uint16_t)v; ++ps;
@@ -2039,7 +2323,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         for (int v = tid; v < L.npad; v += NT) {
             if (v < n) {
                 double sum;
-                const int vv = vn_value(s, v);
+                const int vv = vn_value<DIET>(s, v);
                 if (vv == 1) sum = -1000.0;
                 else if (vv == 0) sum = 1000.0;
                 else sum = HACC ? hsl[v] : ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
@@ -2167,11 +2451,17 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
     // the shot's residual syndrome stays in the state record in HBM
     uint8_t *sdet = (uint8_t *)(smem + a.off_det);
     uint8_t *state_b = a.state + (int64_t)b * a.state_stride;
-    const int dbase = a.wins[wi].row0 & ~3, dlen = min((a.wins[wi].row0 + a.wins[wi].g.m + 3) & ~3, (a.num_det + 3) & ~3) - dbase;
+    constexpr bool SLICE = SWD_P16(NT) && (KIND == 0 || KIND == 3); // (the other kernels keep the whole residual syndrome in LDS: dbase = 0)
+    const int dbase = SLICE ? (a.wins[wi].row0 & ~3) : 0;
+    const int dlen = (SLICE ? min((a.wins[wi].row0 + a.wins[wi].g.m + 3) & ~3, (a.num_det + 3) & ~3) : ((a.num_det + 3) & ~3)) - dbase;
     if (wi == 0) {
         const uint8_t *det_b = a.det + (int64_t)b * a.det_stride;
-        for (int r = tid; r < dlen; r += NT) sdet[r] = (dbase + r < a.num_det && det_b[dbase + r]) ? 1 : 0;
-        if (a.W > 1) { // the rows of the later windows go into the state record right away
+        if constexpr (SLICE) {
+            for (int r = tid; r < dlen; r += NT) sdet[r] = (dbase + r < a.num_det && det_b[dbase + r]) ? 1 : 0;
+        } else {
+            for (int r = tid; r < a.num_det; r += NT) sdet[r] = det_b[r] ? 1 : 0;
+        }
+        if (SLICE && a.W > 1) { // the rows of the later windows go into the state record right away
             uint32_t *st32 = (uint32_t *)state_b;
             for (int q = tid; q < (a.num_det + 3) / 4; q += NT) {
                 if (4 * q >= dbase && 4 * q < dbase + dlen) continue;
@@ -2203,8 +2493,13 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         __syncthreads();
         const uint32_t *st32 = (const uint32_t *)state_b;
         uint32_t *sdet32 = (uint32_t *)sdet;
-        for (int r = tid; r < dlen / 4; r += NT)
-            sdet32[r] = __hip_atomic_load(&st32[4 + dbase / 4 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SLICE) {
+            for (int r = tid; r < dlen / 4; r += NT)
+                sdet32[r] = __hip_atomic_load(&st32[4 + dbase / 4 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (int r = tid; r < (a.num_det + 3) / 4; r += NT)
+                sdet32[r] = __hip_atomic_load(&st32[4 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid == 0) { acc[0] = __hip_atomic_load(&st32[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[1] = 0; }
     }
     // Scratch that one window writes and reads back lives with the workgroup, not with the shot: consecutive
@@ -2286,7 +2581,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                     const int c = w.col0 + i;
                     if (a.obs_mask) { const uint32_t om = a.obs_mask[c]; if (om) atomicXor(&acc[0], om); }
                     for (uint32_t e = a.chk_colptr[c]; e < a.chk_colptr[c + 1]; ++e) {
-                        const int r = a.chk_rows[e], rl = r - dbase;
+                        const int r = a.chk_rows[e];
+                        if constexpr (!SLICE) { atomicXor(&sdet_w[r >> 2], 1u << ((r & 3) * 8)); continue; }
+                        const int rl = r - dbase;
                         if (rl >= 0 && rl < dlen) atomicXor(&sdet_w[rl >> 2], 1u << ((r & 3) * 8));
                         else __hip_atomic_fetch_xor(&((uint32_t *)state_b)[4 + (r >> 2)], 1u << ((r & 3) * 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // a row of another window (not in the reference's circuits)
                     }
@@ -2347,8 +2644,13 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
             // hand the shot to its next window: state, then an agent-scope release of the window count
             uint32_t *st32 = (uint32_t *)state_b;
             const uint32_t *sdet32 = (const uint32_t *)sdet;
-            for (int r = tid; r < dlen / 4; r += NT)
-                __hip_atomic_store(&st32[4 + dbase / 4 + r], sdet32[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (SLICE) {
+                for (int r = tid; r < dlen / 4; r += NT)
+                    __hip_atomic_store(&st32[4 + dbase / 4 + r], sdet32[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (int r = tid; r < (a.num_det + 3) / 4; r += NT)
+                    __hip_atomic_store(&st32[4 + r], sdet32[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (tid == 0) __hip_atomic_store(&st32[0], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the state stores are acknowledged ...
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2379,8 +2681,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         // osd.py:184-187: flagged = residual syndrome of the whole run non-zero; observable flips
         // predicted by the committed faults (compared with the sampled ones by the caller)
         bool nz = false;
-        for (int r = tid; r < dlen; r += NT) nz |= (sdet[r] != 0);
-        if (a.W > 1) { // the rows of the earlier windows: from the state record
+        if constexpr (SLICE) { for (int r = tid; r < dlen; r += NT) nz |= (sdet[r] != 0); }
+        else { for (int r = tid; r < a.num_det; r += NT) nz |= (sdet[r] != 0); }
+        if (SLICE && a.W > 1) { // the rows of the earlier windows: from the state record
             const uint32_t *st32 = (const uint32_t *)state_b;
             for (int q = tid; q < (a.num_det + 3) / 4; q += NT)
                 if (4 * q < dbase || 4 * q >= dbase + dlen) nz |= __hip_atomic_load(&st32[4 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;

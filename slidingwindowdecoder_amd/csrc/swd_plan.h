@@ -161,8 +161,11 @@ struct Plan {
         if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
         if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
         off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
-        int dmax = 0; // LDS keeps the residual syndrome of one window's rows (whole words), swd_osdw_kernel.h
-        for (auto &w : wins) dmax = std::max(dmax, std::min((w.row0 + w.g->m + 3) & ~3, (num_det + 3) & ~3) - (w.row0 & ~3));
+        int dmax = num_det; // tuned osd_window kernels (up to 256 threads): LDS keeps the residual syndrome of one window's rows (whole words), swd_osdw_kernel.h
+        if (kind == 0 && nt <= 256) {
+            dmax = 0;
+            for (auto &w : wins) dmax = std::max(dmax, std::min((w.row0 + w.g->m + 3) & ~3, (num_det + 3) & ~3) - (w.row0 & ~3));
+        }
         lds_total = off_det + align_up(dmax, 16);
         if (lds_total > 160 * 1024) {
             set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
