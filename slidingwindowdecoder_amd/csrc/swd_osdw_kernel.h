@@ -270,19 +270,22 @@ struct VnCache {
     uint32_t par[VF][(DM + 1) / 2];
 };
 
-// The same cache with two offsets per register (the tuned osd_window kernels, whose LDS offsets fit 16 bits).
-template <int VF, int DM>
+// The same cache with two offsets per register.  SH = 0: byte offsets (kernels of up to 256 threads, whose LDS offsets fit
+// 16 bits, PB: one parity byte per check); SH = 3: slot numbers, shifted where they are used (the 1024-thread osd_window
+// kernels: fewer registers in their 128-VGPR budget, classic parity words).
+template <int VF, int DM, int SH = 0, bool PB = true>
 struct VnCacheP {
     static_assert(DM % 2 == 0, "edge offsets are packed in pairs");
+    static constexpr bool par_bytes = PB;
     double llr[VF];
     uint32_t edp[VF][DM / 2];
-    __device__ __forceinline__ void set_ed(int i, int k, uint32_t v) { edp[i][k >> 1] = (k & 1) ? ((edp[i][k >> 1] & 0xFFFFu) | (v << 16)) : ((edp[i][k >> 1] & 0xFFFF0000u) | v); }
+    __device__ __forceinline__ void set_ed(int i, int k, uint32_t v) { v >>= SH; edp[i][k >> 1] = (k & 1) ? ((edp[i][k >> 1] & 0xFFFFu) | (v << 16)) : ((edp[i][k >> 1] & 0xFFFF0000u) | v); }
     __device__ __forceinline__ void get_ed(int i, uint32_t (&ad)[DM]) const {
 #pragma unroll
         for (int k = 0; k < DM; k += 2) {
             uint32_t w = edp[i][k >> 1];
             asm volatile("" : "+v"(w));
-            ad[k] = w & 0xFFFFu; ad[k + 1] = w >> 16;
+            ad[k] = (w & 0xFFFFu) << SH; ad[k + 1] = (w >> 16) << SH;
         }
     }
     uint32_t par[VF][(DM + 1) / 2];
@@ -323,8 +326,8 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
     }
 }
 
-template <int NT, int VF, int DM, bool FULL>
-__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM> &c) {
+template <int NT, int VF, int DM, bool FULL, int SH, bool PB>
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c) {
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
 #pragma unroll
@@ -366,8 +369,8 @@ __device__ __forceinline__ void bp_init(Lds &s, const VnCache<VF, DM> &c) {
     }
 }
 
-template <int VF, int DM>
-__device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM> &c) {
+template <int VF, int DM, int SH, bool PB>
+__device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM, SH, PB> &c) {
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         uint32_t ad[DM];
@@ -397,15 +400,15 @@ struct CnCache {
     __device__ __forceinline__ int slot(int k) const { return (int)sl[k]; }
 };
 
-// The same cache with byte offsets, two per register (tuned osd_window kernels).
-template <int KG>
+// The same cache with offsets packed two per register (SH as in VnCacheP).
+template <int KG, int SH = 0>
 struct CnCacheP {
     uint32_t slp[KG * 2];
-    __device__ __forceinline__ void set_slot(int k, int slot) { const uint32_t v = (uint32_t)slot << 3; slp[k >> 1] = (k & 1) ? ((slp[k >> 1] & 0xFFFFu) | (v << 16)) : ((slp[k >> 1] & 0xFFFF0000u) | v); }
+    __device__ __forceinline__ void set_slot(int k, int slot) { const uint32_t v = ((uint32_t)slot << 3) >> SH; slp[k >> 1] = (k & 1) ? ((slp[k >> 1] & 0xFFFFu) | (v << 16)) : ((slp[k >> 1] & 0xFFFF0000u) | v); }
     __device__ __forceinline__ void group(int gq, uint32_t (&ad)[4]) const { // byte offsets of positions 4 gq .. 4 gq + 3
         uint32_t w0 = slp[2 * gq], w1 = slp[2 * gq + 1];
         asm volatile("" : "+v"(w0), "+v"(w1));
-        ad[0] = w0 & 0xFFFFu; ad[1] = w0 >> 16; ad[2] = w1 & 0xFFFFu; ad[3] = w1 >> 16;
+        ad[0] = (w0 & 0xFFFFu) << SH; ad[1] = (w0 >> 16) << SH; ad[2] = (w1 & 0xFFFFu) << SH; ad[3] = (w1 >> 16) << SH;
     }
     int cnt, live, l, sub, grp;
 };
@@ -458,8 +461,8 @@ __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool
 }
 
 // (the same for the tuned kernels: packed offsets, 48-bit live masks, original degrees from the graph)
-template <int NT, int KG, bool FULL>
-__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCacheP<KG> &cc) {
+template <int NT, int KG, bool FULL, int SH>
+__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCacheP<KG, SH> &cc) {
     constexpr bool DIET = SWD_P16(NT);
     const int m = g.m, dummy = swd_slot_far(g);
     const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
@@ -766,9 +769,9 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 }
 
 // bp_run for the tuned osd_window kernels: packed register caches (offsets unpacked where they are used), one parity byte per check
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false>
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
-                      const VnCacheP<VF, DM> &c, const CnCacheP<KG> &cn, double *hist_b, int &iters_done,
+                      const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
@@ -803,7 +806,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         BPT(tc0);
         {
             if (cv >= 0 && cn.sub == 0) {
-                if constexpr (true) { // tuned kernels: one parity byte per check, flipped by word atomics (bit 8 (l & 3) of word l >> 2)
+                if constexpr (PB) { // tuned kernels: one parity byte per check, flipped by word atomics (bit 8 (l & 3) of word l >> 2)
                     if (it > 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
                     ((uint8_t *)s.par)[l] = (uint8_t)cv;
                 } else {
@@ -948,7 +951,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
                         uint32_t pw = c.par[i][k2];
                         asm volatile("" : "+v"(pw));
-                        if constexpr (true) {
+                        if constexpr (PB) {
                             atomicXor((uint32_t *)(parb + (pw & 0xFFFCu)), 1u << ((pw & 3u) << 3));
                             if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
                         } else {
@@ -970,7 +973,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #endif
     bool unsat = force_unsat;
     for (int l = tid; l < m; l += NT)
-        if (s.cn_val[l] >= 0 && (true ? ((const uint8_t *)s.par)[l] != 0 : s.par[l] != 0u)) unsat = true;
+        if (s.cn_val[l] >= 0 && (PB ? ((const uint8_t *)s.par)[l] != 0 : s.par[l] != 0u)) unsat = true;
     const bool any = block_any<NT>(unsat, s);
     iters_done = max_iter;
     return any ? 0 : 1;
@@ -2027,13 +2030,16 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
     if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
-    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, VnCache<VF, DM>> vc; // the tuned kernels use the packed caches and their overloads of the BP routines
+    // the tuned kernels use the packed caches and their overloads of the BP routines: byte offsets + parity bytes up to 256
+    // threads, slot numbers + parity words in the 1024-thread kernels
+    constexpr bool PK = SWD_OSDW_TUNED && NT >= 1024 && DM % 2 == 0;
+    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, std::conditional_t<PK, VnCacheP<VF, DM, 3, false>, VnCache<VF, DM>>> vc;
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     // the check state and jptr written above are read below by OTHER threads (a check is served by the thread
     // whose ctid equals its lane number, which need not be the thread that initialised it)
     __syncthreads();
     bp_init<VF, DM>(s, vc);
-    std::conditional_t<SWD_P16(NT), CnCacheP<KG>, CnCache<KG>> cn;
+    std::conditional_t<SWD_P16(NT), CnCacheP<KG>, std::conditional_t<PK, CnCacheP<KG, 3>, CnCache<KG>>> cn;
     if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)
         const uint32_t e = cn_map[s.ctid];
         cn_cache_load<NT, KG, true>(g, s, false, (e & 0xFFFFu) == 0xFFFFu ? -1 : (int)(e & 0xFFFFu), (int)((e >> 16) & 3u), (int)(e >> 18), cn);
