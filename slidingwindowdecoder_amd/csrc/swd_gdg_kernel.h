@@ -193,9 +193,16 @@ __device__ __forceinline__ void block_argmin(double &key, int &pos, Lds &s) {
 
 // Compact the still-active selected VNs (position order) into s.lv and (re)build the per-phase
 // register caches.  Messages are untouched (they persist across decimation steps, bpgd.cpp:97-197).
-template <int NT, int VF, int DM, int KG>
-__device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, VnCache<VF, DM> &vc,
-                                                CnCache<KG> &cn) {
+// BP register caches of the guessing decoders: packed (16-bit slot numbers, two per register) in the translation units that
+// set SWD_GDG_PACKED -- fewer live registers in kernels that spill 220 of them.
+#ifndef SWD_GDG_PACKED
+#define SWD_GDG_PACKED 0
+#endif
+template <int VF, int DM> using GdgVC = std::conditional_t<SWD_GDG_PACKED != 0, VnCacheP<VF, DM, 3, false>, VnCache<VF, DM>>;
+template <int KG> using GdgCC = std::conditional_t<SWD_GDG_PACKED != 0, CnCacheP<KG, 3>, CnCache<KG>>;
+
+template <int NT, int VF, int DM, int KG, class VC, class CC>
+__device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, VC &vc, CC &cn) {
     const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
     const int ch = (new_n + NT - 1) / NT;
     const int j0 = tid * ch, j1 = min(new_n, j0 + ch);
@@ -646,8 +653,8 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
         __syncthreads();
         start_failed = s.scal[1] != 0;
         if (!start_failed) {
-            VnCache<VF, DM> vc;
-            CnCache<KG> cn;
+            GdgVC<VF, DM> vc;
+            GdgCC<KG> cn;
             const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
             for (int j = 0; j < maxj; ++j) {
                 const int depth = alt + j;
@@ -757,8 +764,8 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
     __syncthreads();
-    VnCache<VF, DM> vc;
-    CnCache<KG> cn;
+    GdgVC<VF, DM> vc;
+    GdgCC<KG> cn;
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     bp_init<VF, DM>(s, vc);
     cn_cache_load<NT, KG, true>(g, s, false, s.ctid < g.m ? s.ctid : -1, 0, 1, cn);
