@@ -1372,6 +1372,17 @@ __device__ __forceinline__ uint32_t osd_vec_bit(const uint64_t (&v)[WMC], int rw
     return (h >> (rbit & 31)) & 1u;
 }
 
+template <int WMC>
+__device__ __forceinline__ void osd_vec_setbit(uint64_t (&v)[WMC], int rw, int rbit) { // rw, rbit wave-uniform
+    switch (rw) {
+#define SWD_CASE(x) case x: if constexpr (x < WMC) v[x < WMC ? x : 0] |= 1ull << rbit; break;
+        SWD_CASE(0) SWD_CASE(1) SWD_CASE(2) SWD_CASE(3) SWD_CASE(4) SWD_CASE(5) SWD_CASE(6) SWD_CASE(7) SWD_CASE(8)
+        SWD_CASE(9) SWD_CASE(10) SWD_CASE(11) SWD_CASE(12) SWD_CASE(13) SWD_CASE(14) SWD_CASE(15)
+#undef SWD_CASE
+    default: break;
+    }
+}
+
 template <int NT, int DM, int WMC>
 __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
                                          uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
@@ -1434,13 +1445,15 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
 #ifdef SWD_OSDPROF
             q_eval += clock64() - q0_; q0_ = clock64();
 #endif
+            uint64_t pb[WMC]; // the pivoted-row mask, every word in every lane (read back after each pivot, ahead of its use)
+#pragma unroll
+            for (int x = 0; x < WMC; ++x) pb[x] = Pl[x];
             while (npiv < rank) {
                 uint32_t nz = 0;
 #pragma unroll
                 for (int x = 0; x < WMC; ++x) {
-                    const uint64_t pb = Pl[x]; // broadcast read
-                    nz |= (uint32_t)red[x] & ~(uint32_t)pb;
-                    nz |= (uint32_t)(red[x] >> 32) & ~(uint32_t)(pb >> 32);
+                    nz |= (uint32_t)red[x] & ~(uint32_t)pb[x];
+                    nz |= (uint32_t)(red[x] >> 32) & ~(uint32_t)(pb[x] >> 32);
                 }
                 const unsigned long long bal = __ballot(alive && nz != 0u);
                 if (bal == 0ull) break; // every remaining column of the batch is dependent
@@ -1454,8 +1467,12 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
                     for (int x = 0; x < WMC; ++x) ent[x] = red[x];
                 }
                 asm volatile("" ::: "memory");
+                // one round trip: the vector a word per lane (pivot search) and every word in every lane (the update below)
                 const uint64_t wv = ent[ln < WMC ? ln : 0];
-                const uint64_t c = (ln < WMC) ? (wv & ~Pmine) : 0ull; // its ones in unpivoted rows, a word per lane
+                uint64_t S[WMC];
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) S[x] = ent[x];
+                const uint64_t c = (ln < WMC) ? (wv & ~Pmine) : 0ull; // its ones in unpivoted rows
                 const unsigned long long balc = __ballot(c != 0ull);
                 const int fx = __ffsll((long long)balc) - 1;
                 const int bit = __builtin_amdgcn_readlane(__ffsll((long long)c) - 1, fx);
@@ -1468,12 +1485,15 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
                 if (ln == 0) ent[WMC] = (uint64_t)(uint32_t)((fx * 64 + bit) | (cs << 16));
                 asm volatile("" ::: "memory"); // a wave's LDS operations execute in order: the count follows the entry
                 if (ln == 0) ctl[0] = nb + 1;
-                // the batch's later columns under the same row operation
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) pb[x] = Pl[x]; // for the next pivot
+                // the batch's later columns under the same row operation: y ^= S if y[r]; S here still has bit r, which y keeps
                 const uint32_t ybit = osd_vec_bit<WMC>(red, fx, bit);
                 if (ln <= cs) alive = false;
                 else if (alive && ybit) {
 #pragma unroll
-                    for (int x = 0; x < WMC; ++x) red[x] ^= ent[x];
+                    for (int x = 0; x < WMC; ++x) red[x] ^= S[x];
+                    osd_vec_setbit<WMC>(red, fx, bit);
                 }
                 ++npiv; ++nb;
             }
