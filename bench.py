@@ -18,10 +18,15 @@ total split contiguously); one RCCL all_gather of the per-shot decisions (observ
 slidingwindowdecoder_amd.distributed.gather_decisions) closes the job inside the timed region.
 
 Rank 0 prints ONE JSON line.  `roofline`: the kernel keeps its messages in LDS, so HBM is not what bounds it;
-`frac` is the largest of the measured utilisations (the CU's LDS instruction path, LDS array, VALU issue, HBM), each = busy time at the 2.4 GHz
-peak clock from the committed rocprofv3 counters (profiles/) / the kernel time measured live with HIP events --
-at most 1 by construction.  SURVEY 8(d)'s algorithmic-bytes figure is reported next to it as `achieved_algorithmic`
-(it exceeds the HBM peak: that is the traffic the LDS-resident design avoids, not a utilisation).
+`frac` is the largest of the CAPACITY-BOUNDED utilisations -- LDS array busy (SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x t)),
+VALU busy at four cycles per wave instruction (SQ_INSTS_VALU x 4 / (1024 SIMDs x 2.4 GHz x t)) and HBM
+((2 x FETCH_SIZE + WRITE_SIZE) / 8 TB/s) -- none of which can exceed 1; the counters come from the committed rocprofv3
+profile of this same command (profiles/<tag>_<workload>_*), the time from HIP events measured live, and the line says
+`profile_stale` when the live kernel time has moved away from the profiled one.  `lds_pipe` (wave time inside LDS
+instructions) is a diagnostic, not a capacity.  SURVEY 8(d)'s algorithmic-bytes figure is reported next to it as
+`achieved_algorithmic` (it exceeds the HBM peak: that is the traffic the LDS-resident design avoids, not a utilisation),
+and `lds_bytes_algorithmic` (32 E per executed BP iteration) against `lds_bytes_moved` (SQ_INSTS_LDS x 512) shows the
+padding of the LDS traffic.
 `cpu_baseline`: the CPU oracle (bit-exact port of the reference's Cython path) timed on this box's host cores.
 """
 import argparse
@@ -39,6 +44,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 DECODER_KW = dict(pre_max_iter=8, post_max_iter=200, ms_scaling_factor=1.0, new_n=None, osd_method="osd_cs")
+for _k in ("pre_max_iter", "post_max_iter"):  # diagnostics only (scripts/lds_conflict_attribution.sh): attribute counters to a phase by differences
+    if os.environ.get("SWD_BENCH_" + _k.upper()):
+        DECODER_KW[_k] = int(os.environ["SWD_BENCH_" + _k.upper()])
 GDG_KW = dict(decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
               max_tree_branch_step=10, max_side_branch_step=10)  # `Sliding Window GDG.ipynb` cell 3
 # --workload: the headline (BASELINE configs[1], what the driver measures) or one of the other circuit-level configurations
@@ -52,11 +60,15 @@ WORKLOADS = {
     "bb288": dict(problem=dict(N=288, W=4, F=1), metric="sliding windows decoded/s, [[288,12,18]] BB p=0.003",
                   desc="configs[3]: [[288,12,18]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(4,1), "
                        "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d)"),
+    # the quaternary decoder of configs[4], device-resident (the reference runs BP4 on code-capacity noise only: Misc.ipynb cell 2)
+    "bp4": dict(problem=None, metric="bp4_osd decodes/s, [[144,12,12]] BB depolarizing p=0.02", unit="decodes/s",
+                desc="bp4_osd(max_iter=100, alpha=0.625, osd_cs order 10) on [[144,12,12]] hx/hz, depolarizing code-capacity noise p=0.02 "
+                     "(Misc.ipynb cell 2 setting), syndromes resident in HBM"),
 }
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9   # same guide: max clock
 NUM_CU, SIMD_PER_CU = 256, 4
-PROFILE_TAG = "r02"
+PROFILE_TAGS = ("r03",)  # newest first; find_profile falls back to the round-2 headline files
 STUB = os.environ.get("SWD_BENCH_STUB") == "1"  # launcher test on CPU: gloo + a stand-in decoder, never a measurement
 
 
@@ -157,9 +169,10 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline",
                     help="headline = BASELINE configs[1] (default; the only one with roofline / cpu_baseline); gdg, bb288 = configs[2], [3]")
     ap.add_argument("--total-shots", type=int, default=4096 * 8, help="shots per step over all GPUs (strong scaling)")
-    ap.add_argument("--osd-order", type=int, default=0)
+    ap.add_argument("--osd-order", type=int, default=10, help="osd_cs order of the osd_window workloads (the notebooks' default is 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-order10", action="store_true", help="skip the extra osd_cs order-10 measurement (N = 1)")
+    ap.add_argument("--no-order0", "--no-order10", dest="no_side_order", action="store_true",
+                    help="skip the extra measurement at the other OSD order (N = 1): order 0 next to the default 10, or 10 next to 0")
     ap.add_argument("--distinct-batches", type=int, default=4, help="pre-sampled batches cycled over the steps")
     return ap.parse_args(argv)
 
@@ -229,6 +242,69 @@ class GpuEngine:
     def step(self, i):
         self.dec.decode_device(self.dets[i % self.nb], total=self.total, stats=self.stats, min_pm=None, shot_result=self.shot)
 
+    def set_timing(self, on):
+        self.dec.set_timing(on)  # HIP events around every kernel launch, on the launch stream
+
+    def get_timing(self):
+        return self.dec.get_timing()
+
+    def check_status(self):
+        self.dec.check_status()  # raises if any window of any launch gave up waiting for its predecessor
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+class Bp4Engine:
+    """bp4_osd on device-resident syndromes (one launch per step); decisions = exit word + iteration count per shot."""
+
+    def __init__(self, args, rank, local_rank, lo, hi):
+        import torch
+        from slidingwindowdecoder_amd import bp4_osd
+        from slidingwindowdecoder_amd.codes import bb_code
+        self.torch, self.W, self.kernel_ms, self.launches = torch, 1, 0.0, 0
+        self.dev = torch.device("cuda", local_rank)
+        code, _, _ = bb_code(144)
+        n, p = code.hx.shape[1], 0.02
+        pr = np.full(n, p / 3)
+        self.dec = bp4_osd(code.hx, code.hz, channel_probs_x=pr, channel_probs_y=pr, channel_probs_z=pr, max_iter=100,
+                           ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10, device=local_rank)
+        shots = hi - lo
+        self.nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
+        self.sx, self.sz = [], []
+        for i in range(self.nb):  # Pauli errors keyed by (batch, global first shot): a shot's data does not depend on the number of ranks
+            rng = np.random.default_rng([20240318, i, lo])
+            pauli = rng.choice(4, size=(shots, n), p=[1 - p, p / 3, p / 3, p / 3])  # 0 I, 1 X, 2 Y, 3 Z
+            ex, ez = ((pauli == 1) | (pauli == 2)).astype(np.uint8), ((pauli == 3) | (pauli == 2)).astype(np.uint8)
+            self.sx.append(torch.from_numpy(np.ascontiguousarray((ez @ code.hx.T % 2).astype(np.uint8))).to(self.dev))
+            self.sz.append(torch.from_numpy(np.ascontiguousarray((ex @ code.hz.T % 2).astype(np.uint8))).to(self.dev))
+        self.out = torch.empty((shots, 2, n), dtype=torch.uint8, device=self.dev)
+        self.stats = torch.empty((shots, 8), dtype=torch.int32, device=self.dev)
+        self.shot = self.stats[:, :2]
+        self.timing, self.events = False, []
+
+    def step(self, i):
+        if self.timing:  # HIP events on the launch stream (torch's current stream is the stream the kernel is launched on)
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.dec.decode_batch_device(self.sx[i % self.nb], self.sz[i % self.nb], out=self.out, stats=self.stats)
+        if self.timing:
+            e1.record()
+            self.events.append((e0, e1))
+
+    def set_timing(self, on):
+        self.timing = on
+
+    def get_timing(self):
+        self.torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        k = len(self.events)
+        self.events = []
+        return ms, k
+
+    def check_status(self):
+        pass
+
     def sync(self):
         self.torch.cuda.synchronize()
 
@@ -240,62 +316,100 @@ def load_profile(name):
         return None
 
 
-def roofline(alg_bytes, avg_kernel_s, shots, plan):
-    """Utilisation of the three resources the kernel could be bound by, from the committed per-launch counters
-    (separate rocprofv3 --pmc passes of this same command, profiles/) and the live kernel time."""
-    sq = load_profile(f"{PROFILE_TAG}_sq_counters.json") or load_profile("r01_sq_counters.json")
-    sq_src = f"profiles/{PROFILE_TAG}_sq_counters.json" if load_profile(f"{PROFILE_TAG}_sq_counters.json") else "profiles/r01_sq_counters.json"
-    hb = load_profile("hbm_traffic.json")
-    traffic = hb.get("hbm_bytes_per_launch") if hb else None
-    fr = {}
-    if sq:
+def find_profile(workload):
+    """The committed counter profile of this workload's kernel: (sq counters, summary, source names), newest tag first.
+    The round-2 files carry no workload in their names and belong to the headline kernel at OSD order 0."""
+    for tag in PROFILE_TAGS:
+        stem = f"{tag}_{workload}"
+        sq, sm = load_profile(f"{stem}_sq_counters.json"), load_profile(f"{stem}_summary.json")
+        if sq and sm:
+            return sq, sm, f"profiles/{stem}_sq_counters.json", f"profiles/{stem}_summary.json"
+    if workload == "headline":
+        sq, sm = load_profile("r02_sq_counters.json"), load_profile("r02_summary.json")
+        if sq and sm:
+            return sq, sm, "profiles/r02_sq_counters.json", "profiles/r02_summary.json"
+    return None, None, None, None
+
+
+def lds_algorithmic_bytes(plan, stats):
+    """LDS bytes the BP iterations have to move: every live edge's message is read and written once by each of the
+    two passes = 32 bytes per live edge and executed iteration (full graph in the pre phase, the shot's own live edges
+    in the post phase; both counts come from the kernel's statistics)."""
+    total = 0.0
+    for wi, w in enumerate(plan.windows):
+        st = stats[:, wi, :].astype(np.float64)
+        total += (32.0 * w.mat.nnz * st[:, 2] + 32.0 * st[:, 6] * st[:, 3]).sum()
+    return total
+
+
+def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducible):
+    """Utilisation of the resources the kernel could be bound by.  Counters: the committed per-launch means of separate
+    rocprofv3 --pmc passes of this same command (profiles/); time: the kernel time measured live with HIP events.
+    `frac` is the largest of the capacity-bounded ones (each <= 1 by construction):
+      lds   SQ_LDS_IDX_ACTIVE (cycles the LDS array of a CU is busy, summed over the CUs) / (256 CUs x 2.4 GHz x t)
+      valu  SQ_INSTS_VALU x 4 (a wave64 instruction occupies its SIMD's vector ALU for at least four cycles) /
+            (1024 SIMDs x 2.4 GHz x t)
+      hbm   (2 x FETCH_SIZE + WRITE_SIZE) / (8 TB/s x t)"""
+    sq, sm, sq_src, sm_src = find_profile(workload)
+    out = {"kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "bound": "lds", "frac": None, "achieved": None,
+           "peak": None, "unit": None, "traffic": None}
+    fr, diag = {}, {}
+    if sq and sm:
         c = sq["per_launch_mean"]
-        if "SQ_ACTIVE_INST_VALU" in c:  # quad-cycles of VALU issue summed over all waves -> busy seconds per SIMD at peak clock
-            busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
-            fr["valu_issue"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
-                                "counter": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz)", "source": sq_src}
-        if "SQ_ACTIVE_INST_LDS" in c:   # quad-cycles a wave spends issuing LDS instructions, summed over all waves: the LDS unit is one per CU
-            busy = c["SQ_ACTIVE_INST_LDS"] * 4.0 / NUM_CU / PEAK_CLOCK_HZ
-            fr["lds_pipe"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
-                              "counter": "SQ_ACTIVE_INST_LDS x 4 / (256 CUs x 2.4 GHz): time the waves of a CU spend issuing LDS instructions "
-                                         "(a ds_write_b64 occupies the CU's LDS path ~6 cycles, a ds_read_b64 ~2: scripts/ubench/issue_rates.hip)",
-                              "source": sq_src}
-        if "SQ_LDS_IDX_ACTIVE" in c:    # LDS-array cycles summed over the CUs
+        prof_ms = sm.get("avg_ms")
+        out["profile"] = {"counters": sq_src, "kernel_stats": sm_src, "profiled_kernel": sm.get("kernel"), "profiled_avg_kernel_ms": prof_ms,
+                          "git": sm.get("git")}
+        # the counters belong to the binary that was profiled: flag the line when the live kernel time has moved away from it
+        out["profile_stale"] = bool(prof_ms and abs(avg_kernel_s * 1e3 - prof_ms) > 0.05 * prof_ms)
+        if "SQ_LDS_IDX_ACTIVE" in c:
             busy = c["SQ_LDS_IDX_ACTIVE"] / NUM_CU / PEAK_CLOCK_HZ
             fr["lds"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
                          "bank_conflict_share": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"],
-                         "counter": "SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz)", "source": sq_src}
-    if traffic:
-        fr["hbm_measured"] = {"frac": traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "GBps": traffic / avg_kernel_s / 1e9,
-                              "counter": "(2 x FETCH_SIZE + WRITE_SIZE) per launch / 8 TB/s", "source": hb.get("source")}
-    irr = irreducible_hbm_bytes(plan, shots)
-    out = {"kernel": "swd::pipeline_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
-           "traffic": traffic, "irreducible_hbm_bytes": irr,
-           "traffic_over_irreducible": (traffic / irr) if traffic else None,
-           "algorithmic_bytes_per_launch": alg_bytes,
-           "achieved_algorithmic": alg_bytes / avg_kernel_s / 1e9, "achieved_algorithmic_unit": "GB/s",
-           "achieved_algorithmic_over_hbm_peak": alg_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
-           "fractions": fr,
-           "note": "messages never leave LDS, so SURVEY 8(d)'s algorithmic bytes (40E+17n+2m per executed BP iteration + "
-                   "sort + OSD row adds + I/O) exceed what HBM could carry; frac = the highest measured utilisation among "
-                   "the CU's LDS instruction path, the LDS array, VALU issue and HBM (counters from profiles/, time measured "
-                   "here with HIP events).  The launch scales 1.76x from one to two workgroups per CU and not at all from two "
-                   "to three (DESIGN.md section 4)"}
-    if sq and "SQ_ACTIVE_INST_ANY" in sq["per_launch_mean"] and sq["per_launch_mean"].get("SQ_WAVE_CYCLES"):
-        c = sq["per_launch_mean"]  # how the waves spend their cycles (not a capacity: two waves of a SIMD can issue different kinds together)
-        out["wave_cycles"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "parked_waitcnt_or_barrier": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
-                              "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]}
-    out = dict(out)
+                         "counter": "SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz)"}
+        if "SQ_INSTS_VALU" in c:
+            busy = c["SQ_INSTS_VALU"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
+            fr["valu"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
+                          "counter": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz)"}
+        traffic = sm.get("hbm_bytes_per_launch")
+        if traffic:
+            out["traffic"] = traffic
+            fr["hbm"] = {"frac": traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "GBps": traffic / avg_kernel_s / 1e9,
+                         "counter": "(2 x FETCH_SIZE + WRITE_SIZE) per launch / 8 TB/s"}
+        # diagnostics that are NOT capacities (sums of wave time: several waves of a CU can be inside an LDS instruction at once)
+        if "SQ_ACTIVE_INST_LDS" in c:
+            diag["lds_pipe"] = {"value": c["SQ_ACTIVE_INST_LDS"] * 4.0 / NUM_CU / PEAK_CLOCK_HZ / avg_kernel_s,
+                                "meaning": "wave time inside LDS instructions per CU and launch time (SQ_ACTIVE_INST_LDS x 4 / (256 CUs x 2.4 GHz x t)); unbounded"}
+        if c.get("SQ_WAVE_CYCLES"):
+            diag["wave_cycles"] = {"issuing": c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                                   "parked_waitcnt_or_barrier": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                                   "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]}
+        if "SQ_INSTS_LDS" in c:
+            out["lds_bytes_moved"] = c["SQ_INSTS_LDS"] * 512.0
+            out["lds_bytes_moved_note"] = "SQ_INSTS_LDS x 512 B (one 8-byte access per lane of a wave instruction)"
+    if lds_alg_bytes is not None:
+        out["lds_bytes_algorithmic"] = lds_alg_bytes
+        if out.get("lds_bytes_moved"):
+            out["lds_padding_factor"] = out["lds_bytes_moved"] / lds_alg_bytes
+    if irreducible is not None:
+        out["irreducible_hbm_bytes"] = irreducible
+        out["traffic_over_irreducible"] = (out["traffic"] / irreducible) if out["traffic"] else None
+    if alg_bytes is not None:
+        out.update({"algorithmic_bytes_per_launch": alg_bytes, "achieved_algorithmic": alg_bytes / avg_kernel_s / 1e9,
+                    "achieved_algorithmic_unit": "GB/s",
+                    "achieved_algorithmic_over_hbm_peak": alg_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS})
+    out["fractions"] = fr
+    out["diagnostics"] = diag
+    out["note"] = ("messages never leave LDS, so SURVEY 8(d)'s algorithmic bytes (40E+17n+2m per executed BP iteration + sort + OSD "
+                   "row adds + I/O) exceed what HBM could carry; frac = the highest capacity-bounded utilisation among the LDS array, "
+                   "the vector ALUs and HBM (counters from profiles/, time measured here with HIP events)")
     if fr:
         bound = max(fr, key=lambda k: fr[k]["frac"])
-        out.update({"bound": {"lds_pipe": "lds", "valu_issue": "valu", "lds": "lds", "hbm_measured": "hbm"}[bound], "frac": fr[bound]["frac"]})
-        if bound == "hbm_measured":
+        out.update({"bound": bound, "frac": fr[bound]["frac"]})
+        if bound == "hbm":
             out.update({"achieved": fr[bound]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"})
         else:
             out.update({"achieved": fr[bound]["busy_ms_at_peak_clock"], "peak": avg_kernel_s * 1e3,
                         "unit": "ms busy at 2.4 GHz per launch (of the launch's duration)"})
-    else:
-        out.update({"bound": "hbm", "frac": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s"})
     return out
 
 
@@ -307,7 +421,9 @@ def time_steps(engine, args, dist, world, total_shots):
     for i in range(args.warmup):
         engine.step(i)
     engine.sync()
-    if world > 1:
+    if hasattr(engine, "set_timing"):
+        engine.set_timing(True)  # kernel timing covers the timed steps only, not the warm-up launches
+    if dist.is_initialized():
         dist.barrier()
     engine.sync()
     t0 = time.perf_counter()
@@ -315,10 +431,10 @@ def time_steps(engine, args, dist, world, total_shots):
         engine.step(args.warmup + i)
     gathered = gather_decisions(engine.shot, total_shots)  # per-shot decisions of the last step, over RCCL
     engine.sync()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=engine.shot.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -334,9 +450,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the job has WORLD_SIZE={world}")
+    # a process group exists whenever the job was started by torch.distributed.run -- also with one rank, so that the RCCL
+    # initialisation, the barrier and the all_gather of the decisions are the code that runs at every N (SWD_BENCH_DIST=0/1 overrides)
+    use_dist = os.environ.get("SWD_BENCH_DIST", "1" if ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ) else "0") == "1" or world > 1
 
+    wl = WORKLOADS[args.workload]
+    headline = args.workload == "headline"
+    osdw = args.workload in ("headline", "bb288")
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and args.workload == "headline":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)
 
     import torch
@@ -348,8 +470,9 @@ def main():
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if STUB:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -358,20 +481,23 @@ def main():
 
     total_shots = args.shots * world if args.scaling == "weak" else args.total_shots
     lo, hi = shard_bounds(total_shots, rank, world)
-    wl = WORKLOADS[args.workload]
-    headline = args.workload == "headline"
-    plan = None if STUB else build_problem(**wl["problem"])
-    engine = StubEngine(args, rank, lo, hi) if STUB else GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload)
+    plan = None if (STUB or wl["problem"] is None) else build_problem(**wl["problem"])
+    if STUB:
+        engine = StubEngine(args, rank, lo, hi)
+    elif args.workload == "bp4":
+        engine = Bp4Engine(args, rank, local_rank, lo, hi)
+    else:
+        engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload)
     W = engine.W
-    if not STUB:
-        engine.dec.set_timing(True)  # HIP events around every kernel launch, on the launch stream
     elapsed, gathered = time_steps(engine, args, dist, world, total_shots)
     assert gathered.shape[0] == total_shots, (gathered.shape, total_shots)
+    backend = dist.get_backend() if dist.is_initialized() else None
+    dist_ranks = dist.get_world_size() if dist.is_initialized() else 0
 
     line = {
         "metric": wl["metric"],
         "value": total_shots * W * args.steps / elapsed,
-        "unit": "windows/s",
+        "unit": wl.get("unit", "windows/s"),
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -386,57 +512,73 @@ def main():
     if STUB:
         ok = np.array_equal(gathered.numpy(), StubEngine.expected(0, total_shots))
         line["config"] = {"workload": "launcher test", "world_size": world, "shots_total": total_shots,
-                          "shots_this_rank": hi - lo, "gather_ok": bool(ok)}
+                          "shots_this_rank": hi - lo, "gather_ok": bool(ok), "collective_backend": backend, "collective_ranks": dist_ranks}
         if rank == 0:
             print(json.dumps(line))
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         if not ok:
             raise SystemExit("gathered decisions differ from the expected ones")
         return
 
-    kern_ms, launches = engine.dec.get_timing()
-    engine.dec.set_timing(False)
-    engine.dec.check_status()  # raises if any window of any launch gave up waiting for its predecessor
+    kern_ms, launches = engine.get_timing()  # the timed steps only (timing is switched on after the warm-up)
+    engine.set_timing(False)
+    engine.check_status()
 
     # accounting (outside the timed region), on this rank's shard of the last step
     st = engine.stats.cpu().numpy()
-    last = (args.warmup + args.steps - 1) % engine.nb
-    sr = engine.shot.cpu().numpy()
-    logical = (sr[:, 0].astype(np.int64) != engine.obs_true[last]) | (sr[:, 1] != 0)
-    alg_bytes = algorithmic_bytes(plan, st, DECODER_KW["pre_max_iter"]) if headline else None
-    cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
     avg_kernel_s = kern_ms / max(launches, 1) / 1e3
+    cfg = {
+        "workload": (wl["desc"] % args.osd_order if "%d" in wl["desc"] else wl["desc"]) + ", "
+                    + ("".join(f"DIAGNOSTIC RUN {k}={DECODER_KW[k]}, " for k in ("pre_max_iter", "post_max_iter") if os.environ.get("SWD_BENCH_" + k.upper())))
+                    + (f"{args.shots} shots per GPU per step" if args.scaling == "weak" else f"{total_shots} shots per step split over the GPUs"),
+        "world_size": world, "shots_total": total_shots, "shots_rank0": hi - lo, "windows_per_shot": W,
+        "parallelism": f"shots sharded over {world} GPU(s), no data-path collective; one all_gather of 8 B per shot",
+        # what closed the timed region: the RCCL (backend nccl) all_gather over this many ranks, or nothing (plain one-process run)
+        "collective_backend": backend, "collective_ranks": dist_ranks,
+        "kernel_launches_timed": int(launches),
+    }
+    alg_bytes = lds_alg = irr = None
+    if args.workload == "bp4":
+        cls = np.bincount((st[:, 0] & 0xFF).ravel(), minlength=7)
+        cfg["exit_classes_bp_osd_rank0"] = [int(cls[0]), int(cls[2])]
+        cfg["converged_fraction_rank0"] = float(((st[:, 0] & 0x100) != 0).mean())
+        kernel = "swd::bp4_kernel"
+    else:
+        last = (args.warmup + args.steps - 1) % engine.nb
+        sr = engine.shot.cpu().numpy()
+        logical = (sr[:, 0].astype(np.int64) != engine.obs_true[last]) | (sr[:, 1] != 0)
+        cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
+        cfg.update({"exit_classes_pre_post_osd_rank0": [int(cls[0]), int(cls[1]), int(cls[2])], "sched_faults": int(cls[6]),
+                    "logical_errors_last_step_rank0": int(logical.sum())})
+        kernel = "swd::pipeline_kernel"
+        irr = irreducible_hbm_bytes(plan, hi - lo)
+        if osdw:
+            cfg["bp_iterations_pre_post_rank0"] = [int(st[..., 2].sum()), int(st[..., 3].sum())]
+            cfg["live_edge_iterations_pre_post_rank0"] = [int(sum(w.mat.nnz * st[:, i, 2].sum() for i, w in enumerate(plan.windows))),
+                                                          int((st[..., 6].astype(np.int64) * st[..., 3]).sum())]
+            alg_bytes = algorithmic_bytes(plan, st, DECODER_KW["pre_max_iter"])
+            lds_alg = lds_algorithmic_bytes(plan, st)
 
-    order10 = None
-    if rank == 0 and world == 1 and headline and not args.no_order10 and args.osd_order != 10:
-        # the notebooks' default OSD-CS order 10 on the same batches (a second, untimed-by-the-driver loop)
-        e10 = GpuEngine(args, rank, local_rank, lo, hi, plan, 10)
-        k10 = max(1, min(args.steps, 5))
-        e10.step(0); e10.sync()
+    if rank == 0 and world == 1 and headline and not args.no_side_order:
+        # the same batches at the other OSD order (a second, untimed-by-the-driver loop): order 0 next to the notebooks' default 10
+        side = 0 if args.osd_order != 0 else 10
+        e2 = GpuEngine(args, rank, local_rank, lo, hi, plan, side)
+        k2 = max(1, min(args.steps, 5))
+        e2.step(0); e2.sync()
         t0 = time.perf_counter()
-        for i in range(k10):
-            e10.step(i)
-        e10.sync()
-        order10 = total_shots * W * k10 / (time.perf_counter() - t0)
-        e10.dec.check_status()
+        for i in range(k2):
+            e2.step(i)
+        e2.sync()
+        cfg[f"osd_cs_order{side}_windows_per_s"] = total_shots * W * k2 / (time.perf_counter() - t0)
+        e2.check_status()
 
     if rank == 0:
-        line["config"] = {
-            "workload": (wl["desc"] % args.osd_order if "%d" in wl["desc"] else wl["desc"]) + ", "
-                        + (f"{args.shots} shots per GPU per step" if args.scaling == "weak" else f"{total_shots} shots per step split over the GPUs"),
-            "world_size": world, "shots_total": total_shots, "shots_rank0": hi - lo, "windows_per_shot": W,
-            "parallelism": f"shots sharded over {world} GPU(s), no data-path collective; one all_gather of 8 B per shot",
-            "exit_classes_pre_post_osd_rank0": [int(cls[0]), int(cls[1]), int(cls[2])],
-            "sched_faults": int(cls[6]),
-            "logical_errors_last_step_rank0": int(logical.sum()),
-            "osd_cs_order10_windows_per_s": order10,
-        }
-        # roofline and CPU baseline belong to the headline kernel and its committed counter profile
-        line["roofline"] = roofline(alg_bytes, avg_kernel_s, hi - lo, plan) if headline else None
-        line["cpu_baseline"] = cpu if headline else None
+        line["config"] = cfg
+        line["roofline"] = roofline(args.workload, kernel, alg_bytes, lds_alg, avg_kernel_s, irr)
+        line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

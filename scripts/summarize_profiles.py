@@ -1,54 +1,88 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output under gpurun_out/ into the tracked summaries in profiles/.
+"""Condense the rocprofv3 output of scripts/profile_all.sh <tag> <workload> (gpurun_out/<tag>_<workload>/) into the tracked
+summaries profiles/<tag>_<workload>_{kernel_stats.csv, summary.json, sq_counters.json}.
 
-    gpurun_out/prof_stats/*kernel_stats.csv         (rocprofv3 --kernel-trace --stats)
-    gpurun_out/prof_fetch|prof_write/*counter_collection.csv   (separate --pmc passes)
+    stats/   rocprofv3 --kernel-trace --stats            -> average / min / max duration of the workload's kernel
+    fetch/, write/   separate --pmc passes               -> HBM bytes per launch
+    sq1/, sq2/       two SQ --pmc passes                 -> instruction mix, LDS activity, bank conflicts, wave cycles
 
-HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and
-WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, so the read
-side is doubled (upper bound for our mostly narrow accesses)."""
+HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on
+gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, so the read side is doubled (upper bound for our mostly narrow
+accesses).  The summary records the git revision it was made at: bench.py flags a live kernel time that has moved away
+from the profiled one (`profile_stale`)."""
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+wl = sys.argv[2] if len(sys.argv) > 2 else "headline"
+KERNEL = {"bp4": "bp4_kernel"}.get(wl, "pipeline_kernel")
+src = os.path.join(ROOT, "gpurun_out", f"{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
+stem = os.path.join(dst, f"{tag}_{wl}")
 os.makedirs(dst, exist_ok=True)
 
-out = {}
-for f in glob.glob(os.path.join(src, "prof_stats", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+def git_rev():
+    try:
+        rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "slidingwindowdecoder_amd", "bench.py"], text=True).strip()
+        return rev + ("+uncommitted" if dirty else "")
+    except Exception:
+        return None
+
+
+out = {"git": git_rev(), "workload": wl}
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, stem + "_kernel_stats.csv")
     for row in csv.DictReader(open(f)):
-        if "pipeline_kernel" in row["Name"]:
+        if KERNEL in row["Name"]:
             out["kernel"] = row["Name"]
             out["calls"] = int(row["Calls"])
             out["avg_ms"] = float(row["AverageNs"]) / 1e6
             out["min_ms"] = float(row["MinNs"]) / 1e6
             out["max_ms"] = float(row["MaxNs"]) / 1e6
 
-for name, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     vals, meta = [], {}
     for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "pipeline_kernel" in row["Kernel_Name"] and row["Counter_Name"] == name:
+            if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == name:
                 vals.append(float(row["Counter_Value"]))
-                meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+                meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size") if k in row}
     if vals:
         out[name + "_KiB_per_launch"] = sum(vals) / len(vals)
         out["dispatch"] = meta
 if "FETCH_SIZE_KiB_per_launch" in out and "WRITE_SIZE_KiB_per_launch" in out:
     out["hbm_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_KiB_per_launch"] + out["WRITE_SIZE_KiB_per_launch"]) * 1024.0
     out["hbm_bytes_note"] = "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc passes, gfx950 read-side correction"
-json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-if "hbm_bytes_per_launch" in out:
-    json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json"},
-              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-bj = os.path.join(src, "bench.json")
-if os.path.exists(bj):
-    shutil.copy(bj, os.path.join(dst, f"{tag}_bench.json"))
-print(json.dumps(out, indent=1))
+for log in glob.glob(os.path.join(src, "stats.log")):
+    for ln in open(log):
+        if ln.startswith("{"):
+            out["bench_line_under_the_profiler"] = json.loads(ln)
+json.dump(out, open(stem + "_summary.json", "w"), indent=1)
+
+vals = {}
+for d in ("sq1", "sq2"):
+    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL in row["Kernel_Name"]:
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+c = {k: sum(v) / len(v) for k, v in vals.items()}
+sq = {"git": out["git"], "workload": wl, "per_launch_mean": c,
+      "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles summed over all waves; SQ_INSTS_* in wave instructions"}
+if "SQ_WAVE_CYCLES" in c:
+    w = c["SQ_WAVE_CYCLES"]
+    sq["fractions_of_wave_cycles"] = {k: c[k] / w for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                                                            "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS") if k in c}
+if "SQ_LDS_IDX_ACTIVE" in c and "SQ_LDS_BANK_CONFLICT" in c:
+    sq["lds_bank_conflict_share_of_lds_active"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+if c:
+    json.dump(sq, open(stem + "_sq_counters.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_the_profiler"}, indent=1))
+print(json.dumps(sq.get("fractions_of_wave_cycles", {}), indent=1))

@@ -53,6 +53,10 @@ __device__ __forceinline__ void ag_publish_barrier() {
 #define SWD_ITEM_FINAL 2u
 #define SWD_ITEM_NONE 0xFFFFFFFEu
 #define SWD_ITEM_EXIT 0xFFFFFFFFu
+// a UNIT item holds the window in 8 bits and the shot in 22: plans with more windows / launches with more shots take the serial
+// form (Plan::finalize, launch in swd_osdw.hip)
+#define SWD_GDG_ITEM_MAX_WINDOWS 256
+#define SWD_GDG_ITEM_MAX_SHOTS (1 << 22)
 __device__ __forceinline__ uint32_t item_unit(int b, int wi) { return (SWD_ITEM_UNIT << 30) | ((uint32_t)wi << 22) | (uint32_t)b; }
 __device__ __forceinline__ uint32_t item_side(int ctxid, int slot) { return (SWD_ITEM_SIDE << 30) | ((uint32_t)ctxid << 8) | (uint32_t)slot; }
 __device__ __forceinline__ uint32_t item_final(int ctxid) { return (SWD_ITEM_FINAL << 30) | (uint32_t)ctxid; }

@@ -168,7 +168,7 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // guessing decoders: the parallel form (side branches as work items) shortens the critical path of a batch that
     // cannot fill the device with whole shots; large batches keep the serial walk (no speculation, no queue traffic)
     static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 6144; // measured (parallel vs serial): 5120 shots 69 vs 77 ms, 6144 shots 76 vs 78 ms, 7168 shots 88 vs 79 ms
-    const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots;
+    const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots && a.B < SWD_GDG_ITEM_MAX_SHOTS;
     // osd_window: when the posterior history is only consumed as its slot-order sum (no history in or out, both
     // iteration caps multiples of four) the kernel that accumulates the sum in registers runs: no 4 x n ring in HBM
     const bool acc = d->kind == 0 && d->variant->launch_acc && !a.hist && !a.P.record_all && !a.P.hist_is_state && !a.P.zero_hist &&

@@ -2414,14 +2414,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
 #endif
     bool queued = false; // parallel form of the guessing decoders: work items instead of window-major tickets
     if constexpr (KIND == 2) queued = a.gdgp.q != nullptr;
-    uint32_t shots0 = 0; // parallel form: shots admitted at the start; a finished shot admits the next one
-    if constexpr (KIND == 2) {
-        if (queued) {
-            shots0 = (uint32_t)min(a.B, a.gdgp.shots_inflight);
-            if (tid == 0)
-                for (uint32_t b0 = blockIdx.x; b0 < shots0; b0 += gridDim.x) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit((int)b0, 0));
-        }
-    }
+    // parallel form: every shot is admitted through the counter a.sched[0] -- by a workgroup that finds nothing unclaimed in the
+    // ring, or by the one that finishes a shot -- so progress never depends on a workgroup that is not resident yet
+    constexpr uint32_t shots0 = 0;
     for (;;) {
     const long long t_unit0 = wall_clock64();
     int wi, b, final_ctx = -1;

@@ -49,8 +49,6 @@ struct Plan {
     swd_gdg_params gp{};
     int kind = 0;           // 0 osd_window, 1 bpgdg, 2 bpgd, 3 bp_history
     bool gdg_parallel = false; // bpgdg: side branches of the decimation tree run as work items on the persistent grid
-    DevBuf gfree_tmpl;         // a full free-context ring, copied into the launch slot's ring per launch
-    int gfree_n = 0;
     int new_n_max = 0;
     int max_guess = 0;
     int64_t snap_stride = 0;
@@ -72,6 +70,8 @@ struct Plan {
     // that re-uses a slot first makes its stream wait for the slot's previous launch (hipStreamWaitEvent).
     struct LaunchSlot {
         DevBuf sched, state, hist, snap, gq, gfq, gctx, gsnap;
+        DevBuf gfree_tmpl;     // a full free-context ring, copied into the slot's ring per launch (per slot: a launch on another
+        int gfree_n = 0;       // stream may still be copying from the template of ITS slot while this one is rebuilt)
         hipEvent_t done = nullptr;
     };
     static constexpr int kSlots = 4;
@@ -131,8 +131,9 @@ struct Plan {
             if (max_guess < 0) max_guess = 0;
             if (max_guess > 64) { set_error("max_guess=%d exceeds the device limit of 64 snapshots", max_guess); return -1; }
             // parallel form of the tree search (swd_gdg_kernel.h): needs its record formats to hold the parameters
+            // (and its work items to hold the unit: item_unit packs the window in 8 bits and the shot in 22, swd_gdg_kernel.h)
             gdg_parallel = kind == 1 && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
-                           !getenv("SWD_GDG_SERIAL");
+                           wins.size() <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_GDG_SERIAL");
             snap_stride = 0;
             for (auto &w : wins) {
                 const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
@@ -271,14 +272,14 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         if (sl.gq.reserve(qbytes) || sl.gfq.reserve(fbytes) || sl.gctx.reserve((size_t)nctx * a.gdgp.ctx_stride) ||
             sl.gsnap.reserve((size_t)nctx * a.gdgp.csnap_stride))
             return -1;
-        if (d->gfree_n != (int)nctx) { // template of the full free ring: ids 0..nctx-1 in order
+        if (sl.gfree_n != (int)nctx) { // template of the full free ring: ids 0..nctx-1 in order
             std::vector<uint64_t> tmpl(2 + nctx);
             const unsigned navail = getenv("SWD_GDG_NCTX") ? std::min<unsigned>(nctx, (unsigned)atoi(getenv("SWD_GDG_NCTX"))) : nctx; // diagnostics
             tmpl[0] = (uint64_t)navail << 32; tmpl[1] = 0; // head 0, tail = contexts available
             for (unsigned t = 0; t < nctx; ++t) tmpl[2 + t] = ((uint64_t)(t + 1) << 32) | t;
-            if (d->gfree_tmpl.reserve(fbytes)) return -1;
-            SWD_HIP(hipMemcpy(d->gfree_tmpl.p, tmpl.data(), fbytes, hipMemcpyHostToDevice));
-            d->gfree_n = (int)nctx;
+            if (sl.gfree_tmpl.reserve(fbytes)) return -1;
+            SWD_HIP(hipMemcpy(sl.gfree_tmpl.p, tmpl.data(), fbytes, hipMemcpyHostToDevice));
+            sl.gfree_n = (int)nctx;
         }
         a.gdgp.q = sl.gq.as<uint32_t>(); a.gdgp.qmask = cap - 1;
         a.gdgp.fq = sl.gfq.as<uint32_t>(); a.gdgp.fmask = nctx - 1;
@@ -288,14 +289,16 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         a.gdgp.nctx = (int)nctx; a.gdgp.chk_status = d->status.as<uint32_t>();
         a.gdgp.static_bound = getenv("SWD_GDG_STATIC_BOUND") ? 1 : 0;
         SWD_HIP(hipMemsetAsync(a.gdgp.q, 0, qbytes, st));
-        SWD_HIP(hipMemcpyAsync(a.gdgp.fq, d->gfree_tmpl.p, fbytes, hipMemcpyDeviceToDevice, st));
+        SWD_HIP(hipMemcpyAsync(a.gdgp.fq, sl.gfree_tmpl.p, fbytes, hipMemcpyDeviceToDevice, st));
     }
     // history ring and (guessing decoders) snapshot stack: per workgroup for sliding-window plans, per shot
     // otherwise; a caller-provided history buffer (single-window calls) is used as it is
     const size_t nscr = a.slot_scratch ? (size_t)grid : (size_t)a.B;
-    if (!a.hist) {
-        if (d->cur->hist.reserve(nscr * a.hist_stride * sizeof(double))) return -1;
-        a.hist = d->cur->hist.as<double>();
+    if constexpr (KIND != 3) { // (kind 3 accumulates the history sum in registers and never touches the ring)
+        if (!a.hist) {
+            if (d->cur->hist.reserve(nscr * a.hist_stride * sizeof(double))) return -1;
+            a.hist = d->cur->hist.as<double>();
+        }
     }
     if (d->kind != 0) {
         if (d->cur->snap.reserve(nscr * d->snap_stride + 8)) return -1;

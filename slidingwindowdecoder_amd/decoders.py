@@ -383,6 +383,24 @@ class bp4_osd:
         self.last_llr, self.last_osd0, self.last_bp_decoding = lpr, osd0, bpd
         return out
 
+    def decode_batch_device(self, synd_x, synd_z, out=None, stats=None, llr=None, stream=None):
+        """Device-resident batch: ``synd_x`` [B, mx], ``synd_z`` [B, mz] contiguous torch uint8 CUDA tensors ->
+        (out uint8 [B, 2, n], stats int32 [B, 8]); ``llr`` (float64 [B, 3, n], optional) receives the posterior LLRs.
+        Asynchronous on the current (or given) torch stream."""
+        import torch
+        B, dev = synd_x.shape[0], synd_x.device
+        for t, m in ((synd_x, self.mx), (synd_z, self.mz)):
+            if t.dtype != torch.uint8 or t.dim() != 2 or t.shape != (B, m) or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError(f"syndromes must be contiguous uint8 CUDA tensors [B, {self.mx}] and [B, {self.mz}]")
+        out = torch.empty((B, 2, self.n), dtype=torch.uint8, device=dev) if out is None else out
+        stats = torch.empty((B, _lib.STAT_WORDS), dtype=torch.int32, device=dev) if stats is None else stats
+        st = torch.cuda.current_stream(dev) if stream is None else stream
+        rc = _lib.lib().swd_bp4_decode_batch_dev(self._h, B, synd_x.data_ptr(), synd_z.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                                 llr.data_ptr() if llr is not None else None, None, None, st.cuda_stream)
+        if rc:
+            raise RuntimeError(f"swd_bp4_decode_batch_dev failed: {_lib.last_error()}")
+        return out, stats
+
     def decode(self, input_vector_x, input_vector_z):
         sx, sz = np.asarray(input_vector_x), np.asarray(input_vector_z)
         if sx.shape[0] != self.mx or sz.shape[0] != self.mz:

@@ -30,8 +30,8 @@ def gather_decisions(local, num_shots: int):
     rank.  Shards may differ by one row; they are padded to a common length for the collective."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
+    if not (dist.is_available() and dist.is_initialized()):
+        return local  # (a one-rank process group still runs the collective: the same code path at every N)
     world = dist.get_world_size()
     sizes = [shard_bounds(num_shots, r, world) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)

@@ -198,3 +198,57 @@ def test_hypothesis_ensemble_mode():
             assert (conv | ~c1).all()
             both = conv & c1
             assert (ens.last_min_pm[both] <= single.last_min_pm[both]).all()
+
+
+def test_pipeline_with_more_than_256_windows_takes_the_serial_form():
+    """The parallel tree search packs the window number of a work item into 8 bits (swd_gdg_kernel.h, item_unit): a plan with more
+    windows must run the serial walk (Plan::finalize) -- a 300-round block-banded detector error model, (2,1) windows ->
+    299 windows, against the oracle driven through the host window loop."""
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    from slidingwindowdecoder_amd.windows import Window, WindowPlan, sliding_window_decode_host
+    rng = np.random.default_rng(77)
+    h, R, W = 6, 300, 2
+    rows, cols, starts, nloc = [], [], [], []
+    col = 0
+    for r in range(R):
+        starts.append(col)
+        loc = [[r * h + i] for i in range(h)] + [sorted(rng.choice(h, 2, replace=False) + r * h) for _ in range(4)]
+        span = [] if r == R - 1 else [[r * h + int(rng.integers(h)), (r + 1) * h + int(rng.integers(h))] for _ in range(5)]
+        nloc.append(len(loc))
+        for rr in loc + span:
+            rows += list(rr); cols += [col] * len(rr); col += 1
+    starts.append(col)
+    chk = sp.csr_matrix((np.ones(len(rows), np.uint8), (rows, cols)), shape=(R * h, col))
+    priors = rng.uniform(0.01, 0.05, size=col)
+    obs = sp.csr_matrix((rng.random((3, col)) < 0.1).astype(np.uint8))
+    wins = []
+    for top in range(R - W + 1):
+        last = top + W >= R
+        r0, r1, c0 = top * h, (top + W) * h, starts[top]
+        if not last:
+            c1 = starts[top + W - 1] + nloc[top + W - 1]
+            ident = sp.csr_matrix((np.ones(h, np.uint8), (np.arange(W * h - h, W * h), np.arange(h))), shape=(W * h, h))
+            mat = sp.hstack((chk[r0:r1, c0:c1], ident), format="csr")
+            prior = np.concatenate((priors[c0:c1], np.full(h, 0.03)))
+            ncg, commit = c1 - c0, starts[top + 1] - c0
+        else:
+            mat, prior = sp.csr_matrix(chk[r0:r1, c0:col]), priors[c0:col].copy()
+            ncg = commit = col - c0
+        mat.sort_indices()
+        wins.append(Window(r0, r1, c0, ncg, commit, mat, prior, last))
+    assert len(wins) == 299
+    plan = WindowPlan(chk, obs, priors, np.arange(col), [(r * h, starts[r]) for r in range(R)] + [(R * h, col)], wins, 0.03, h)
+    kw = dict(max_iter=6, ms_scaling_factor=1.0, max_iter_per_step=4, max_step=8, max_tree_depth=2, max_side_depth=5,
+              max_tree_branch_step=10, max_side_branch_step=6)
+    e = (rng.random((6, col)) < priors * 1.5).astype(np.uint8)
+    det = ((sp.csr_matrix(e) @ chk.T.astype(np.int32)).toarray() % 2).astype(np.uint8)
+    dev = SlidingWindowDecoder(plan, decoder="bpgdg_decoder", **kw)
+    total = dev.decode(det)
+
+    class Fresh:
+        def __init__(self, w): self.w = w
+        def decode(self, s): return O.bpgdg_decoder(self.w.mat, channel_probs=self.w.prior, **kw).decode(s)
+    want, _ = sliding_window_decode_host(plan, det, Fresh)
+    assert np.array_equal(total, want)

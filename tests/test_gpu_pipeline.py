@@ -115,3 +115,28 @@ def test_window_placement_is_validated():
     plan.windows[0] = type(w)(w.row0, w.row1, w.col0, w.ncols_global, w.mat.shape[1] + 1, w.mat, w.prior, w.is_last)
     with pytest.raises(ValueError, match="invalid window placement"):
         SlidingWindowDecoder(plan, **fx.params(f, "osd0_params"))
+
+
+@pytest.mark.parametrize("method,W,F,noisy", [(0, 3, 1, None), (2, 3, 1, None), (2, 4, 2, None), (1, 3, 1, 0.05), (2, 3, 2, 0.02)])
+def test_plan_windows_methods_vs_oracle_host_loop(method, W, F, noisy):
+    """Window extraction variants of osd.py:79-121: method 0 (plain sub-matrices), method 2 (identity block behind ALL faults
+    of the last round block) and a caller-given noisy-syndrome prior -- [[72,12,6]] circuit-level DEM, device pipeline against
+    the oracle driven through the host-side window loop."""
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    from slidingwindowdecoder_amd.circuit import bb_dem
+    from slidingwindowdecoder_amd.codes import bb_code
+    from slidingwindowdecoder_amd.windows import plan_windows, sample_dem, sliding_window_decode_host
+    code, A, B = bb_code(72)
+    dem = bb_dem(code, A, B, 0.004, 6)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 36, W, F, method=method, noisy_prior=noisy)
+    if noisy is not None:
+        assert plan.noisy_prior == noisy and all(np.all(w.prior[-36:] == noisy) for w in plan.windows[:-1])
+    det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, 96, seed=100 + method)
+    kw = dict(pre_max_iter=8, post_max_iter=40, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=4)
+    dec = SlidingWindowDecoder(plan, **kw)
+    total = dec.decode(det)
+    want, _ = sliding_window_decode_host(plan, det, lambda w: O.osd_window(w.mat, channel_probs=w.prior, **kw))
+    bad = np.flatnonzero((total != want).any(axis=1))
+    assert bad.size == 0, f"shots {bad.tolist()} differ"
+    assert len(np.unique(dec.last_stats[..., 0] & 0xFF)) >= 2

@@ -24,7 +24,7 @@ def test_shyps_windows_vs_oracle(order):
     cls = np.bincount((dec.last_stats[..., 0] & 0xFF).ravel(), minlength=6)
     assert cls[2] > 0 and cls[1] > 0  # OSD and post-BP exits both exercised
     flagged, logical = logical_error_stats(plan, det, obs, total)
-    assert logical.mean() < 0.5
+    assert not flagged.any()  # (p = 0.004 is a parity point far above the regime of the notebook: the rate itself is checked below at p = 0.001)
 
 
 def test_shyps_twelve_round_window_vs_oracle():
@@ -47,3 +47,51 @@ def test_shyps_twelve_round_window_vs_oracle():
     assert cls[2] > 0 and cls[1] > 0
     flagged, _ = logical_error_stats(plan, det, obs, total)
     assert not flagged.any()  # every shot's committed faults reproduce its detector data
+
+
+def _device_run(plan, shots, **kw):
+    import torch
+    from slidingwindowdecoder_amd import DemSampler, SlidingWindowDecoder
+    dec = SlidingWindowDecoder(plan, **kw)
+    det, flips = DemSampler(plan.chk, plan.obs, plan.priors).sample_device(shots, seed=20240318)
+    shot = torch.empty((shots, 2), dtype=torch.int32, device="cuda")
+    _, stats, _ = dec.decode_device(det, shot_result=shot)
+    dec.check_status()
+    sr = shot.cpu().numpy()
+    true = flips.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    return sr[:, 1] != 0, (sr[:, 0].astype(np.int64) & 0xFFFFFFFF) != true, stats.cpu().numpy()
+
+
+def test_shyps_p001_logical_error_rate_matches_the_notebook():
+    """/root/reference/SHYPS.ipynb cell 2 (outputs at :212-234): r = 3, p = 0.001, 4 rounds, (W,F) = (3,1), OSD order 0, 20 000 shots ->
+    0 flagged, 170 logical errors, 2.13e-3 per round (there with the third-party ldpc decoder inside the windows).  Same
+    experiment, same number of shots, osd_window in the windows: no flagged shot and a logical count within three standard
+    deviations of the difference of two such samples."""
+    from slidingwindowdecoder_amd import shyps
+    from slidingwindowdecoder_amd.windows import plan_windows
+    dem = shyps.shyps_dem(3, 0.001, 4)
+    assert dem.chk.shape == (105, 833)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 21, 3, 1, method=1)
+    shots, ref = 20000, 170
+    flagged, logical, _ = _device_run(plan, shots, pre_max_iter=8, post_max_iter=100, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=0)
+    nerr = int((logical | flagged).sum())
+    per_round = 1.0 - (1.0 - nerr / shots) ** (1.0 / 4)
+    print(f"SHYPS r=3 p=0.001 (3,1): {nerr}/{shots} logical errors, {per_round:.3e} per round (notebook: 170/20000, 2.13e-3)")
+    assert not flagged.any()
+    assert abs(nerr - ref) < 3.0 * (nerr + ref) ** 0.5, (nerr, ref)
+
+
+def test_shyps_twelve_round_windows_p001_rate():
+    """the twelve-round windows at the notebook's noise level: a wider window must not decode worse than the (3,1) run
+    (2.13e-3 per round, SHYPS.ipynb:234) -- 14 rounds, 8192 device-sampled shots"""
+    from slidingwindowdecoder_amd import shyps
+    from slidingwindowdecoder_amd.windows import plan_windows
+    dem = shyps.shyps_dem(3, 0.001, 14)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 21, 12, 1, method=1)
+    shots = 8192
+    flagged, logical, _ = _device_run(plan, shots, pre_max_iter=8, post_max_iter=100, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=10)
+    nerr = int((logical | flagged).sum())
+    per_round = 1.0 - (1.0 - nerr / shots) ** (1.0 / 14)
+    print(f"SHYPS r=3 p=0.001 (12,1), 14 rounds: {nerr}/{shots} logical errors, {per_round:.3e} per round")
+    assert not flagged.any()
+    assert per_round < 2.6e-3  # 2.13e-3 + three standard deviations of this sample size
