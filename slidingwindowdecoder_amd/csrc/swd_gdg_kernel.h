@@ -632,7 +632,7 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
     const bool pruned = alt > (int)*bcast; // the serial order has already passed this snapshot by
     if (!pruned) {
         Lds s;
-        lds_bind(s, smem, L);
+        lds_bind(s, smem, L, smem);
         s.fpar = 0; s.ctid = ctid; s.vtid = vtid;
         GdgLds G;
         gdg_bind(G, s.scratch, L, n, new_n);

@@ -9,7 +9,7 @@
 
 namespace swd {
 
-int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
+int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bool big) {
     const int m = g.m, n = g.n, E = g.E, wm = g.wm;
     const int npad = std::max(next_pow2(n), 2);
     L.npad = npad;
@@ -41,7 +41,9 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
     L.off_hs = align_up(L.off_aux + n * 2, 16); // behind the decided-0 list of the OSD ordering, used before the elimination sets up
     scratch = std::max(scratch, L.off_hs + n * 8);
     scratch = align_up(scratch, 16);
-    int o = scratch;
+    // large graphs: the scratch region goes to HBM; what follows is laid out from LDS offset 0
+    L.big_scratch = big ? scratch : 0;
+    int o = big ? 0 : scratch;
     // The tuned osd_window kernels (up to 256 threads, swd_osdw_kernel.h: SWD_P16 / DIET) keep a smaller state: 32 + 16 bits of
     // live mask per check (row weight <= 48), one parity byte per check, no copy of the original check degrees, one
     // "decided" bit per variable node.  Every other kernel: the classic arrays.
@@ -72,7 +74,7 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L) {
 
 // OSD-only layout of a graph (used by the quaternary decoder): npad / off_idx / off_aux / off_cs / cs_par,
 // off_livemask = bytes of scratch the OSD phase needs
-int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L) { return make_layout(g, g.n, nt, 0, L); }
+int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L) { return make_layout(g, g.n, nt, 0, L, false); }
 
 
 // Static check-to-thread map of the full-graph BP phase for variants that share heavy checks among threads
@@ -120,6 +122,21 @@ static const Variant kVariants[] = {
     SWD_VARIANTS(X)
 #undef X
 };
+
+#define X(nt, vf, dm, kg) SWD_DECLARE_LAUNCHER(5, nt, vf, dm, kg, 0) SWD_DECLARE_LAUNCHER(6, nt, vf, dm, kg, 0)
+SWD_BIG_VARIANTS(X)
+#undef X
+static const Variant kBigVariants[] = {
+#define X(nt, vf, dm, kg) {nt, vf, dm, kg, 0, SWD_LAUNCHER_NAME(5, nt, vf, dm, kg, 0), nullptr, nullptr, SWD_LAUNCHER_NAME(6, nt, vf, dm, kg, 0)},
+    SWD_BIG_VARIANTS(X)
+#undef X
+};
+
+const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax) {
+    for (const Variant &v : kBigVariants)
+        if (v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm && 4 * v.kg >= kmax) return &v;
+    return nullptr;
+}
 
 const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind) {
     for (const Variant &v : kVariants) {

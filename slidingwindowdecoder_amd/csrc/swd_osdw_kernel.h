@@ -41,6 +41,10 @@ struct SwdLdsLayout {
     int32_t off_bak;   // inside scratch: state backup of the parallel peel (10 m + 2 n bytes)
     int32_t off_hs;    // inside scratch: f64 hs[n], summed posterior history of the live VNs after a failed post phase (HACC kernels)
     int32_t off_oslot; // inside scratch (tail of the sort keys): exchange slots of the column-form elimination (osd0_cols), -1 if unused
+    // Large graphs (kernels instantiated with BIG, swd_kernels_k5.hip): the scratch region -- messages, sort keys, staged lists,
+    // OSD arrays -- lives in HBM, big_scratch bytes per workgroup, and every other offset above (off_livemask ... off_misc, total)
+    // is relative to the workgroup's LDS, which then only holds the per-check / per-variable-node state.  0: everything in LDS.
+    int32_t big_scratch;
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -121,6 +125,8 @@ struct SwdPipeArgs {
     uint8_t *state;           // [B][state_stride]: residual syndrome + accumulators handed to the next window
     int64_t state_stride;
     int32_t slot_scratch;     // hist / snap are private to the workgroup (indexed by blockIdx.x), not to the shot
+    uint8_t *big;             // BIG kernels: [gridDim.x][big_stride] scratch regions of the workgroups in HBM
+    int64_t big_stride;
     SwdGdgPar gdgp;
 };
 
@@ -2006,14 +2012,16 @@ struct WinResult {
     long long t[9]; // phase boundaries (wall_clock64 ticks): init, pre, sort, shorten, post, osd sort, elim, sweep
 };
 
-__device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout &L) {
-    s.scratch = smem;
-    s.msg = (double *)smem;
+// scratch: where the scratch region of this workgroup starts -- the LDS block itself, or (BIG kernels) its region in HBM, in which
+// case the remaining offsets of the layout are LDS offsets as they stand
+__device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout &L, char *scratch) {
+    s.scratch = scratch;
+    s.msg = (double *)scratch;
     s.livemask = (uint64_t *)(smem + L.off_livemask);
     s.par = (uint32_t *)(smem + L.off_par);
     s.lv = (uint16_t *)(smem + L.off_lv);
     s.jptr = (uint16_t *)(smem + L.off_jptr);
-    s.lslot = (uint16_t *)(smem + (L.off_lslot >= 0 ? L.off_lslot : 0));
+    s.lslot = (uint16_t *)((L.off_lslot > 0 ? smem : scratch) + (L.off_lslot >= 0 ? L.off_lslot : 0)); // 0: staged at the start of the scratch region
     s.cn_val = (int8_t *)(smem + L.off_cnval);
     s.cn_deg = (uint8_t *)(smem + L.off_cndeg);
     s.cn_deg0 = (uint8_t *)(smem + L.off_cndeg0);
@@ -2027,7 +2035,7 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 
 // osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
 // order).  On return s.hard[0..n) is the vector decode() returns.
-template <int NT, int VF, int DM, int KG, bool SF, bool HACC>
+template <int NT, int VF, int DM, int KG, bool SF, bool HACC, bool BIG = false>
 __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                               const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map) {
     constexpr bool DIET = SWD_P16(NT); // the tuned kernels' LDS forms (decided-node bits, 48-bit live masks, no copy of the check degrees)
@@ -2359,7 +2367,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         }
         __syncthreads();
     }
-    R.pm = osd_run<NT, DM, true>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted);
+    R.pm = osd_run<NT, DM, !BIG>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted); // (the column-form elimination addresses LDS explicitly)
     R.exit_class = SWD_EXIT_OSD;
 }
 
@@ -2391,8 +2399,11 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 // (gfx950's sc1 accesses; the guide lists "sc1 payload -> asm vmcnt(0) -> sc1 flag" as a valid form).
 // A wait that exceeds its 10 s bound sets bit 0 of *status, records exit class SWD_EXIT_SCHED_FAULT for the unit
 // and commits nothing for it: the caller sees the fault (swd_pipeline_status) instead of a plausible wrong answer.
-template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
+// BIG (large graphs, osd_window only): the scratch region of the window's layout -- fp64 messages, sort keys, OSD arrays --
+// is the workgroup's region of a.big in HBM (served by L2 / the memory-side cache); LDS keeps the per-check and per-node state.
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2))) pipeline_kernel(const SwdPipeArgs a) {
+    static_assert(!BIG || KIND == 0 || KIND == 3, "the HBM-resident scratch region exists for the osd_window kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     // One workgroup decodes ONE window of one shot.  Units are handed out by an atomic ticket in
@@ -2537,7 +2548,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         const SwdWindowDev &w = a.wins[wi];
         const SwdGraphDev &g = w.g;
         const SwdLdsLayout &L = w.L;
-        lds_bind(s, smem, L);
+        lds_bind(s, smem, L, BIG ? (char *)(a.big + (int64_t)blockIdx.x * a.big_stride) : smem);
         WinResult R;
 #ifdef SWD_BPPROF
         if (tid == 0) { s.scal[24] = s.scal[25] = s.scal[26] = s.scal[27] = 0; s.scal[20] = s.scal[21] = s.scal[22] = 0; }
@@ -2547,7 +2558,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
             R = WinResult{};
             R.exit_class = SWD_EXIT_SCHED_FAULT;
         } else if constexpr (KIND == 0 || KIND == 3) // 3: osd_window with the posterior history accumulated in registers (bp_run, ACC)
-            decode_window<NT, VF, DM, KG, SF, KIND == 3>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
+            decode_window<NT, VF, DM, KG, SF, KIND == 3, BIG>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
                                                          a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
         else {
             uint8_t *snap_b = a.snap + (int64_t)sidx * a.snap_stride;

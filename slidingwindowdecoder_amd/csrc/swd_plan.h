@@ -19,7 +19,7 @@ namespace swd {
 inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L);
+int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bool big = false);
 
 struct WindowHost {
     std::shared_ptr<Graph> g;
@@ -39,6 +39,7 @@ struct Variant {
     int (*launch_acc)(Plan *, const SwdPipeArgs &, hipStream_t);  // osd_window, posterior history accumulated in registers (kind 3)
 };
 const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
+const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax); // osd_window on graphs beyond one CU's LDS: scratch region in HBM
 bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);
 
 
@@ -56,6 +57,8 @@ struct Plan {
     int device = 0, nt = 256, vf = 7, dm = 8;
     const Variant *variant = nullptr;
     int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
+    bool big = false;          // large graphs: the layouts' scratch region lives in HBM (big_stride bytes per workgroup)
+    int64_t big_stride = 0;
     DevBuf d_wins, d_chk, d_obs, d_cnmap;
     DevBuf shot;
     const uint32_t *d_colptr = nullptr;
@@ -69,7 +72,7 @@ struct Plan {
     // launches of one decoder on different streams (or from different host threads) never share it: a launch
     // that re-uses a slot first makes its stream wait for the slot's previous launch (hipStreamWaitEvent).
     struct LaunchSlot {
-        DevBuf sched, state, hist, snap, gq, gfq, gctx, gsnap;
+        DevBuf sched, state, hist, snap, gq, gfq, gctx, gsnap, big;
         DevBuf gfree_tmpl;     // a full free-context ring, copied into the slot's ring per launch (per slot: a launch on another
         int gfree_n = 0;       // stream may still be copying from the template of ITS slot while this one is rebuilt)
         hipEvent_t done = nullptr;
@@ -148,30 +151,42 @@ struct Plan {
         int kmax = 0;
         mmax = 0;
         for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
-        variant = select_variant(wins, mmax, nmax, dm, kmax, kind);
-        if (!variant) {
-            set_error("no kernel variant for m=%d n=%d column weight %d row weight %d", mmax, nmax, dm, kmax);
-            return -1;
+        const int mtop = mmax, ktop = kmax;
+        // the LDS-resident kernels first; graphs beyond them (no variant, or more than a CU's 160 KB of LDS per shot) take the
+        // large-graph form of the osd_window kernels, whose scratch region lives in HBM
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            big = attempt == 1;
+            if (big && kind != 0) break;
+            variant = big ? select_big_variant(mtop, nmax, dm, ktop) : select_variant(wins, mtop, nmax, dm, ktop, kind);
+            if (!variant) {
+                set_error("no kernel variant for m=%d n=%d column weight %d row weight %d%s", mtop, nmax, dm, ktop,
+                          big ? " (large-graph kernels: up to 1024 checks, 9216 columns, column weight 10, row weight 64)" : "");
+                continue;
+            }
+            nt = variant->nt; vf = variant->vf;
+            mmax = 0; lmax = 0; big_stride = 0;
+            for (auto &w : wins) {
+                make_layout(*w.g, w.new_n, nt, kind, w.L, big);
+                lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
+                big_stride = std::max<int64_t>(big_stride, align_up(w.L.big_scratch, 256));
+            }
+            if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
+            if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
+            off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
+            int dmax = num_det; // tuned osd_window kernels (up to 256 threads): LDS keeps the residual syndrome of one window's rows (whole words), swd_osdw_kernel.h
+            if (kind == 0 && nt <= 256) {
+                dmax = 0;
+                for (auto &w : wins) dmax = std::max(dmax, std::min((w.row0 + w.g->m + 3) & ~3, (num_det + 3) & ~3) - (w.row0 & ~3));
+            }
+            lds_total = off_det + align_up(dmax, 16);
+            if (lds_total > 160 * 1024) {
+                set_error("window graph needs %d bytes of LDS per shot (> 163840)%s", lds_total, big ? " even with its messages in HBM" : "");
+                variant = nullptr;
+                continue;
+            }
+            break;
         }
-        nt = variant->nt; vf = variant->vf;
-        mmax = 0;
-        for (auto &w : wins) {
-            make_layout(*w.g, w.new_n, nt, kind, w.L);
-            lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
-        }
-        if (chk) { num_det = chk->m; num_col = chk->n; } else { num_det = mmax; num_col = 0; }
-        if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
-        off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
-        int dmax = num_det; // tuned osd_window kernels (up to 256 threads): LDS keeps the residual syndrome of one window's rows (whole words), swd_osdw_kernel.h
-        if (kind == 0 && nt <= 256) {
-            dmax = 0;
-            for (auto &w : wins) dmax = std::max(dmax, std::min((w.row0 + w.g->m + 3) & ~3, (num_det + 3) & ~3) - (w.row0 & ~3));
-        }
-        lds_total = off_det + align_up(dmax, 16);
-        if (lds_total > 160 * 1024) {
-            set_error("window graph needs %d bytes of LDS per shot (> 163840)", lds_total);
-            return -1;
-        }
+        if (!variant) return -1;
         if (status.reserve(64)) return -1; // word 0: fault flags; words 1..15: counters of diagnostic builds
         SWD_HIP(hipMemset(status.p, 0, 64));
         std::vector<SwdWindowDev> hw(wins.size());
@@ -220,14 +235,14 @@ struct Plan {
 
 
 
-template <int NT, int VF, int DM, int KG, int KIND, bool SF = false>
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false>
 int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     SwdPipeArgs a = a0;
     static std::mutex fn_mu; // the attribute and the occupancy answer belong to the function, not to a decoder
     std::lock_guard<std::mutex> fn_lock(fn_mu);
     static int lds_limit[64] = {0}; // per device, monotone
     if (d->lds_total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
     }
     // persistent grid: as many workgroups as fit the device at once (they draw work units until none is left)
@@ -235,7 +250,7 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     static int slots_lds[64] = {0};
     if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->lds_total) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF>, NT, (size_t)d->lds_total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG>, NT, (size_t)d->lds_total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         // the occupancy API accepts 54 592 B of LDS for three workgroups per CU; the hardware placed a third one up to 53 552 B
         // and not at 54 032 B (scripts/residency_check.py): count LDS in granules of 1280 B
@@ -300,11 +315,15 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
             a.hist = d->cur->hist.as<double>();
         }
     }
+    if constexpr (BIG) { // the workgroups' scratch regions in HBM (messages, sort keys, OSD arrays)
+        if (d->cur->big.reserve((size_t)grid * d->big_stride)) return -1;
+        a.big = d->cur->big.as<uint8_t>(); a.big_stride = d->big_stride;
+    }
     if (d->kind != 0) {
         if (d->cur->snap.reserve(nscr * d->snap_stride + 8)) return -1;
         a.snap = d->cur->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
     }
-    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF>), dim3(grid), dim3(NT), d->lds_total, st, a);
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG>), dim3(grid), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
@@ -312,6 +331,9 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
 // one launcher per kernel instantiation, defined in swd_kernels_*.hip
 #define SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf) swd_launch_k##kind##_##nt##_##vf##_##dm##_##kg##_##sf
 #define SWD_DECLARE_LAUNCHER(kind, nt, vf, dm, kg, sf) int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *, const SwdPipeArgs &, hipStream_t);
+// large-graph form of the osd_window kernels: kind 5 = kind 0, kind 6 = kind 3 (history sum in registers), scratch region in HBM
+#define SWD_DEFINE_BIG_LAUNCHER(kind, nt, vf, dm, kg) \
+    int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, 0)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, (kind) == 6 ? 3 : 0, false, true>(d, a, st); }
 #define SWD_DEFINE_LAUNCHER(kind, nt, vf, dm, kg, sf) \
     int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, kind, (sf) != 0>(d, a, st); }
 

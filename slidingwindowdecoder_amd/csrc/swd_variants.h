@@ -21,3 +21,10 @@
     X(1024, 3, 10, 12, 0, 1, 0, 0)  /* SHYPS r=3 twelve-round windows (252 x 2240, column weight 9, row weight 44) */   \
     X(1024, 8, 8, 16, 0, 1, 0, 0)
 #endif
+
+// Large graphs (row J of the scope table: osd_window on matrices whose fp64 messages do not fit a CU's LDS, e.g. the un-windowed
+// 936 x 8784 detector error model of /root/reference/IBM.ipynb:119): one 1024-thread workgroup per shot, the scratch region of
+// the layout in HBM (pipeline_kernel<..., BIG>).  Chosen when no variant above fits.  X(nt, vf, dm, kg)
+#define SWD_BIG_VARIANTS(X)                                                                                           \
+    X(1024, 9, 6, 9)     /* [[144,12,12]] global DEM: 936 x 8784, column weight 6, row weight 35 */                      \
+    X(1024, 9, 10, 16)   /* up to 1024 checks, 9216 columns, column weight 10, row weight 64 */

@@ -290,6 +290,42 @@ def gen_bb288(ref, shots=24):
     save("bb288_circuit_p005_w4f1.npz", **arrs)
 
 
+def gen_global144(ref, shots=288):
+    """Row J: osd_window on the UN-windowed detector error model, as /root/reference/IBM.ipynb:119-135 configures it
+    (`decode(..., shorten=True)`: pre_max_iter=16, post_max_iter=1000, new_n=None -> 2 x 936 columns kept, osd_cs order 10) on the
+    [[144,12,12]] circuit of 12 rounds at p = 0.004 (936 x 8784, 30 672 edges: the messages of one shot do not fit a CU's LDS).
+    One reference object decodes all shots in sequence, like the notebook's loop."""
+    from slidingwindowdecoder_amd.codes import bb_code
+    from slidingwindowdecoder_amd.circuit import bb_dem
+    from slidingwindowdecoder_amd.windows import sample_dem
+    code, A, B = bb_code(144)
+    dem = bb_dem(code, A, B, 0.004, 12)
+    chk = sp.csr_matrix(dem.chk)
+    assert chk.shape == (936, 8784)
+    det, obs, _ = sample_dem(chk, dem.obs, dem.priors, shots, seed=20240401)
+    kw = dict(pre_max_iter=16, post_max_iter=1000, ms_scaling_factor=1.0, new_n=None, osd_method="osd_cs", osd_order=10)
+    arrs = {"params": json.dumps(kw), "obs_data": pack(obs)}
+    arrs.update(graph_arrays(chk, dem.priors, "chk_"))
+    arrs.update(graph_arrays(sp.csr_matrix(dem.obs), dem.priors, "obs_"))
+    t = time.time()
+    rec = Recorder(ref.osd_window(chk, channel_probs=dem.priors, **kw), chk.shape[1], hist_every=0, has_hist=False)
+    for j in range(shots):
+        rec.decode(det[j])
+    conv, it = np.array(rec.conv), np.array(rec.iters)
+    print(f"  global144: {time.time() - t:.1f}s for {shots} shots; pre {int(((conv == 1) & (it <= 16)).sum())} "
+          f"post {int(((conv == 1) & (it > 16)).sum())} osd {int((conv == 0).sum())}")
+    arrs.update(rec.arrays("osd10_"))
+    # a second, cheaper parameter set on the same syndromes: OSD order 0, post phase capped at 100 iterations (more OSD exits)
+    kw2 = dict(kw, post_max_iter=100, osd_order=0)
+    arrs["params_b"] = json.dumps(kw2)
+    rec2 = Recorder(ref.osd_window(chk, channel_probs=dem.priors, **kw2), chk.shape[1], hist_every=0, has_hist=False)
+    for j in range(shots):
+        rec2.decode(det[j])
+    print(f"  global144/b: osd exits {int((np.array(rec2.conv) == 0).sum())}")
+    arrs.update(rec2.arrays("osd0_"))
+    save("bb144_global_p004.npz", **arrs)
+
+
 def gen_kat288(ref):
     """`Syndrome code.ipynb` cell 6: weight-2 syndromes of the [[288,12,18]] hx.  The notebook's
     stored output ((0,72) and (1,73) converge "with 14 VNs") is what the MULTI-thread reference
@@ -434,7 +470,7 @@ def gen_bp4_shyps(ref):
 def main():
     ensure_reference()
     import src as ref
-    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4", "camel", "bp4_shyps"]
+    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4", "camel", "bp4_shyps", "global144"]
     if "bb72" in which:
         gen_bb72(ref)
     if "bb144" in which:
@@ -443,6 +479,8 @@ def main():
         gen_bb288(ref)
     if "kat288" in which:
         gen_kat288(ref)
+    if "global144" in which:
+        gen_global144(ref)
     if "bp4" in which:
         gen_bp4(ref)
     if "camel" in which:

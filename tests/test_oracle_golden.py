@@ -10,8 +10,8 @@ from oracle import oracle as O
 from tests import fixtures as fx
 
 
-def replay(dec, tr, check_hist=True):
-    for k in range(len(tr)):
+def replay(dec, tr, check_hist=True, limit=None):
+    for k in range(len(tr) if limit is None else min(limit, len(tr))):
         out = dec.decode(tr.synd[k])
         assert (out == tr.out[k]).all(), f"decode {k}: vector differs in {(out != tr.out[k]).sum()} bits"
         assert bool(dec.converge) == bool(tr.converge[k]), f"decode {k}: converge"
@@ -143,3 +143,17 @@ def test_constructor_errors_match_reference():
     d = O.osd_window(mat, channel_probs=priors)
     with pytest.raises(ValueError):
         d.decode(np.zeros(35))
+
+
+@pytest.mark.parametrize("tag,pkey", [("osd10_", "params"), ("osd0_", "params_b")])
+def test_bb144_global_dem(tag, pkey):
+    """osd_window on the un-windowed 936 x 8784 detector error model, configured like /root/reference/IBM.ipynb:119-135
+    (pre 16, post 1000, osd_cs 10) and with a shorter post phase at order 0: the reference's recorded run, one object, in order"""
+    f = fx.load("bb144_global_p004.npz")
+    mat, priors = fx.graph(f, "chk_")
+    assert mat.shape == (936, 8784) and mat.nnz == 30672
+    dec = O.osd_window(mat, channel_probs=priors, **fx.params(f, pkey))
+    # ~0.4 s per decode on this matrix: the CPU suite replays the first 40 decodes of each run (SWD_FULL_GOLDEN=1: all 288 --
+    # green on the committed oracle); the GPU suite compares all of them with the device
+    import os
+    replay(dec, fx.Trace(f, tag, *mat.shape), check_hist=False, limit=None if os.environ.get("SWD_FULL_GOLDEN") == "1" else 40)
