@@ -86,6 +86,9 @@ def lib():
         L.swo_gdg_free.argtypes = [C.c_void_p]
         L.swo_gdg_clear_history.argtypes = [C.c_void_p]
         L.swo_gdg_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_Result)]
+        L.swo_gdg_ensemble_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.swo_gdg_cols.restype = C.POINTER(C.c_int)
+        L.swo_gdg_cols.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -245,7 +248,28 @@ class bp_history_decoder(_GdgBase):
 
 
 class bpgdg_decoder(_GdgBase):
+    """multi_thread=False: the deterministic gdg() (bp_guessing_decoder.pyx:254-338); multi_thread=True: the threaded ensemble
+    (bpgd.cpp:419-688) with its thread bodies run in a fixed order -- main, tree threads by id, side threads by index, ties of the
+    path metric to the earliest (swd_oracle.c: gdg_multi_run)."""
     _mode = 0
+
+    def __init__(self, parity_check_matrix, **kw):
+        super().__init__(parity_check_matrix, **kw)
+        if kw.get("multi_thread", False):
+            self._mode = 3
+
+    def ensemble_info(self):
+        """after a multi_thread decode that ran the post-processing: (path metric per hypothesis [main, tree 1.., side 1..],
+        10000.0 = not converged; index of the winner or -1; number of converged hypotheses sharing the winning metric with a
+        different vector -- non-zero: the reference's answer for this syndrome depends on thread timing)"""
+        pm = np.zeros(256)
+        w, t = C.c_int32(), C.c_int32()
+        k = lib().swo_gdg_ensemble_info(self._h, pm.ctypes.data, 256, C.byref(w), C.byref(t))
+        return pm[:k].copy(), w.value, t.value
+
+    @property
+    def cols(self):
+        return np.ctypeslib.as_array(lib().swo_gdg_cols(self._h), (self.n,)).astype(np.int32)
 
 
 class bpgd_decoder(_GdgBase):

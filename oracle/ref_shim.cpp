@@ -76,4 +76,25 @@ void ref_bpgd_llr_posterior(void *b, double *out) {  // n x 4
     for (int v = 0; v < p->n; v++) memcpy(out + 4 * v, p->llr_posterior[v], 4 * sizeof(double));
 }
 
+// The reference's threaded ensemble itself (BPGD_main_thread::do_work, bpgd.cpp:591-688, spawns its tree and side threads):
+// one decode of the post-processing for a given column order.  Besides the shared result (min_pm, min_pm_error) the
+// per-thread path metrics are read back from the thread objects -- each is a pure function of the inputs, only the strict-<
+// update of the shared result depends on thread timing (on exact ties) -- so the oracle's restatement can be held to every
+// thread's metric bit for bit.  pms: [num_tree + num_side], 10000.0 = not converged.  Returns num_tree | num_side << 16.
+int ref_gdg_multi(void *Hv, int m, int new_n, int num_iter, int max_step, int max_tree_depth, int max_side_depth, int max_tree_step,
+                  int max_side_step, int low_error_mode, double factor, int32_t *cols, double *llr, const uint8_t *synd,
+                  uint8_t *min_pm_error, double *min_pm, double *pms) {
+    BPGD_main_thread mt(m, new_n, num_iter, max_step, max_tree_depth, max_side_depth, max_tree_step, max_side_step, low_error_mode, factor);
+    char *s = (char *)malloc(m);
+    for (int i = 0; i < m; i++) s[i] = (char)synd[i];
+    mt.do_work((mod2sparse *)Hv, (int *)cols, llr, s);
+    free(s);
+    for (int v = 0; v < new_n; v++) min_pm_error[v] = (uint8_t)mt.min_pm_error[v];
+    *min_pm = mt.min_pm;
+    int k = 0;
+    for (auto &t : mt.bpgd_tree_vec) pms[k++] = t->min_pm;
+    for (auto &t : mt.bpgd_side_vec) pms[k++] = t->min_pm;
+    return mt.num_tree_threads | (mt.num_side_threads << 16);
+}
+
 }  // extern "C"

@@ -612,6 +612,10 @@ struct swo_gdg {
     int *decision_vn_stack, *alt_depth_stack;
     double min_pm;
     int converge, bp_iteration;
+    /* threaded ensemble (mode 3): path metric of every hypothesis of the last decode, 10000.0 = did not converge:
+     * [0] main thread, [1 .. T] tree threads by id, [T+1 .. T+S] side threads by index */
+    double *ens_pm;
+    int ens_count, ens_winner, ens_ties;
 };
 
 static void bpgd_alloc(bpgd_t *b, int m, int n, int num_iter, int low_error_mode, double factor) {
@@ -772,6 +776,7 @@ void swo_gdg_free(swo_gdg *d) {
     for (int i = 0; i < d->max_guess; i++) { free(d->vn_stack[i]); free(d->cn_stack[i]); free(d->cn_degree_stack[i]); }
     free(d->vn_stack); free(d->cn_stack); free(d->cn_degree_stack);
     free(d->decision_value_stack); free(d->decision_vn_stack); free(d->alt_depth_stack);
+    free(d->ens_pm);
     free(d);
 }
 void swo_gdg_clear_history(swo_gdg *d) { memset(d->hist, 0, (size_t)d->n * 4 * sizeof(double)); }
@@ -924,12 +929,203 @@ static void gd_run(swo_gdg *d) {
     for (int v = 0; v < new_n; v++) d->bp_decoding[d->cols[v]] = d->bpgd_error[v];
 }
 
+/* BPGD::select_vn bpgd.cpp:288-355 -- the C++ selection routine the threaded ensemble uses (the single-thread gdg() has its own
+ * in Cython, restated above as gdg_select_vn).  Thresholds are the class's int members (bpgd.hpp:15): A, A_sum, C = 30, D = 3.
+ * Returns the favoured value and *guess_vn (may be -1), or -1 when an aggressive decimation or the peeling after it fails. */
+static int bpgd_select_vn(bpgd_t *b, int A, int A_sum, int current_depth, int *guess_vn) {
+    const tanner *t = &b->pcm;
+    const int C = 30, D = 3;
+    int sum_smallest_vn = -1, sum_smallest_all_neg_vn = -1;
+    double sum_smallest = 10000.0, sum_smallest_all_neg = 10000.0;
+    for (int vn = 0; vn < b->n; vn++) {
+        if (b->vn_mask[vn] != -1) continue;
+        if (b->vn_degree[vn] <= 2) continue;
+        int num_flip = 0;
+        for (int k = t->col_ptr[vn]; k < t->col_ptr[vn + 1]; k++) {
+            int cn = t->row_idx[k];
+            if (b->cn_mask[cn] == -1) continue;
+            if (b->syndrome[cn] != b->temp_syndrome[cn]) num_flip++;
+        }
+        const double *h = b->post + (size_t)vn * 4;
+        int all_smaller_than_A = 1, all_negative = 1, all_larger_than_C = 1, all_larger_than_D = 1;
+        double history_sum = 0.0;
+        for (int i = 0; i < 4; i++) {
+            double llr = h[i];
+            history_sum += llr;
+            if (llr < C) all_larger_than_C = 0;
+            if (llr < D) all_larger_than_D = 0;
+            if (llr > A) all_smaller_than_A = 0;
+            if (llr > 0) all_negative = 0;
+        }
+        if (!b->low_error_mode && all_larger_than_C && current_depth < 4) { if (bpgd_vn_set_value(b, vn, 0) == -1) return -1; }
+        else if (!b->low_error_mode && num_flip >= 3 && all_larger_than_D) { if (bpgd_vn_set_value(b, vn, 0) == -1) return -1; }
+        else if (!b->low_error_mode && all_smaller_than_A && history_sum < A_sum) { if (bpgd_vn_set_value(b, vn, 1) == -1) return -1; }
+        else {
+            if (history_sum < sum_smallest) { sum_smallest = history_sum; sum_smallest_vn = vn; }
+            if (all_negative && history_sum < sum_smallest_all_neg) { sum_smallest_all_neg = history_sum; sum_smallest_all_neg_vn = vn; }
+        }
+    }
+    if (bpgd_peel(b) == -1) return -1;
+    if (sum_smallest_all_neg_vn != -1) { *guess_vn = sum_smallest_all_neg_vn; return 1; }
+    *guess_vn = sum_smallest_vn;
+    return (sum_smallest > 0) ? 0 : 1;
+}
+
+/* The threaded ensemble, bpgdg_decoder.gdg_multi_thread (bp_guessing_decoder.pyx:238-251) over BPGD_main_thread::do_work
+ * (bpgd.cpp:591-688), BPGD_tree_thread::do_work (:435-525) and BPGD_side_thread::do_work (:527-570), as ONE thread running
+ * the bodies in a fixed order: main, tree threads by id, side threads by index.  Every thread's work is a pure function of
+ * (matrix, column order, priors, syndrome) and -- side threads -- of the snapshot the main thread hands over; the only thing
+ * the reference's threads race for is the strict-< update of the shared best under store_mtx (:463-466, :552-556, :650-654),
+ * whose outcome depends on the arrival order only when two converged hypotheses carry exactly the same path metric.  Here
+ * ties go to the earliest in the order above; ens_ties counts the converged hypotheses that share the winning metric with a
+ * DIFFERENT vector (several threads often reach the same vector), so a caller can tell the shots on which the reference's own
+ * answer is timing dependent.  State is that of a newly built
+ * object (min_pm_error zero-initialised, bpgd.cpp:583): when BPGD::reset fails the zero vector comes back. */
+static void ens_offer(swo_gdg *d, int who, const bpgd_t *b, double pm, double *best, signed char *best_err) {
+    d->ens_pm[who] = pm;
+    if (pm < *best) { *best = pm; memcpy(best_err, b->error, d->new_n); d->ens_winner = who; d->ens_ties = 0; }
+    else if (pm == *best && memcmp(best_err, b->error, d->new_n) != 0) d->ens_ties++; /* same metric, another vector */
+}
+
+static void gdg_multi_run(swo_gdg *d) {
+    bpgd_t *b = &d->b;
+    const int n = d->n, new_n = d->new_n, m = d->m;
+    const int Dp = d->p.max_tree_depth, S = d->p.max_side_depth;
+    const int T = (1 << Dp) - 1, NS = (S - Dp > 0) ? S - Dp : 0;
+    for (int v = 0; v < n; v++) { const double *h = d->hist + (size_t)v * 4; d->llr_sum[v] = h[0] + h[1] + h[2] + h[3]; }
+    index_sort(d->llr_sum, d->cols, n);
+    d->ens_count = 1 + T + NS; d->ens_winner = -1; d->ens_ties = 0;
+    free(d->ens_pm); d->ens_pm = xcalloc(d->ens_count, sizeof(double));
+    for (int i = 0; i < d->ens_count; i++) d->ens_pm[i] = 10000.0;
+    double best = 10000.0;
+    signed char *best_err = xcalloc(new_n ? new_n : 1, 1);
+    /* snapshots handed to the side threads (:655-667) */
+    signed char *side_vn = xcalloc((size_t)(NS ? NS : 1) * new_n, 1), *side_cn = xcalloc((size_t)(NS ? NS : 1) * m, 1);
+    int *side_deg = xcalloc((size_t)(NS ? NS : 1) * m, sizeof(int)), *side_status = xcalloc(NS ? NS : 1, sizeof(int));
+    int *side_vnidx = xcalloc(NS ? NS : 1, sizeof(int)), *side_val = xcalloc(NS ? NS : 1, sizeof(int)), *side_depth = xcalloc(NS ? NS : 1, sizeof(int));
+    signed char *bk_vn = xcalloc(new_n ? new_n : 1, 1), *bk_cn = xcalloc(m, 1);
+    int *bk_deg = xcalloc(m, sizeof(int));
+    int main_converge = 0;
+
+    /* ---- main thread (:591-688): thresholds (-3, -16 at depth 0 / -12, 30, 3) */
+    if (bpgd_reset(b, &d->t, d->cols, d->g->llr, d->synd) != -1) {
+        for (int depth = 0; depth < d->p.max_step; depth++) {
+            int conv = bpgd_min_sum_log(b);
+            int guess_vn = -1;
+            int favor = bpgd_select_vn(b, -3, depth == 0 ? -16 : -12, depth, &guess_vn); /* BEFORE the convergence test (:630-633) */
+            if (conv || favor == -1 || guess_vn == -1) {
+                int j = depth - Dp; if (j < 0) j = 0;
+                for (; j < NS; j++) side_status[j] = -1;
+                if (!conv) break;
+                main_converge = 1;
+                ens_offer(d, 0, b, bpgd_get_pm(b), &best, best_err);
+                break;
+            }
+            if (depth >= Dp && depth < S) {
+                int j = depth - Dp;
+                memcpy(side_vn + (size_t)j * new_n, b->vn_mask, new_n);
+                memcpy(side_cn + (size_t)j * m, b->cn_mask, m);
+                memcpy(side_deg + (size_t)j * m, b->cn_degree, m * sizeof(int));
+                side_vnidx[j] = guess_vn; side_val[j] = 1 - favor; side_depth[j] = depth + 1; side_status[j] = 1;
+            }
+            if (bpgd_vn_set_value(b, guess_vn, favor) != -1 && bpgd_peel(b) != -1) continue;
+            int j = depth + 1 - Dp; if (j < 0) j = 0;
+            for (; j < NS; j++) side_status[j] = -1;
+            break;
+        }
+        signed char *main_err = xcalloc(new_n ? new_n : 1, 1);
+        memcpy(main_err, b->error, new_n);
+
+        /* ---- tree threads id = 1 .. 2^D - 1 (:435-525) */
+        for (int id = 1; id <= T; id++) {
+            if (bpgd_reset(b, &d->t, d->cols, d->g->llr, d->synd) == -1) continue;
+            int on_side = 0, saved = 0, A = -3, A_sum = -16, bk_vnidx = -1, bk_val = 0, done = 0;
+            double own_pm = 10000.0;
+            for (int depth = 0; depth < d->p.max_tree_branch_step + Dp + 1; depth++) {
+                if (depth > 0 && !on_side) A_sum = -12;
+                if (bpgd_min_sum_log(b)) { own_pm = bpgd_get_pm(b); ens_offer(d, id, b, own_pm, &best, best_err); done = 1; break; }
+                int guess_vn = -1;
+                int favor = bpgd_select_vn(b, A, A_sum, depth, &guess_vn);
+                if (favor == -1 || guess_vn == -1) break;
+                if (depth < Dp) {
+                    int dir = (id >> (Dp - 1 - depth)) & 1;
+                    if (dir) { on_side = 1; A = 0; A_sum = -10; favor = 1 - favor; } /* no re-initialisation of the messages (:494-495) */
+                } else if (depth == Dp) {
+                    memcpy(bk_vn, b->vn_mask, new_n); memcpy(bk_cn, b->cn_mask, m); memcpy(bk_deg, b->cn_degree, m * sizeof(int));
+                    bk_vnidx = guess_vn; bk_val = 1 - favor; saved = 1;
+                }
+                if (bpgd_vn_set_value(b, guess_vn, favor) == -1) break;
+                if (bpgd_peel(b) == -1) break;
+            }
+            if (done || !saved) continue;
+            bpgd_set_masks(b, bk_vn, bk_cn, bk_deg); /* :501-506: masks, error = vn_mask, init() */
+            if (bpgd_vn_set_value(b, bk_vnidx, bk_val) == -1) continue;
+            if (bpgd_peel(b) == -1) continue;
+            int depth = Dp + 1;
+            for (int i = 0; i < d->p.max_tree_branch_step; i++) {
+                if (bpgd_min_sum_log(b)) {
+                    double pm = bpgd_get_pm(b);
+                    if (pm > own_pm) break;
+                    ens_offer(d, id, b, pm, &best, best_err);
+                    break;
+                }
+                int guess_vn = -1;
+                int favor = bpgd_select_vn(b, A, A_sum, depth, &guess_vn);
+                if (favor == -1 || guess_vn == -1) break;
+                if (bpgd_vn_set_value(b, guess_vn, favor) == -1) break;
+                if (bpgd_peel(b) == -1) break;
+                depth++;
+            }
+        }
+
+        /* ---- side threads (:527-570): thresholds (0, -10, 30, 3); their messages come from their own reset(), i.e. the priors */
+        for (int j = 0; j < NS; j++) {
+            if (side_status[j] != 1) continue;
+            if (bpgd_reset(b, &d->t, d->cols, d->g->llr, d->synd) == -1) continue;
+            memcpy(b->vn_mask, side_vn + (size_t)j * new_n, new_n);
+            memcpy(b->cn_mask, side_cn + (size_t)j * m, m);
+            memcpy(b->cn_degree, side_deg + (size_t)j * m, m * sizeof(int));
+            for (int v = 0; v < new_n; v++) b->error[v] = b->vn_mask[v];
+            if (bpgd_vn_set_value(b, side_vnidx[j], side_val[j]) == -1) continue;
+            if (bpgd_peel(b) == -1) continue;
+            int depth = side_depth[j];
+            for (int i = 0; i < d->p.max_side_branch_step; i++) {
+                if (bpgd_min_sum_log(b)) { ens_offer(d, 1 + T + j, b, bpgd_get_pm(b), &best, best_err); break; }
+                int guess_vn = -1;
+                int favor = bpgd_select_vn(b, 0, -10, depth, &guess_vn);
+                if (favor == -1 || guess_vn == -1) break;
+                if (bpgd_vn_set_value(b, guess_vn, favor) == -1) break;
+                if (bpgd_peel(b) == -1) break;
+                depth++;
+            }
+        }
+        if (!main_converge && best > 10000.0 - 1.0) memcpy(best_err, main_err, new_n); /* :677-682 */
+        free(main_err);
+    }
+    d->min_pm = best;
+    d->converge = best < 9999.0;
+    for (int v = 0; v < new_n; v++) d->bp_decoding[d->cols[v]] = best_err[v];
+    for (int v = new_n; v < n; v++) d->bp_decoding[d->cols[v]] = 0;
+    free(best_err); free(side_vn); free(side_cn); free(side_deg); free(side_status); free(side_vnidx); free(side_val); free(side_depth);
+    free(bk_vn); free(bk_cn); free(bk_deg);
+}
+
+/* per-hypothesis path metrics of the last ensemble decode: returns their number, *winner, *ties */
+int swo_gdg_ensemble_info(const swo_gdg *d, double *pm, int cap, int32_t *winner, int32_t *ties) {
+    for (int i = 0; i < d->ens_count && i < cap; i++) pm[i] = d->ens_pm[i];
+    if (winner) *winner = d->ens_winner;
+    if (ties) *ties = d->ens_ties;
+    return d->ens_count;
+}
+const int *swo_gdg_cols(const swo_gdg *d) { return d->cols; }
+
 int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_result *res) {
     for (int c = 0; c < d->m; c++) d->synd[c] = (signed char)synd[c];
     int exit_class = 0;
     if (gdg_bp(d)) { d->converge = 1; exit_class = SWO_EXIT_PRE; }
     else if (mode == 0) { gdg_run(d); exit_class = SWO_EXIT_POST; }
     else if (mode == 1) { gd_run(d); exit_class = SWO_EXIT_POST; }
+    else if (mode == 3) { gdg_multi_run(d); exit_class = SWO_EXIT_POST; }
     else { d->converge = 0; exit_class = SWO_EXIT_NO_OSD; }
     for (int v = 0; v < d->n; v++) out[v] = (uint8_t)d->bp_decoding[v];
     if (res) {

@@ -96,7 +96,14 @@ void swo_gdg_free(swo_gdg *d);
 void swo_gdg_clear_history(swo_gdg *d);
 /* mode 0: bpgdg_decoder.decode (single thread gdg); mode 1: bpgd_decoder.decode (gd);
  * mode 2: bp_history_decoder (plain BP only) */
+/* mode 3: bpgdg_decoder.decode with multi_thread=True -- the threaded ensemble of bpgd.cpp:419-688 with the thread bodies run
+ * in a fixed order (main, tree threads by id, side threads by index; ties of the path metric to the earliest) */
 int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_result *res);
+/* after a mode-3 decode: path metric per hypothesis (10000.0: not converged) -> number of hypotheses; the winner's index (-1:
+ * none) and how many converged hypotheses share the winning metric with a different vector (> 0: the reference's own answer
+ * depends on thread timing) */
+int swo_gdg_ensemble_info(const swo_gdg *d, double *pm, int cap, int32_t *winner, int32_t *ties);
+const int *swo_gdg_cols(const swo_gdg *d); /* column order of the last post-processing (index_sort of the history sums) */
 const double *swo_gdg_history(const swo_gdg *d);
 
 /* ---- bp4_osd (src/bp4_osd.pyx): quaternary min-sum BP on (Hx, Hz) + one OSD per basis ---- */

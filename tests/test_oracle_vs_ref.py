@@ -138,3 +138,87 @@ def test_bpgd_worker_class(R):
             nconv += 1
     assert nconv >= 20
     R.ref_bpgd_free(b)
+
+
+def _ensemble_case(R, mat, priors, kw, synds):
+    """Oracle ensemble (fixed thread order) vs the reference's real threads on the same column order: every thread's path metric
+    must agree bit for bit (those are race free); the shared result must agree whenever the winning metric is unique."""
+    m, n = mat.shape
+    dec = O.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
+    p = Pcm(R, mat)
+    llr = np.ascontiguousarray(np.log((1 - priors) / priors))
+    new_n = min(n, 2 * m)
+    R.ref_gdg_multi.argtypes = [C.c_void_p] + [C.c_int32] * 9 + [C.c_double] + [C.c_void_p] * 6
+    ran = ties = conv = 0
+    for s in synds:
+        dec.clear_history()
+        out = dec.decode(s)
+        if dec._res.exit_class == 0:
+            continue  # pre-processing BP converged: no ensemble
+        pms, winner, nt = dec.ensemble_info()
+        cols = np.ascontiguousarray(dec.cols)
+        err, rpm, rpms = np.zeros(new_n, np.uint8), C.c_double(), np.zeros(256)
+        su = np.ascontiguousarray(s, np.uint8)
+        rc = R.ref_gdg_multi(p.h, m, new_n, kw["max_iter_per_step"], kw["max_step"], kw["max_tree_depth"], kw["max_side_depth"],
+                             kw["max_tree_branch_step"], kw["max_side_branch_step"], int(kw.get("low_error_mode", False)),
+                             float(kw.get("gdg_factor", 1.0)), cols.ctypes.data, llr.ctypes.data, su.ctypes.data, err.ctypes.data,
+                             C.byref(rpm), rpms.ctypes.data)
+        T, S = rc & 0xFFFF, rc >> 16
+        assert len(pms) == 1 + T + S
+        assert np.array_equal(pms[1:], rpms[:T + S]), f"per-thread path metrics differ: {pms[1:]} vs {rpms[:T + S]}"
+        assert dec.min_pm == rpm.value and bool(dec.converge) == (rpm.value < 9999.0)
+        if rpm.value < 9999.0 and pms[0] < 9999.0:
+            assert pms[0] >= rpm.value
+        ran += 1
+        conv += int(dec.converge)
+        if nt > 0:
+            ties += 1  # another vector with the same metric: the reference's own answer depends on which thread got the lock first
+            continue
+        ref_out = np.zeros(n, np.uint8)
+        ref_out[cols[:new_n]] = err
+        assert np.array_equal(out, ref_out), f"ensemble result differs (winner {winner}, pm {dec.min_pm})"
+    return ran, conv, ties
+
+
+def test_threaded_ensemble_bb72(R):
+    f = fx.load("bb72_capacity.npz")
+    mat, _ = fx.graph(f, "gdg_")
+    rng = np.random.default_rng(23)
+    priors = rng.uniform(0.03, 0.08, size=72)  # unequal priors: path metrics of different hypotheses rarely tie
+    kw = dict(max_iter=8, ms_scaling_factor=1.0, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+              max_tree_branch_step=10, max_side_branch_step=10, gdg_factor=1.0)
+    H = sp.csr_matrix(mat).astype(np.int64)
+    synds = [(H @ (rng.random(72) < priors * 1.3).astype(np.int64) % 2).astype(np.uint8) for _ in range(300)]
+    ran, conv, ties = _ensemble_case(R, mat, priors, kw, synds)
+    assert ran >= 60 and conv >= 30 and ties < ran // 10, (ran, conv, ties)
+
+
+def test_threaded_ensemble_bb144_window(R):
+    """a circuit-level window of configs[2] with the notebook's parameters (Sliding Window GDG.ipynb cell 3), multi_thread=True"""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    mat, priors = fx.graph(f, "win5_")
+    tr = fx.Trace(f, "gdg_win5_", *mat.shape)
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    ran, conv, ties = _ensemble_case(R, mat, priors, kw, list(tr.synd[:192]))
+    assert ran >= 40 and conv >= 30, (ran, conv, ties)
+
+
+def test_threaded_ensemble_weight2_known_answer():
+    """`Syndrome code.ipynb` cell 6 (:233-234): with multi_thread=True only the syndromes (0,72) and (1,73) of the [[288,12,18]] hx
+    converge, both with 14 flipped variable nodes -- that stored output is the ensemble's, and the oracle's ensemble reproduces it
+    (the reference's own run, recorded in the fixture, agrees)."""
+    f = fx.load("bb288_hx_wt2_kat.npz")
+    from slidingwindowdecoder_amd.codes import bb_code
+    code, _, _ = bb_code(288)
+    kw = fx.params(f, "params")
+    dec = O.bpgdg_decoder(code.hx, channel_probs=np.ones(288) * 0.01, multi_thread=True, **kw)
+    ok = []
+    for i, j in f["pairs"]:
+        s = np.zeros(144, np.uint8)
+        s[i] = s[j] = 1
+        dec.clear_history()
+        e = dec.decode(s)
+        if dec.converge:
+            ok.append((int(i), int(j), int(e.sum())))
+    assert ok == [tuple(int(x) for x in r) for r in f["multi"]] == [(0, 72, 14), (1, 73, 14)]
