@@ -60,6 +60,12 @@ WORKLOADS = {
     "bb288": dict(problem=dict(N=288, W=4, F=1), metric="sliding windows decoded/s, [[288,12,18]] BB p=0.003",
                   desc="configs[3]: [[288,12,18]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(4,1), "
                        "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d)"),
+    # row J: osd_window on the UN-windowed detector error model as /root/reference/IBM.ipynb:119-135 configures it (936 x 8784, 30 672
+    # edges = 245 KB of fp64 messages per shot: the large-graph kernels keep them in HBM, so here SURVEY 8(d)'s HBM roofline applies)
+    "global144": dict(problem=dict(p=0.004, W=13, F=1), decoder_kw=dict(pre_max_iter=16, post_max_iter=1000),
+                      metric="global decodes/s, [[144,12,12]] BB p=0.004, osd_window on the 936 x 8784 DEM", unit="decodes/s",
+                      desc="IBM.ipynb decode(shorten=True): [[144,12,12]] BB, circuit-level p=0.004, 12 rounds, ONE window = the whole "
+                           "936 x 8784 detector error model, osd_window(pre=16, post=1000, alpha=1.0, osd_cs order %d)"),
     # the quaternary decoder of configs[4], device-resident (the reference runs BP4 on code-capacity noise only: Misc.ipynb cell 2)
     "bp4": dict(problem=None, metric="bp4_osd decodes/s, [[144,12,12]] BB depolarizing p=0.02", unit="decodes/s",
                 desc="bp4_osd(max_iter=100, alpha=0.625, osd_cs order 10) on [[144,12,12]] hx/hz, depolarizing code-capacity noise p=0.02 "
@@ -223,7 +229,7 @@ class GpuEngine:
         self.torch = torch
         self.dev = torch.device("cuda", local_rank)
         self.plan, self.W = plan, len(plan.windows)
-        kw = dict(GDG_KW) if workload == "gdg" else dict(DECODER_KW, osd_order=order)
+        kw = dict(GDG_KW) if workload == "gdg" else dict(DECODER_KW, osd_order=order, **WORKLOADS[workload].get("decoder_kw", {}))
         self.dec = SlidingWindowDecoder(plan, device=local_rank, **kw)
         shots = hi - lo
         self.nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
@@ -456,7 +462,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     headline = args.workload == "headline"
-    osdw = args.workload in ("headline", "bb288")
+    osdw = args.workload in ("headline", "bb288", "global144")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)
@@ -558,7 +564,7 @@ def main():
             cfg["live_edge_iterations_pre_post_rank0"] = [int(sum(w.mat.nnz * st[:, i, 2].sum() for i, w in enumerate(plan.windows))),
                                                           int((st[..., 6].astype(np.int64) * st[..., 3]).sum())]
             alg_bytes = algorithmic_bytes(plan, st, DECODER_KW["pre_max_iter"])
-            lds_alg = lds_algorithmic_bytes(plan, st)
+            lds_alg = lds_algorithmic_bytes(plan, st) if args.workload != "global144" else None  # (its messages are not in LDS)
 
     if rank == 0 and world == 1 and headline and not args.no_side_order:
         # the same batches at the other OSD order (a second, untimed-by-the-driver loop): order 0 next to the notebooks' default 10

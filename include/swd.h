@@ -125,12 +125,16 @@ typedef struct swd_gdg_params {
     int32_t new_n;               /* <=0: min(n, 2m) */
     int32_t low_error_mode;
     int32_t mode;                /* 0 bpgdg_decoder, 1 bpgd_decoder, 2 bp_history_decoder */
-    int32_t multi_thread;        /* bpgdg_decoder(multi_thread=True): the hypothesis ensemble of bpgd.cpp:419-688 -- every
-                                    leaf of the decimation tree counts (no min_converge_depth pruning, no snapshot cap),
-                                    smallest path metric wins, ties to the earliest in stack order.  Deterministic here;
-                                    the reference's threaded version is racy, so this mode is no parity target.  0: the
-                                    single-thread gdg() semantics (bit-exact).  Either way the side branches of one
-                                    shot run concurrently on different workgroups. */
+    int32_t multi_thread;        /* 0: the single-thread gdg() (bit-exact; side branches of one shot run concurrently on different
+                                    workgroups).  1: bpgdg_decoder(multi_thread=True), the threaded ensemble of bpgd.cpp:419-688
+                                    (main thread, 2^D - 1 tree threads, S - D side threads; kernel kind 7) with the thread
+                                    bodies in a fixed order -- identical to the reference on every syndrome whose winning path
+                                    metric is not shared by a second, different vector (statistics word 7 counts those; the
+                                    reference's own answer depends on thread timing there).  stats for this mode: [4]
+                                    hypotheses run, [5] BP blocks, [6] winner (0 main, 1.. tree ids, then side threads; -1 none),
+                                    [7] tied hypotheses with a different vector.  2: NOT a reference mode -- every leaf of gdg()'s
+                                    decimation tree counts (no min_converge_depth pruning, no snapshot cap), smallest path metric
+                                    wins, ties to the earliest in stack order. */
 } swd_gdg_params;
 
 typedef struct swd_gdg swd_gdg;

@@ -15,9 +15,11 @@ if os.environ.get('SWD_CONFIG') == 'shyps12':  # SHYPS r=3, twelve-round windows
     from slidingwindowdecoder_amd.windows import plan_windows
     _dem = shyps.shyps_dem(3, 0.001, 14)
     plan = plan_windows(_dem.chk, _dem.obs, _dem.priors, 21, 12, 1, method=1)
+elif os.environ.get('SWD_CONFIG') == 'global144':  # the un-windowed 936 x 8784 DEM on the large-graph kernels (IBM.ipynb:119-135)
+    plan = bench.build_problem(**bench.WORKLOADS["global144"]["problem"])
 else:
     plan = bench.build_problem(N=288, W=4, F=1) if os.environ.get('SWD_CONFIG') == '288' else bench.build_problem()
-dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=order))
+dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=order, **(bench.WORKLOADS["global144"]["decoder_kw"] if os.environ.get('SWD_CONFIG') == 'global144' else {})))
 det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=1)
 d = torch.from_numpy(det).cuda()
 dec.decode_device(d); torch.cuda.synchronize()

@@ -324,14 +324,14 @@ struct GdgSpec {
     int fail_before, fail_after, child; // out
 };
 
+// The scan itself -- classification of every position, the aggressive decimations in position order, the peeling after
+// them, and the candidate to guess -- shared by the Cython routine above and by BPGD::select_vn (bpgd.cpp:288-355, thresholds
+// A / A_sum of the calling thread; C = 30, D = 3).  Returns -1 when a decimation or the peeling fails; else guess_pos (0x7fffffff:
+// no candidate) and the favoured value.
 template <int NT>
-__device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
-                                             const double *hist_b, bool side, int depth, int min_converge_depth,
-                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr) {
+__device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
+                                               const double *hist_b, double A, double A_sum, int depth, int &guess_pos, int &favor) {
     const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
-    const double A = side ? 0.0 : -3.0;
-    double A_sum = side ? -10.0 : -12.0;
-    if (depth == 0) A_sum = -16.0;
     const double C = 30.0, D = 3.0;
     double best_all = 10000.0, best_neg = 10000.0;
     int pos_all = 0x7fffffff, pos_neg = 0x7fffffff;
@@ -399,11 +399,23 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();
-        if (s.scal[1]) { if (sp) sp->fail_before = 1; return -1; }
+        if (s.scal[1]) return -1;
     }
-    int guess_pos, favor;
     if (pos_neg != 0x7fffffff) { guess_pos = pos_neg; favor = 1; }
     else { guess_pos = pos_all; favor = (best_all > 0) ? 0 : 1; }
+    return 0;
+}
+
+template <int NT>
+__device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
+                                             const double *hist_b, bool side, int depth, int min_converge_depth,
+                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr) {
+    const int tid = threadIdx.x, new_n = g.new_n;
+    const double A = side ? 0.0 : -3.0;
+    double A_sum = side ? -10.0 : -12.0;
+    if (depth == 0) A_sum = -16.0;
+    int guess_pos, favor;
+    if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, guess_pos, favor) == -1) { if (sp) sp->fail_before = 1; return -1; }
     bool guess = true;
     if (depth > min_converge_depth) guess = false;
     if (!side && depth >= P.max_side_depth) guess = false;
@@ -742,11 +754,148 @@ __device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDeco
     return true;
 }
 
+// The reference's threaded ensemble (bpgdg_decoder(multi_thread=True): bp_guessing_decoder.pyx:238-251 over
+// BPGD_main_thread / BPGD_tree_thread / BPGD_side_thread::do_work, bpgd.cpp:435-688) on one workgroup, the thread bodies in
+// the order main, tree threads by id, side threads by index -- the order of oracle/swd_oracle.c:gdg_multi_run, which is
+// pinned to the reference's real threads.  Every body is a pure function of its inputs; only the strict-< update of the
+// shared best depends on thread timing in the reference, and only when two converged hypotheses carry the same path metric
+// with different vectors (statistics word 7 counts those: such shots have no single reference answer).
+//   main   thresholds (-3, -16 at depth 0 else -12); select_vn runs BEFORE the convergence test (:630-633); at depths D..S-1 the
+//          masks before the guess go to side thread depth - D together with the unfavoured value
+//   tree   id = 1 .. 2^D - 1: at depth d < D bit (D-1-d) of id picks favour / unfavour (unfavour: thresholds (0, -10) from then on,
+//          NO re-initialisation of the messages); at depth D the masks are saved; after max_tree_branch_step + D + 1 steps the
+//          saved masks are restored with freshly initialised messages and the unfavoured value, max_tree_branch_step more steps
+//   side   thresholds (0, -10): the handed-over masks, messages = priors, the unfavoured value, max_side_branch_step steps
+// Snapshot slots in snap_b: 0 = state after BPGD::reset, 1 = the tree thread's saved masks, 2 + j = side thread j's.
+// Entered with the state after reset (peeled, caches built, messages initialised).  Leaves the winner in G.best_err.
+template <int NT, int VF, int DM, int KG>
+__device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
+                                                 double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
+                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn) {
+    const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
+    const int Dp = P.max_tree_depth, S = P.max_side_depth;
+    const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
+    const int64_t rec = gdg_snap_bytes(m, new_n);
+    const int NONE = 0x7fffffff;
+    double best = 10000.0;
+    int winner = -1, ties = 0, blocks = 0, ran = 1, it = 0;
+    auto block = [&](bool first) { // one min_sum_log call (bpgd.cpp:97-197); first: the messages start from the priors
+        const int nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
+        if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
+        const int cv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        ++blocks; R.post_it += it;
+        return cv;
+    };
+    auto set_value = [&](int pos, int val) { // vn_set_value + peel; true on failure
+        __syncthreads();
+        if (tid < 64) {
+            bool bad = (pos == NONE) ? true : gdg_set_value_wave(g, s, G.pos_lv[pos], val);
+            if (!bad) bad = peel_wave(g, s);
+            if (tid == 0) s.scal[1] = bad ? 1 : 0;
+        }
+        __syncthreads();
+        return s.scal[1] != 0;
+    };
+    auto offer = [&](int who) { // the strict-< update of the shared best under store_mtx
+        const double pm = gdg_get_pm<NT>(g, s, G);
+        if (pm < best) {
+            best = pm; winner = who; ties = 0;
+            for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
+            __syncthreads();
+        } else if (pm == best) { // same metric: a different vector makes the reference's answer timing dependent
+            bool diff = false;
+            for (int j = tid; j < new_n; j += NT) diff |= (G.best_err[j] != s.hard[G.pos_lv[j]]);
+            if (block_any<NT>(diff, s)) ++ties;
+        }
+        return pm;
+    };
+    gdg_snap_save<NT>(g, s, G, snap_b); // slot 0: what every thread's reset() arrives at
+    // ---- main thread
+    bool main_conv = false;
+    for (int depth = 0; depth < P.max_step; ++depth) {
+        const int cv = block(false);
+        int gpos = NONE, favor = 0;
+        const int rc = gdg_select_core<NT>(g, P, s, G, hist_b, -3.0, depth == 0 ? -16.0 : -12.0, depth, gpos, favor);
+        if (cv || rc == -1 || gpos == NONE) {
+            if (cv) { main_conv = true; offer(0); }
+            break;
+        }
+        if (depth >= Dp && depth < S) {
+            const int j = depth - Dp;
+            gdg_snap_save<NT>(g, s, G, snap_b + (int64_t)(2 + j) * rec);
+            if (tid == 0) { G.dec_vn[j] = (int16_t)gpos; G.dec_val[j] = (int8_t)(1 - favor); G.alt_depth[j] = (int16_t)(depth + 1); }
+        }
+        if (set_value(gpos, favor)) break;
+    }
+    if (!main_conv) { // returned when no hypothesis converges (:677-682)
+        for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
+    }
+    __syncthreads();
+    // which side threads were handed a snapshot: depth d saved iff the main loop reached its save, i.e. alt_depth[j] == Dp + j + 1
+    // (the array is cleared by the caller)
+    // ---- tree threads
+    for (int id = 1; id <= T; ++id) {
+        ++ran;
+        gdg_snap_load<NT>(g, s, G, snap_b);
+        bool on_side = false, saved = false, done = false;
+        double A = -3.0, A_sum = -16.0, own_pm = 10000.0;
+        int bk_pos = NONE, bk_val = 0;
+        for (int depth = 0; depth < P.max_tree_branch_step + Dp + 1; ++depth) {
+            if (depth > 0 && !on_side) A_sum = -12.0;
+            if (block(depth == 0)) { own_pm = offer(id); done = true; break; }
+            int gpos = NONE, favor = 0;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor) == -1 || gpos == NONE) break;
+            if (depth < Dp) {
+                if ((id >> (Dp - 1 - depth)) & 1) { on_side = true; A = 0.0; A_sum = -10.0; favor = 1 - favor; }
+            } else if (depth == Dp) {
+                gdg_snap_save<NT>(g, s, G, snap_b + rec);
+                bk_pos = gpos; bk_val = 1 - favor; saved = true;
+            }
+            if (set_value(gpos, favor)) break;
+        }
+        if (done || !saved) continue;
+        gdg_snap_load<NT>(g, s, G, snap_b + rec);
+        if (set_value(bk_pos, bk_val)) continue;
+        int depth = Dp + 1;
+        for (int i = 0; i < P.max_tree_branch_step; ++i) {
+            if (block(i == 0)) {
+                const double pm = gdg_get_pm<NT>(g, s, G);
+                if (!(pm > own_pm)) offer(id);
+                break;
+            }
+            int gpos = NONE, favor = 0;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor) == -1 || gpos == NONE) break;
+            if (set_value(gpos, favor)) break;
+            ++depth;
+        }
+    }
+    // ---- side threads
+    for (int j = 0; j < NS; ++j) {
+        if (G.alt_depth[j] != Dp + j + 1) continue; // never handed a snapshot (status -1 / 0)
+        ++ran;
+        gdg_snap_load<NT>(g, s, G, snap_b + (int64_t)(2 + j) * rec);
+        if (set_value((int)G.dec_vn[j], (int)G.dec_val[j])) continue;
+        int depth = G.alt_depth[j];
+        for (int i = 0; i < P.max_side_branch_step; ++i) {
+            if (block(i == 0)) { offer(1 + T + j); break; }
+            int gpos = NONE, favor = 0;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, 0.0, -10.0, depth, gpos, favor) == -1 || gpos == NONE) break;
+            if (set_value(gpos, favor)) break;
+            ++depth;
+        }
+    }
+    __syncthreads();
+    R.conv = best < 9999.0; R.pm = best;
+    R.live_vn = ran; R.live_cn = blocks; R.live_e = winner; R.osd_rowadds = ties;
+}
+
 // bpgdg_decoder.decode / bpgd_decoder.decode / bp_history_decoder for one syndrome.  On return
 // s.hard[0..n) is the returned vector.
 // par != nullptr (parallel form): a tree with side branches is parked in a context and its side branches are queued;
 // then R.exit_class = -2 on return and the result arrives later as a FINAL item (gdg_finalize).
-template <int NT, int VF, int DM, int KG>
+// ENS (kernel kind 7): bpgdg_decoder(multi_thread=True) -- the post-processing is the reference's threaded ensemble
+// (gdg_ensemble_ref) instead of gdg()'s tree walk.
+template <int NT, int VF, int DM, int KG, bool ENS = false>
 __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                                   const uint8_t *synd, double *hist_b, uint8_t *snap_b, WinResult &R,
                                                   const SwdPipeArgs *par = nullptr, uint32_t *acc = nullptr, int wi = 0, int b = 0) {
@@ -836,7 +985,9 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     }
     __syncthreads();
     if (s.scal[1]) { // BPGD::reset failed: decode returns the BP vector with cols[new_n:] zeroed
-        for (int v = tid; v < n; v += NT) s.hard[v] = G.bp_hard[v];
+        // (the threaded ensemble returns its zero-initialised min_pm_error instead: bp_guessing_decoder.pyx:247-251 copy it
+        // over the first new_n sorted columns whatever happened, bpgd.cpp:619-625 return before anything is written to it)
+        for (int v = tid; v < n; v += NT) s.hard[v] = ENS ? (uint8_t)0 : G.bp_hard[v];
         __syncthreads();
         R.exit_class = SWD_EXIT_FAIL_PEEL;
         return;
@@ -844,6 +995,19 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     int nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
     bp_init<VF, DM>(s, vc);
     __syncthreads();
+    if constexpr (ENS) {
+        for (int j = tid; j < 64; j += NT) G.alt_depth[j] = -1;
+        __syncthreads();
+        gdg_ensemble_ref<NT, VF, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vc, cn);
+        for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+        __syncthreads();
+        for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
+        __syncthreads();
+        R.total_it = R.pre_it + R.post_it;
+        R.exit_class = SWD_EXIT_POST;
+        R.t[5] = wall_clock64();
+        return;
+    }
 
     double min_pm = 10000.0;
     int used_guess = 0, min_converge_depth = P.max_step, converge = 0, blocks = 0;

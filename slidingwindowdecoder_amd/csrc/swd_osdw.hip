@@ -114,11 +114,11 @@ bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map) {
 #define SWD_IF(c, ...) SWD_IF_##c(__VA_ARGS__)
 #define SWD_PTR_0(kind, nt, vf, dm, kg, sf) nullptr
 #define SWD_PTR_1(kind, nt, vf, dm, kg, sf) SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)
-#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_DECLARE_LAUNCHER(0, nt, vf, dm, kg, sf) SWD_IF(k1, SWD_DECLARE_LAUNCHER(1, nt, vf, dm, kg, sf)) SWD_IF(k2, SWD_DECLARE_LAUNCHER(2, nt, vf, dm, kg, sf)) SWD_IF(k3, SWD_DECLARE_LAUNCHER(3, nt, vf, dm, kg, sf))
+#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_DECLARE_LAUNCHER(0, nt, vf, dm, kg, sf) SWD_IF(k1, SWD_DECLARE_LAUNCHER(1, nt, vf, dm, kg, sf)) SWD_IF(k2, SWD_DECLARE_LAUNCHER(2, nt, vf, dm, kg, sf)) SWD_IF(k3, SWD_DECLARE_LAUNCHER(3, nt, vf, dm, kg, sf)) SWD_IF(k1, SWD_DECLARE_LAUNCHER(7, nt, vf, dm, kg, sf))
 SWD_VARIANTS(X)
 #undef X
 static const Variant kVariants[] = {
-#define X(nt, vf, dm, kg, sf, k1, k2, k3) {nt, vf, dm, kg, sf, SWD_PTR_1(0, nt, vf, dm, kg, sf), SWD_PTR_##k1(1, nt, vf, dm, kg, sf), SWD_PTR_##k2(2, nt, vf, dm, kg, sf), SWD_PTR_##k3(3, nt, vf, dm, kg, sf)},
+#define X(nt, vf, dm, kg, sf, k1, k2, k3) {nt, vf, dm, kg, sf, SWD_PTR_1(0, nt, vf, dm, kg, sf), SWD_PTR_##k1(1, nt, vf, dm, kg, sf), SWD_PTR_##k2(2, nt, vf, dm, kg, sf), SWD_PTR_##k3(3, nt, vf, dm, kg, sf), SWD_PTR_##k1(7, nt, vf, dm, kg, sf)},
     SWD_VARIANTS(X)
 #undef X
 };
@@ -127,7 +127,7 @@ static const Variant kVariants[] = {
 SWD_BIG_VARIANTS(X)
 #undef X
 static const Variant kBigVariants[] = {
-#define X(nt, vf, dm, kg) {nt, vf, dm, kg, 0, SWD_LAUNCHER_NAME(5, nt, vf, dm, kg, 0), nullptr, nullptr, SWD_LAUNCHER_NAME(6, nt, vf, dm, kg, 0)},
+#define X(nt, vf, dm, kg) {nt, vf, dm, kg, 0, SWD_LAUNCHER_NAME(5, nt, vf, dm, kg, 0), nullptr, nullptr, SWD_LAUNCHER_NAME(6, nt, vf, dm, kg, 0), nullptr},
     SWD_BIG_VARIANTS(X)
 #undef X
 };
@@ -190,8 +190,9 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // iteration caps multiples of four) the kernel that accumulates the sum in registers runs: no 4 x n ring in HBM
     const bool acc = d->kind == 0 && d->variant->launch_acc && !a.hist && !a.P.record_all && !a.P.hist_is_state && !a.P.zero_hist &&
                      a.P.pre_iter >= 4 && a.P.pre_iter % 4 == 0 && a.P.post_iter >= 4 && a.P.post_iter % 4 == 0 && !getenv("SWD_NO_HACC");
+    const bool ens = d->kind == 1 && d->gp.multi_thread == 1; // the reference's threaded ensemble: its own kernel (kind 7)
     rc = (d->kind == 0) ? (acc ? d->variant->launch_acc(d, a, st) : d->variant->launch(d, a, st))
-                        : (par ? d->variant->launch_par(d, a, st) : d->variant->launch_gdg(d, a, st));
+                        : (ens ? d->variant->launch_ens(d, a, st) : (par ? d->variant->launch_par(d, a, st) : d->variant->launch_gdg(d, a, st)));
     if (rc) return rc;
     SWD_HIP(hipEventRecord(sl.done, st));
     if (d->timing) {
@@ -237,7 +238,7 @@ static void fill_params(const Plan *d, SwdDecodeParams &P, bool hist_is_state, b
         P.max_iter_per_step = d->gp.max_iter_per_step; P.max_step = d->gp.max_step;
         P.max_tree_depth = d->gp.max_tree_depth; P.max_side_depth = d->gp.max_side_depth;
         P.max_side_branch_step = d->gp.max_side_branch_step; P.low_error_mode = d->gp.low_error_mode;
-        P.max_guess = d->max_guess; P.gdg_factor = d->gp.gdg_factor;
+        P.max_guess = d->max_guess; P.gdg_factor = d->gp.gdg_factor; P.max_tree_branch_step = d->gp.max_tree_branch_step;
         P.zero_hist = (!hist_is_state && (hist_is_output || d->gp.max_iter < 4)) ? 1 : 0;
     }
 }
@@ -540,6 +541,7 @@ extern "C" int swd_pipeline_get_profile(swd_pipeline *h, int32_t B, int64_t *out
 // ------------------------------------------------------------------------------------------
 static int check_gdg_params(const swd_gdg_params &gp) {
     if (gp.mode < 0 || gp.mode > 2) { set_error("gdg mode %d invalid (0 bpgdg, 1 bpgd, 2 bp_history)", gp.mode); return -1; }
+    if (gp.multi_thread < 0 || gp.multi_thread > 2) { set_error("invalid guessing-decoder parameters: multi_thread"); return -1; }
     if (gp.max_iter_per_step < 0 || gp.max_step < 0 || gp.max_tree_depth < 0 || gp.max_tree_depth > 6) {
         set_error("invalid guessing-decoder parameters"); return -1;
     }

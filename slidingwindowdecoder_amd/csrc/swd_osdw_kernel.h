@@ -60,6 +60,8 @@ struct SwdDecodeParams {
     int32_t max_iter_per_step, max_step, max_tree_depth, max_side_depth, max_side_branch_step, low_error_mode;
     int32_t max_guess;
     double gdg_factor;
+    int32_t max_tree_branch_step; // threaded ensemble (kernel kind 7): steps of a tree thread after its last split
+    int32_t pad_;
 };
 
 // one window of the sliding-window plan: its graph + where it sits in the global DEM
@@ -2586,7 +2588,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 asm volatile("" ::: "memory"); dbg_tc = wall_clock64(); asm volatile("" ::: "memory");
 #endif
                 s.fpar = 0;
-                decode_window_gdg<NT, VF, DM, KG>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
+                decode_window_gdg<NT, VF, DM, KG, KIND == 7>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
 #ifdef SWD_GDG_DEBUG
                 if (tid == 0 && queued) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(R.exit_class == -2 ? 9 : 10, 1); GDG_COUNT(R.exit_class == -2 ? 11 : 12, wall_clock64() - t_unit0); }
 #endif

@@ -37,6 +37,7 @@ struct Variant {
     int (*launch_gdg)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing decoders, serial tree walk (kind 1)
     int (*launch_par)(Plan *, const SwdPipeArgs &, hipStream_t);  // guessing decoders, side branches as work items (kind 2)
     int (*launch_acc)(Plan *, const SwdPipeArgs &, hipStream_t);  // osd_window, posterior history accumulated in registers (kind 3)
+    int (*launch_ens)(Plan *, const SwdPipeArgs &, hipStream_t);  // bpgdg_decoder(multi_thread=True): the reference's threaded ensemble (kind 7)
 };
 const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
 const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax); // osd_window on graphs beyond one CU's LDS: scratch region in HBM
@@ -135,12 +136,17 @@ struct Plan {
             if (max_guess > 64) { set_error("max_guess=%d exceeds the device limit of 64 snapshots", max_guess); return -1; }
             // parallel form of the tree search (swd_gdg_kernel.h): needs its record formats to hold the parameters
             // (and its work items to hold the unit: item_unit packs the window in 8 bits and the shot in 22, swd_gdg_kernel.h)
-            gdg_parallel = kind == 1 && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
+            if (gp.multi_thread == 1 && (gp.max_side_depth - gp.max_tree_depth > 62 || gp.max_tree_depth > 6)) {
+                set_error("multi_thread: at most 62 side threads and tree depth 6 on the device"); return -1;
+            }
+            gdg_parallel = kind == 1 && gp.multi_thread != 1 && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
                            wins.size() <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_GDG_SERIAL");
             snap_stride = 0;
             for (auto &w : wins) {
                 const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
-                snap_stride = std::max(snap_stride, rec * (gdg_parallel ? SWD_GDG_SLOTS : std::max(max_guess, 1)));
+                // (the threaded-ensemble form keeps: the state after reset, one tree thread's saved masks, one record per side thread)
+                const int ens_slots = (kind == 1 && gp.multi_thread == 1) ? 2 + std::max(gp.max_side_depth - gp.max_tree_depth, 0) : 0;
+                snap_stride = std::max(snap_stride, rec * (gdg_parallel ? SWD_GDG_SLOTS : std::max(std::max(max_guess, 1), ens_slots)));
                 new_n_max = std::max(new_n_max, w.new_n);
             }
         }
@@ -299,7 +305,7 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         a.gdgp.q = sl.gq.as<uint32_t>(); a.gdgp.qmask = cap - 1;
         a.gdgp.fq = sl.gfq.as<uint32_t>(); a.gdgp.fmask = nctx - 1;
         a.gdgp.ctx = sl.gctx.as<uint8_t>(); a.gdgp.csnap = sl.gsnap.as<uint8_t>();
-        a.gdgp.ensemble = d->gp.multi_thread ? 1 : 0;
+        a.gdgp.ensemble = d->gp.multi_thread == 2 ? 1 : 0;
         a.gdgp.inflight_max = inflight;
         a.gdgp.nctx = (int)nctx; a.gdgp.chk_status = d->status.as<uint32_t>();
         a.gdgp.static_bound = getenv("SWD_GDG_STATIC_BOUND") ? 1 : 0;

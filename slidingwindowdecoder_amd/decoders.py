@@ -227,7 +227,7 @@ def _gdg_params(kwargs, mode):
     if hyp is not None:
         if int(hyp) != 64:
             raise ValueError("hypotheses: only 64 is provided (max_tree_depth=5, max_side_depth=6)")
-        kwargs.update(max_tree_depth=5, max_side_depth=6, multi_thread=True)
+        kwargs.update(max_tree_depth=5, max_side_depth=6, multi_thread=2)  # 2: every leaf of gdg()'s tree (not a reference mode)
     new_n = kwargs.get("new_n", None)
     return _lib.GdgParams(int(kwargs.get("max_iter", 50)), float(kwargs.get("ms_scaling_factor", 1.0)),
                           int(kwargs.get("max_iter_per_step", 6)), int(kwargs.get("max_step", 25)),
@@ -235,15 +235,17 @@ def _gdg_params(kwargs, mode):
                           int(kwargs.get("max_tree_branch_step", 10)), int(kwargs.get("max_side_branch_step", 10)),
                           float(kwargs.get("gdg_factor", kwargs.get("gd_factor", 1.0))),
                           int(new_n) if new_n else 0, int(bool(kwargs.get("low_error_mode", False))), mode,
-                          int(bool(kwargs.get("multi_thread", False))) if mode == 0 else 0)
+                          (2 if kwargs.get("multi_thread", False) == 2 else int(bool(kwargs.get("multi_thread", False)))) if mode == 0 else 0)
 
 
 class bp_history_decoder:
     """Plain min-sum BP with a 4-deep posterior history (reference: src/bp_guessing_decoder.pyx:5-158)
     and base class of the guessing decoders.  ``bpgdg_decoder``: the side branches of a shot's decimation tree run
     concurrently on different workgroups; with ``multi_thread=False`` (default) the result is that of the reference's
-    deterministic single-thread ``gdg()`` bit for bit, with ``multi_thread=True`` every hypothesis counts like in the
-    reference's threaded ensemble (which is racy: that mode is deterministic here but no parity target)."""
+    deterministic single-thread ``gdg()`` bit for bit; ``multi_thread=True`` runs the reference's threaded ensemble
+    (bpgd.cpp:419-688: main thread, 2^D - 1 tree threads, S - D side threads) with the thread bodies in a fixed order, equal to
+    the reference on every syndrome whose winning path metric is unique (``last_stats[:, 7]`` counts the tied, different
+    vectors); ``hypotheses=64`` is this package's own ensemble over every leaf of gdg()'s tree (no reference counterpart)."""
     _mode = 2
 
     def __init__(self, parity_check_matrix, **kwargs):

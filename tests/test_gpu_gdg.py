@@ -175,9 +175,9 @@ def test_parallel_tree_search_equals_serial_in_every_record():
 
 
 def test_hypothesis_ensemble_mode():
-    """multi_thread=True / hypotheses=64: every leaf counts (the reference's threaded ensemble, which is racy and no
-    parity target).  Properties: deterministic, never worse than the single-thread search in path metric, every
-    converged answer reproduces the syndrome."""
+    """multi_thread=2 / hypotheses=64: this package's own ensemble over every leaf of gdg()'s tree (no reference counterpart).
+    Properties: deterministic, never worse than the single-thread search in path metric, every converged answer reproduces
+    the syndrome."""
     import slidingwindowdecoder_amd as S
     f = fx.load("bb144_circuit_p003_w3f1.npz")
     kw = fx.params(f, "gdg_params")
@@ -186,7 +186,7 @@ def test_hypothesis_ensemble_mode():
     tr = fx.Trace(f, "gdg_win5_", *mat.shape)
     single = S.bpgdg_decoder(mat, channel_probs=priors, **kw)
     out1 = single.decode_batch(tr.synd)
-    for extra in (dict(multi_thread=True), dict(hypotheses=64)):
+    for extra in (dict(multi_thread=2), dict(hypotheses=64)):
         ens = S.bpgdg_decoder(mat, channel_probs=priors, **dict(kw, **extra))
         out = ens.decode_batch(tr.synd)
         assert np.array_equal(out, ens.decode_batch(tr.synd))  # deterministic
@@ -198,6 +198,83 @@ def test_hypothesis_ensemble_mode():
             assert (conv | ~c1).all()
             both = conv & c1
             assert (ens.last_min_pm[both] <= single.last_min_pm[both]).all()
+
+
+def _ensemble_vs_oracle(mat, priors, kw, synd, min_post=20):
+    """device bpgdg_decoder(multi_thread=True) against the oracle's restatement of the threaded ensemble (which
+    tests/test_oracle_vs_ref.py pins to the reference's real threads): vectors, converge flags and path metrics of EVERY shot --
+    also the tied ones, the device breaks ties in the oracle's thread order -- plus the winner and the tie count per shot."""
+    import slidingwindowdecoder_amd as S
+    from oracle import oracle as O
+    dev = S.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
+    ora = O.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
+    out = dev.decode_batch(synd)
+    post = ties = 0
+    for k in range(len(synd)):
+        ora.clear_history()
+        want = ora.decode(synd[k])
+        assert np.array_equal(out[k], want), f"shot {k}: vectors differ"
+        assert bool(dev.last_status[k] & 0x100) == bool(ora.converge), f"shot {k}: converge"
+        if ora._res.exit_class == 0:
+            continue
+        pms, winner, nt = ora.ensemble_info()
+        if (dev.last_status[k] & 0xFF) == 4:  # BPGD::reset failed (no ensemble ran)
+            assert not want.any()
+            continue
+        post += 1
+        ties += int(nt > 0)
+        assert dev.last_min_pm[k] == ora.min_pm, f"shot {k}: min_pm {dev.last_min_pm[k]} vs {ora.min_pm}"
+        assert dev.last_stats[k, 6] == winner and dev.last_stats[k, 7] == nt, f"shot {k}: winner / ties {dev.last_stats[k, 6:8]} vs {(winner, nt)}"
+    assert post >= min_post, post
+    return post, ties
+
+
+def test_threaded_ensemble_bb72_vs_oracle():
+    f = fx.load("bb72_capacity.npz")
+    mat, _ = fx.graph(f, "gdg_")
+    rng = np.random.default_rng(23)
+    priors = rng.uniform(0.03, 0.08, size=72)
+    kw = dict(max_iter=8, ms_scaling_factor=1.0, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+              max_tree_branch_step=10, max_side_branch_step=10, gdg_factor=1.0)
+    H = mat.toarray().astype(np.int64)
+    synd = np.array([(H @ (rng.random(72) < priors * 1.3).astype(np.int64) % 2) for _ in range(300)], dtype=np.uint8)
+    post, ties = _ensemble_vs_oracle(mat, priors, kw, synd, 60)
+    print(f"bb72: {post} ensembles, {ties} with a tied different vector")
+    # other tree shapes and fewer iterations per block than history slots
+    for D, S_, T in ((2, 5, 3), (1, 4, 6), (0, 3, 5)):
+        kw2 = dict(kw, max_tree_depth=D, max_side_depth=S_, max_iter_per_step=T, max_step=12, max_tree_branch_step=4, max_side_branch_step=7,
+                   gdg_factor=0.9, low_error_mode=bool(D == 1))
+        _ensemble_vs_oracle(mat, priors, kw2, synd[:120], 20)
+
+
+def test_threaded_ensemble_bb144_window_vs_oracle():
+    """configs[2]'s window matrices and parameters (Sliding Window GDG.ipynb cell 3) with multi_thread=True"""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    for wi in (0, 5, 10):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        tr = fx.Trace(f, f"gdg_win{wi}_", *mat.shape)
+        post, ties = _ensemble_vs_oracle(mat, priors, kw, tr.synd[:96], 15)
+        print(f"bb144 window {wi}: {post} ensembles, {ties} with a tied different vector")
+
+
+def test_threaded_ensemble_weight2_known_answer():
+    """`Syndrome code.ipynb` cell 6 (:233-234): only (0,72) and (1,73) converge, both with 14 flipped variable nodes -- the stored
+    output of the reference's multi_thread=True run (recorded again in the fixture)"""
+    import slidingwindowdecoder_amd as S
+    from slidingwindowdecoder_amd.codes import bb_code
+    k = fx.load("bb288_hx_wt2_kat.npz")
+    code, _, _ = bb_code(288)
+    pairs = k["pairs"]
+    synd = np.zeros((len(pairs), 144), np.uint8)
+    for q, (i, j) in enumerate(pairs):
+        synd[q, i] = synd[q, j] = 1
+    dec = S.bpgdg_decoder(code.hx, channel_probs=np.ones(288) * 0.01, multi_thread=True, **fx.params(k, "params"))
+    out = dec.decode_batch(synd)
+    conv = np.flatnonzero(dec.last_status & 0x100)
+    got = [(int(pairs[q][0]), int(pairs[q][1]), int(out[q].sum())) for q in conv]
+    assert got == [tuple(int(x) for x in r) for r in k["multi"]] == [(0, 72, 14), (1, 73, 14)]
 
 
 def test_pipeline_with_more_than_256_windows_takes_the_serial_form():
