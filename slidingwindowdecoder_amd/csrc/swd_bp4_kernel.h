@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
             const SwdLdsLayout &L = basis == 0 ? a.Lx : a.Lz;
             uint64_t *key = (uint64_t *)s.scratch;
             uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
+            s.aux = s.scratch + L.off_aux; // the OSD arrays of this basis' layout
             __syncthreads();
             for (int v = tid; v < L.npad; v += NT) {
                 if (v < n) {

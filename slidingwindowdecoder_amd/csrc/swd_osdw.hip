@@ -9,13 +9,14 @@
 
 namespace swd {
 
-int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bool big) {
+int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bool big, int lds_budget) {
     const int m = g.m, n = g.n, E = g.E, wm = g.wm;
     const int npad = std::max(next_pow2(n), 2);
     L.npad = npad;
     L.off_idx = npad * 8;
     L.off_aux = align_up(npad * 10, 16);
     int osd_bytes = align_up(L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16, 16);
+    const int osd_bytes_at_aux = osd_bytes; // end of the arrays that start at off_aux (the higher-order sweep's may follow)
     // higher-order OSD arrays: over the dead sort keys when they fit there, else after the OSD-0 arrays
     L.cs_par = std::min(nt, 256);
     const int kset = std::max(new_n - g.rank, 0);
@@ -68,13 +69,33 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     L.off_vnval = o = align_up(o, 4); o += diet ? ((n + 31) / 32) * 4 : n;
     L.off_hard = o; o = align_up(o + n + 1, 16); // +1: sink for threads without a VN
     L.off_misc = o; o += 640; // flags[32] scal[32] dbl[24] iaux[32]
+    o = align_up(o, 16);
+    // large graphs: what fits beside the state goes back into LDS -- the messages of the shortened graph (one column of cells per
+    // live variable node: D x new_n cells + the sink, far and zero slots) and the arrays of the OSD phase that start at off_aux
+    L.off_pmsg = -1; L.pmsg_bytes = 0; L.post_lds = 0; L.osd_lds = 0;
+    if (big && !getenv("SWD_BIG_NO_LDS")) {
+        const int post_b = align_up((g.D * new_n + 1 + 2 * (nt / 64)) * 8, 16);
+        // (transform matrix, pivots; the ordered list behind them stays in the scratch region -- osd_run)
+        const int aux_b = align_up(std::max(std::max(osd_bytes_at_aux - n * 2, rare_bytes) - L.off_aux, L.off_hs + n * 8 - L.off_aux), 16);
+        const int avail = lds_budget - o;
+        const bool post_ok = g.D * new_n <= 65535 && post_b <= avail && L.off_lslot == 0 && new_n <= 2 * nt, aux_ok = aux_b <= avail;
+        if (post_ok || aux_ok) {
+            L.off_pmsg = o;
+            L.post_lds = post_ok ? 1 : 0; L.osd_lds = aux_ok ? 1 : 0;
+            L.pmsg_bytes = std::max(post_ok ? post_b : 0, aux_ok ? aux_b : 0);
+            o += L.pmsg_bytes;
+        }
+    }
+    // experiment (SWD_POST_RENUM=1, tuned osd_window kernels of up to 256 threads): renumber the shortened graph's message cells
+    // one column per live variable node inside the scratch region; the old-slot -> cell table takes the staged column table's place
+    if (diet && getenv("SWD_POST_RENUM") && L.off_lslot == 0 && (g.D * new_n + 1 + 2 * (nt / 64)) * 8 <= L.off_rc) L.post_lds = 1;
     L.total = align_up(o, 16);
     return 0;
 }
 
 // OSD-only layout of a graph (used by the quaternary decoder): npad / off_idx / off_aux / off_cs / cs_par,
 // off_livemask = bytes of scratch the OSD phase needs
-int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L) { return make_layout(g, g.n, nt, 0, L, false); }
+int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L) { return make_layout(g, g.n, nt, 0, L, false, 0); }
 
 
 // Static check-to-thread map of the full-graph BP phase for variants that share heavy checks among threads

@@ -26,6 +26,11 @@
 #define SWD_OSDW_TUNED 0
 #endif
 #define SWD_P16(NT) (SWD_OSDW_TUNED && (NT) <= 256)
+// experiment builds only (scripts/devbuild.sh -DSWD_POST_RENUM=1 + SWD_POST_RENUM=1 in the environment): the shortened graph's message
+// cells renumbered one column per live variable node in the tuned kernels too (the large-graph kernels always do it)
+#ifndef SWD_POST_RENUM
+#define SWD_POST_RENUM 0
+#endif
 
 struct SwdLdsLayout {
     int32_t off_livemask, off_par, off_lv, off_jptr, off_lslot, off_cnval, off_cndeg, off_cndeg0, off_vnval, off_hard,
@@ -45,6 +50,11 @@ struct SwdLdsLayout {
     // OSD arrays -- lives in HBM, big_scratch bytes per workgroup, and every other offset above (off_livemask ... off_misc, total)
     // is relative to the workgroup's LDS, which then only holds the per-check / per-variable-node state.  0: everything in LDS.
     int32_t big_scratch;
+    // ... and what still fits beside that state goes back into LDS: off_pmsg >= 0 = a region of pmsg_bytes for
+    //   post_lds  the messages of the shortened graph, renumbered one column of cells per live variable node
+    //             (cell(k, i) = k * nlive + i for edge position k of the i-th live node: (column weight) x new_n cells)
+    //   osd_lds   the arrays of the OSD phase that start at off_aux (transform matrix, pivots, ordered lists)
+    int32_t off_pmsg, pmsg_bytes, post_lds, osd_lds;
 };
 
 // decoder parameters shared by every window of a launch (osd_window.pyx:10-16)
@@ -137,6 +147,7 @@ namespace swd {
 struct Lds {
     double *msg;        // scratch region start
     char *scratch;
+    char *aux;          // scratch + off_aux (BIG kernels: possibly the LDS region of the layout instead)
     uint64_t *livemask; // [m]  (diet form: u32 [m] + u16 [m], see lm_get)
     int lm_m;           // m (diet form)
     uint32_t *par;      // [m]
@@ -334,8 +345,11 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
     }
 }
 
+// remap != nullptr (shortened graph, BIG kernels with the post-phase messages in LDS): the messages are renumbered one column of
+// cells per live variable node -- cell(k, i) = k * nlive + i for edge position k of the i-th live node, so that the threads of a
+// wave touch consecutive cells in the variable-node pass -- and remap[old slot] = cell for the check side (g.E = D * nlive here).
 template <int NT, int VF, int DM, bool FULL, int SH, bool PB>
-__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c) {
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr) {
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
 #pragma unroll
@@ -355,7 +369,9 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
                 if (k < deg) {
                     const uint32_t e = g.vn_edge[k * n + v];
                     if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
-                        c.set_ed(i, k, swd_edge_slot(e) << 3);
+                        uint32_t slot = swd_edge_slot(e);
+                        if (!FULL && remap) { const uint32_t cell = (uint32_t)(k * nlive + idx); remap[slot] = (uint16_t)cell; slot = cell; }
+                        c.set_ed(i, k, slot << 3);
                         c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
                                                    : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
                     }
@@ -1957,11 +1973,11 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
     uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
     if (!presorted) sort_pairs<NT>(key, idx, L.npad);
     t_sorted = wall_clock64();
-    uint64_t *Tc = (uint64_t *)(s.scratch + L.off_aux);
+    uint64_t *Tc = (uint64_t *)s.aux;
     uint64_t *Sbuf = Tc + m * g.wm;
     uint16_t *piv_col = (uint16_t *)(Sbuf + g.wm);
     uint16_t *piv_row = piv_col + g.rank;
-    uint16_t *list1 = piv_row + g.rank;
+    uint16_t *list1 = (uint16_t *)(s.scratch + L.off_aux + (size_t)(m * g.wm + g.wm) * 8 + (size_t)g.rank * 4); // (its place in the scratch region, wherever s.aux points)
     for (int i = tid; i < m * g.wm; i += NT) { // word-major identity: Tw[w*m + j]
         const int w = i / m, j = i - w * m;
         Tc[i] = (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
@@ -2018,6 +2034,7 @@ struct WinResult {
 // case the remaining offsets of the layout are LDS offsets as they stand
 __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout &L, char *scratch) {
     s.scratch = scratch;
+    s.aux = scratch + L.off_aux;
     s.msg = (double *)scratch;
     s.livemask = (uint64_t *)(smem + L.off_livemask);
     s.par = (uint32_t *)(smem + L.off_par);
@@ -2122,7 +2139,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     for (int e = tid; e < g.E; e += NT) rc[e] = g.row_col[e];
     __syncthreads();
     // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
-    if (g.new_n < n) select_smallest<NT>(key, n, g.new_n, (int *)(s.scratch + L.off_aux), s);
+    if (g.new_n < n) select_smallest<NT>(key, n, g.new_n, (int *)s.aux, s);
     R.t[3] = wall_clock64();
     bool contra = false;
     for (int l = tid; l < m; l += NT) {
@@ -2148,7 +2165,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         // "setting vn failed" (osd_window.pyx:179-181): the reference stops at the first decimation
         // that empties an unsatisfied check; only VNs up to that sorted position were zeroed.
         sort_pairs<NT>(key, idx, L.npad);
-        uint16_t *pos = (uint16_t *)(s.scratch + L.off_aux);
+        uint16_t *pos = (uint16_t *)s.aux;
         for (int i = tid; i < n; i += NT) pos[idx[i]] = (uint16_t)i;
         if (tid == 0) s.scal[0] = 0x7fffffff;
         __syncthreads();
@@ -2276,16 +2293,65 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     R.live_vn = nlive; R.live_cn = s.scal[2]; R.live_e = s.scal[3];
     int clc, csub, cgrp;
     cn_assign<NT, KG>(g, s, dhist, cord, uselist, true, R.live_cn, clc, csub, cgrp);
-    vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
-    cn_cache_load<NT, KG, false>(g, s, uselist, clc, csub, cgrp, cn);
-    __syncthreads(); // every lane has read its slot list before the messages are re-initialised
-    bp_init<VF, DM>(s, vc);
-    __syncthreads();
-    R.t[4] = wall_clock64();
+    // BIG kernels: the shortened graph's messages move into LDS (layout flag post_lds), renumbered one column of cells per live
+    // variable node; the staged column table of the shortening step (dead now) becomes the old-slot -> cell table
+    // (tuned kernels of up to 256 threads, experiment SWD_POST_RENUM: the same renumbering inside their LDS scratch region --
+    // the variable-node pass of the shortened graph then touches consecutive cells instead of scattered slots)
+    SwdGraphDev gp = g;
+    bool renum = false;
+    constexpr bool kPackedVc = !std::is_same_v<decltype(vc), VnCache<VF, DM>>;
+    constexpr bool kRenum = (BIG || (SWD_POST_RENUM && SWD_P16(NT))) && kPackedVc;
+    if constexpr (kRenum) renum = L.post_lds != 0 && uselist;
+    // the post phase proper, for a register cache of any depth: caches, (re)initialised messages, the iterations
+    // (renum_tag: compile-time twin of `renum`, so that a BIG kernel's post-phase message pointer is an LDS pointer on every path
+    // that reaches the iterations -- ds_read / ds_write instead of flat accesses)
+    auto run_post = [&](auto &vcx, double *hsx, auto vfx, auto renum_tag) {
+        constexpr int VFX = decltype(vfx)::value;
+        if constexpr (kRenum && decltype(renum_tag)::value) {
+            {
+                uint16_t *remap = rc;
+                gp.E = g.D * nlive;
+                if constexpr (BIG) s.msg = (double *)(s.hard - L.off_hard + L.off_pmsg); // the LDS block starts off_hard bytes below s.hard
+                vn_cache_load<NT, VFX, DM, false>(gp, s, nlive, vcx, remap);
+                __syncthreads();
+                for (int l = tid; l < m; l += NT)
+                    if (s.cn_val[l] >= 0) {
+                        const int d = s.cn_deg[l];
+                        for (int k = 0; k < d; ++k) s.lslot[k * m + l] = remap[s.lslot[k * m + l]];
+                    }
+                __syncthreads();
+            }
+        } else vn_cache_load<NT, VFX, DM, false>(gp, s, nlive, vcx);
+        cn_cache_load<NT, KG, false>(gp, s, uselist, clc, csub, cgrp, cn);
+        __syncthreads(); // every lane has read its slot list before the messages are re-initialised
+        bp_init<VFX, DM>(s, vcx);
+        __syncthreads();
+        R.t[4] = wall_clock64();
+        return bp_run<NT, VFX, DM, KG, false, false, HACC>(gp, P, s, P.post_iter, nlive, vcx, cn, hist_b, it, P.alpha, false, hsx);
+    };
+    // BIG kernels keep VF = 9 variable nodes per thread for the full graph; the shortened graph has at most new_n live ones,
+    // normally <= 2 m <= 2 NT: a register cache of depth 2 keeps the iteration loop free of spills (128 VGPRs per thread)
+    // (the host sets post_lds only for new_n <= 2 NT, so the renumbered form always runs at depth 2)
+    bool post_done = false;
+    if constexpr (BIG && kPackedVc && VF > 2) {
+        if (renum && g.new_n <= 2 * NT) {
+            VnCacheP<2, DM, 3, false> vc2;
+            double hs2[2] = {0.0, 0.0};
+            R.conv = run_post(vc2, hs2, std::integral_constant<int, 2>{}, std::true_type{});
+            hs[0] = hs2[0]; hs[1] = hs2[1];
+            post_done = true;
+        }
+    } else if constexpr (kRenum) {
+        if (renum) { R.conv = run_post(vc, hs, std::integral_constant<int, VF>{}, std::true_type{}); post_done = true; }
+    }
+    if (!post_done) R.conv = run_post(vc, hs, std::integral_constant<int, VF>{}, std::false_type{});
 #ifdef SWD_SHPROF
     if (tid == 0) { s.scal[20] = (int)(sh0 - R.t[3]); s.scal[21] = (int)(sh1 - sh0); s.scal[22] = (int)(sh2 - sh1); s.scal[23] = (int)(R.t[4] - sh2); }
 #endif
-    R.conv = bp_run<NT, VF, DM, KG, false, false, HACC>(g, P, s, P.post_iter, nlive, vc, cn, hist_b, it, P.alpha, false, hs);
+    if constexpr (BIG) {
+        s.msg = (double *)s.scratch;
+        if (L.osd_lds) s.aux = (char *)s.hard - L.off_hard + L.off_pmsg; // the arrays of the OSD phase go where the post-phase messages were
+    }
     R.post_it = it;
     R.t[5] = wall_clock64();
     R.total_it = R.pre_it + R.post_it;
@@ -2295,7 +2361,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         return;
     }
     if (P.osd_order < 0) { R.exit_class = SWD_EXIT_NO_OSD; return; }
-    double *hsl = (double *)(s.scratch + L.off_hs); // HACC: history sums of the live VNs by column (the messages are dead now)
+    double *hsl = (double *)(s.aux + (L.off_hs - L.off_aux)); // HACC: history sums of the live VNs by column (the messages are dead now)
     if constexpr (HACC) {
         __syncthreads();
 #pragma unroll
@@ -2316,7 +2382,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     bool presorted = false;
     {
         const uint64_t k1000 = f2key(1000.0);
-        uint16_t *zlist = (uint16_t *)(s.scratch + L.off_aux); // [n], free until the transform matrix is set up
+        uint16_t *zlist = (uint16_t *)s.aux; // [n], free until the transform matrix is set up
         const int ch = (n + NT - 1) / NT;
         const int v0 = tid * ch, v1 = min(n, v0 + ch);
         int cnt = 0; // rest count | zero count << 16

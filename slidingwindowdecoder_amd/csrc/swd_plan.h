@@ -19,7 +19,7 @@ namespace swd {
 inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bool big = false);
+int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bool big = false, int lds_budget = 0);
 
 struct WindowHost {
     std::shared_ptr<Graph> g;
@@ -158,6 +158,8 @@ struct Plan {
         mmax = 0;
         for (auto &w : wins) { kmax = std::max(kmax, w.g->K); mmax = std::max(mmax, w.g->m); }
         const int mtop = mmax, ktop = kmax;
+        int mtop_rows = 0;
+        for (auto &w : wins) mtop_rows = std::max(mtop_rows, w.row0 + w.g->m);
         // the LDS-resident kernels first; graphs beyond them (no variant, or more than a CU's 160 KB of LDS per shot) take the
         // large-graph form of the osd_window kernels, whose scratch region lives in HBM
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -171,8 +173,10 @@ struct Plan {
             }
             nt = variant->nt; vf = variant->vf;
             mmax = 0; lmax = 0; big_stride = 0;
+            // (large graphs: LDS left for the post-phase messages / OSD arrays after the state, the accumulators and the syndrome bytes)
+            const int det_est = chk ? chk->m : mtop_rows;
             for (auto &w : wins) {
-                make_layout(*w.g, w.new_n, nt, kind, w.L, big);
+                make_layout(*w.g, w.new_n, nt, kind, w.L, big, 160 * 1024 - 64 - align_up(det_est, 16));
                 lmax = std::max(lmax, w.L.total); mmax = std::max(mmax, w.row0 + w.g->m);
                 big_stride = std::max<int64_t>(big_stride, align_up(w.L.big_scratch, 256));
             }
