@@ -9,8 +9,8 @@ if os.environ.get("SWD_LIB"): _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.
 from slidingwindowdecoder_amd import SlidingWindowDecoder
 from slidingwindowdecoder_amd.windows import sample_dem
 shots = 4096
-plan = bench.build_problem()
-dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=0))
+plan = bench.build_problem(N=288, W=4, F=1) if os.environ.get("SWD_CONFIG") == "288" else bench.build_problem()  # SWD_CONFIG=288: configs[3]
+dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=int(os.environ.get("SWD_ORDER", "0"))))
 ds = [torch.from_numpy(sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=s)[0]).cuda() for s in (1, 2)]
 for d in ds: dec.decode_device(d)
 torch.cuda.synchronize()

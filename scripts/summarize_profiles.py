@@ -28,6 +28,16 @@ stem = os.path.join(dst, f"{tag}_{wl}")
 os.makedirs(dst, exist_ok=True)
 
 
+def newest(pattern):
+    """files of the most recent run only: gpurun merges every call's output into the same local directory, and rocprofv3 names
+    its files by process id, so a re-profiled workload leaves the older run's files next to the new ones"""
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        return []
+    t = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if t - os.path.getmtime(f) < 600]
+
+
 def git_rev():
     try:
         rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
@@ -38,7 +48,7 @@ def git_rev():
 
 
 out = {"git": git_rev(), "workload": wl}
-for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest(os.path.join(src, "stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, stem + "_kernel_stats.csv")
     for row in csv.DictReader(open(f)):
         if KERNEL in row["Name"]:
@@ -50,7 +60,7 @@ for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recurs
 
 for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     vals, meta = [], {}
-    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, d, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == name:
                 vals.append(float(row["Counter_Value"]))
@@ -69,7 +79,7 @@ json.dump(out, open(stem + "_summary.json", "w"), indent=1)
 
 vals = {}
 for d in ("sq1", "sq2"):
-    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, d, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if KERNEL in row["Kernel_Name"]:
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))

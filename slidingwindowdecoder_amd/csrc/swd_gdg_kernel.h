@@ -197,13 +197,9 @@ __device__ __forceinline__ void block_argmin(double &key, int &pos, Lds &s) {
 
 // Compact the still-active selected VNs (position order) into s.lv and (re)build the per-phase
 // register caches.  Messages are untouched (they persist across decimation steps, bpgd.cpp:97-197).
-// BP register caches of the guessing decoders: packed (16-bit slot numbers, two per register) in the translation units that
-// set SWD_GDG_PACKED -- fewer live registers in kernels that spill 220 of them.
-#ifndef SWD_GDG_PACKED
-#define SWD_GDG_PACKED 0
-#endif
-template <int VF, int DM> using GdgVC = std::conditional_t<SWD_GDG_PACKED != 0, VnCacheP<VF, DM, 3, false>, VnCache<VF, DM>>;
-template <int KG> using GdgCC = std::conditional_t<SWD_GDG_PACKED != 0, CnCacheP<KG, 3>, CnCache<KG>>;
+// BP register caches of the guessing decoders: 16-bit slot numbers, two per register, classic parity words
+template <int VF, int DM> using GdgVC = VnCacheP<VF, DM, 3, false>;
+template <int KG> using GdgCC = CnCacheP<KG, 3>;
 
 template <int NT, int VF, int DM, int KG, class VC, class CC>
 __device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, VC &vc, CC &cn) {

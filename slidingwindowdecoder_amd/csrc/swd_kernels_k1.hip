@@ -1,6 +1,5 @@
 // Instantiations of swd::pipeline_kernel for kind 1 (guessing decoders, serial tree walk) and
 // their launchers (swd_plan.h); one translation unit per kind so that the kernels compile in parallel.
-#define SWD_GDG_PACKED 1 // packed BP register caches (swd_gdg_kernel.h)
 #include "swd_plan.h"
 #include "swd_variants.h"
 

@@ -1,7 +1,6 @@
 // Instantiations of swd::pipeline_kernel for kind 7 (bpgdg_decoder(multi_thread=True): the reference's threaded ensemble,
 // swd_gdg_kernel.h: gdg_ensemble_ref) and their launchers; its own translation unit so that the serial and the parallel
 // tree-walk kernels (kinds 1, 2) keep their register allocation.
-#define SWD_GDG_PACKED 1 // packed BP register caches (swd_gdg_kernel.h)
 #include "swd_plan.h"
 #include "swd_variants.h"
 

@@ -31,6 +31,9 @@
 #ifndef SWD_POST_RENUM
 #define SWD_POST_RENUM 0
 #endif
+#ifndef SWD_POST_DEPTH2
+#define SWD_POST_DEPTH2 0
+#endif
 
 struct SwdLdsLayout {
     int32_t off_livemask, off_par, off_lv, off_jptr, off_lslot, off_cnval, off_cndeg, off_cndeg0, off_vnval, off_hard,
@@ -282,14 +285,7 @@ __device__ __forceinline__ void wave_fence() {
 // unpacking inside the iteration loop -- hoisted out of it, the 32-bit copies would take the registers back.  With the
 // packed caches the <256, 7, 6, 9> kernel needs no spill at 248 VGPRs and one reload per BP loop at the 168 of three
 // waves per SIMD.
-template <int VF, int DM>
-struct VnCache {
-    double llr[VF];
-    uint32_t ed[VF][DM];
-    uint32_t par[VF][(DM + 1) / 2];
-};
-
-// The same cache with two offsets per register.  SH = 0: byte offsets (kernels of up to 256 threads, whose LDS offsets fit
+// Two offsets per register, unpacked where they are used.  SH = 0: byte offsets (kernels of up to 256 threads, whose LDS offsets fit
 // 16 bits, PB: one parity byte per check); SH = 3: slot numbers, shifted where they are used (the 1024-thread osd_window
 // kernels: fewer registers in their 128-VGPR budget, classic parity words).
 template <int VF, int DM, int SH = 0, bool PB = true>
@@ -313,37 +309,6 @@ struct VnCacheP {
 __device__ __forceinline__ int swd_slot_far(const SwdGraphDev &g) { return g.E + 1 + (int)(threadIdx.x >> 6); }
 template <int NT>
 __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E + 1 + NT / 64 + (int)(threadIdx.x >> 6); }
-
-template <int NT, int VF, int DM, bool FULL>
-__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCache<VF, DM> &c) {
-    const int n = g.n, cnt = FULL ? n : nlive;
-    const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
-#pragma unroll
-    for (int i = 0; i < VF; ++i) {
-        const int idx = s.vtid + i * NT;
-        c.llr[i] = 0.0;
-#pragma unroll
-        for (int k = 0; k < DM; ++k) c.ed[i][k] = dead;
-#pragma unroll
-        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
-        if (idx < cnt) {
-            const int v = FULL ? idx : (int)s.lv[idx];
-            const int deg = g.col_deg[v];
-            c.llr[i] = g.llr[v];
-#pragma unroll
-            for (int k = 0; k < DM; ++k) {
-                if (k < deg) {
-                    const uint32_t e = g.vn_edge[k * n + v];
-                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
-                        c.ed[i][k] = swd_edge_slot(e) << 3;
-                        c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
-                                                   : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
-                    }
-                }
-            }
-        }
-    }
-}
 
 // remap != nullptr (shortened graph, BIG kernels with the post-phase messages in LDS): the messages are renumbered one column of
 // cells per live variable node -- cell(k, i) = k * nlive + i for edge position k of the i-th live node, so that the threads of a
@@ -384,15 +349,6 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
 __device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
-template <int VF, int DM>
-__device__ __forceinline__ void bp_init(Lds &s, const VnCache<VF, DM> &c) {
-#pragma unroll
-    for (int i = 0; i < VF; ++i) {
-#pragma unroll
-        for (int k = 0; k < DM; ++k) swd_msg_at(s, c.ed[i][k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
-    }
-}
-
 template <int VF, int DM, int SH, bool PB>
 __device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM, SH, PB> &c) {
 #pragma unroll
@@ -413,18 +369,7 @@ __device__ __forceinline__ int wave_max(int x) {
 // Per-thread register cache of the check a lane owns during one BP phase: the LDS slots of its
 // edges (u16, two per register) in walk order; unused / dead positions hold the wave's far slot.
 // KG = groups of four positions.
-template <int KG>
-struct CnCache {
-    uint16_t sl[KG * 4];
-    int cnt;  // positions to walk (0 for lanes without a live check)
-    int live; // live edges among them
-    int l;    // the check (lane numbering of the graph) this thread serves, -1 for none
-    int sub;  // which of the check's grp threads this is (it walks positions sub, sub + grp, ...)
-    int grp;  // 1, 2 or 4 adjacent threads (lanes of one quad) share the check
-    __device__ __forceinline__ int slot(int k) const { return (int)sl[k]; }
-};
-
-// The same cache with offsets packed two per register (SH as in VnCacheP).
+// (offsets packed two per register, SH as in VnCacheP)
 template <int KG, int SH = 0>
 struct CnCacheP {
     uint32_t slp[KG * 2];
@@ -460,31 +405,7 @@ template <bool D = false> __device__ __forceinline__ void lm_set(Lds &s, int l, 
 }
 
 // grp = 1, 2 or 4 threads share a check (adjacent lanes of a quad): thread `sub` walks positions sub, sub + grp, ...
-template <int NT, int KG, bool FULL>
-__device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCache<KG> &cc) {
-    const int m = g.m, dummy = swd_slot_far(g);
-    const bool act = (lc >= 0) && (lc < m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
-    const int l = act ? lc : 0;
-    cc.l = act ? lc : -1;
-    cc.sub = sub;
-    cc.grp = grp;
-    // list mode walks the compacted live edges, otherwise all original positions (dead ones skipped)
-    const bool bylist = !FULL && uselist;
-    const int cnt = act ? ((FULL || bylist) ? (int)s.cn_deg[l] : (int)s.cn_deg0[l]) : 0;
-    const uint64_t lmask = (FULL || bylist || !act) ? ~0ull : s.livemask[l];
-    cc.cnt = (cnt > sub) ? (cnt - sub + grp - 1) / grp : 0;
-    cc.live = act ? (int)s.cn_deg[l] : 0;
-#pragma unroll
-    for (int kk = 0; kk < KG * 4; ++kk) {
-        const int k = kk * grp + sub;
-        int sv = dummy;
-        if (k < cnt && ((lmask >> (k & 63)) & 1ull))
-            sv = bylist ? (int)s.lslot[k * m + l] : (int)s.jptr[k] + l;
-        cc.sl[kk] = (uint16_t)sv;
-    }
-}
-
-// (the same for the tuned kernels: packed offsets, 48-bit live masks, original degrees from the graph)
+// (tuned kernels: 48-bit live masks, original degrees from the graph)
 template <int NT, int KG, bool FULL, int SH>
 __device__ __forceinline__ void cn_cache_load(const SwdGraphDev &g, Lds &s, bool uselist, int lc, int sub, int grp, CnCacheP<KG, SH> &cc) {
     constexpr bool DIET = SWD_P16(NT);
@@ -598,201 +519,8 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // max_iter iterations, and with max_iter a multiple of four slot order is chronological order of the last four
 // iterations: the sum is accumulated in registers (hs[i] for the i-th variable node of the thread) in exactly
 // that order and the 4 x n ring in HBM is neither written nor read.
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false>
-__device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
-                      const VnCache<VF, DM> &c, const CnCache<KG> &cn, double *hist_b, int &iters_done,
-                      double alpha, bool force_unsat = false, double *hs = nullptr) {
-    const int tid = threadIdx.x, m = g.m, n = g.n;
-    const int vcnt = FULL ? n : nlive;
-    const bool record_all = P.record_all != 0;
-    const int l = cn.l >= 0 ? cn.l : 0;      // NT >= m: at most one check per thread
-    const int cv = (cn.l >= 0) ? (int)s.cn_val[l] : -1;
-    const int cnt = cn.cnt;
-    const int wmax = wave_max(cnt);
-    const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
-    constexpr int K4 = KG * 4;
-    constexpr int NR = (K4 + 31) / 32;       // sign shift registers
-    iters_done = 0;
-    if (max_iter <= 0) return 0;
-    // VNs this wave walks (wave-uniform): entries vtid + i*NT < vcnt for some lane
-    const int wbase = s.vtid & ~63;
-    const int nch = __builtin_amdgcn_readfirstlane((vcnt > wbase) ? min(VF, (vcnt - wbase + NT - 1) / NT) : 0);
-#ifdef SWD_BPPROF
-    if (!FULL && (tid & 63) == 0) ((uint8_t *)&s.scal[28])[tid >> 6] = (uint8_t)wmax;
-#endif
-    s.msg[farslot] = 64.0;
-    s.msg[zeroslot] = 0.0;
-    char *const parb = (char *)s.par;
-#ifdef SWD_BPPROF
-    long long tc0, tc1, tc2, tc3;
-    long long acc_cn = 0, acc_any = 0, acc_vn = 0, acc_bar = 0;
-#define BPT(x) x = clock64()
-#else
-#define BPT(x)
-#endif
-    for (int it = 0; it < max_iter; ++it) {
-        bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
-        BPT(tc0);
-        {
-            if (cv >= 0 && cn.sub == 0) {
-                if (it > 0 && s.par[l] != 0u) unsat = true;
-                s.par[l] = (uint32_t)cv;
-            }
-            // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
-            // group of four are independent.  The two-minimum update
-            //   min2 = min(min2, max(min1, a)); min1 = min(min1, a)
-            // equals the reference's left/right running minima; |clip(x, -50, 50)| = min(|x|, 50).
-            // (A hand-made software pipeline over the groups was faster with the default machine scheduler and
-            // is slower with iterative-ilp, which overlaps the reads of the next group by itself.)
-            double min1 = 1e308, min2 = 1e308;
-            int argslot = farslot;
-            uint32_t neg[NR];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) neg[r] = 0;
-#pragma unroll
-            for (int gq = 0; gq < KG; ++gq) {
-                if (gq * 4 < wmax) { // wave-uniform
-                    double xs[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) xs[u] = s.msg[cn.slot(gq * 4 + u)];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = gq * 4 + u;
-                        const double ax = vminabs64(xs[u], 50.0);
-                        argslot = (ax < min1) ? cn.slot(k) : argslot;
-                        min2 = vmin64(min2, vmax64(min1, ax));
-                        min1 = vmin64(min1, ax);
-                        neg_shift_in(neg[k >> 5], xs[u]);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) neg[(gq * 4 + u) >> 5] <<= 1; // keep position k at bit (31 - k % 32) ...
-                }
-            }
-            // ... after this alignment of a partly filled last register
-            if (K4 & 31) neg[NR - 1] <<= (32 - (K4 & 31));
-            int npar = (cn.sub == 0) ? cv : 0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) npar += __popc(neg[r]);
-            if constexpr (!FULL || SF) {
-                // merge the partial results of the check's threads (butterfly inside the quad).  On a tie
-                // of the minima the second minimum equals the first, so which side's position is kept
-                // as "first minimum" does not change any value written below.
-                {
-                    const double o1 = quad_xor<1>(min1), o2 = quad_xor<1>(min2);
-                    const int oa = quad_xor<1>(argslot), op = quad_xor<1>(npar);
-                    if (cn.grp >= 2) {
-                        npar += op;
-                        argslot = (o1 < min1) ? oa : argslot;
-                        min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
-                        min1 = vmin64(min1, o1);
-                    }
-                }
-                {
-                    const double o1 = quad_xor<2>(min1), o2 = quad_xor<2>(min2);
-                    const int oa = quad_xor<2>(argslot), op = quad_xor<2>(npar);
-                    if (cn.grp == 4) {
-                        npar += op;
-                        argslot = (o1 < min1) ? oa : argslot;
-                        min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
-                        min1 = vmin64(min1, o1);
-                    }
-                }
-            }
-            const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
-            // the first position holding the minimum gets the second minimum (ties: both equal).
-            // Its own sign is re-read before the slots are overwritten.
-            const double xarg = s.msg[argslot];
-            if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
-            const double p1 = min1 * alpha, p2 = min2 * alpha;
-            const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
-#pragma unroll
-            for (int gq = 0; gq < KG; ++gq) {
-                if (gq * 4 < wmax) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = gq * 4 + u;
-                        const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
-                        const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
-                        s.msg[cn.slot(k)] = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
-                    }
-                }
-            }
-            {
-                const uint32_t sb = (((xarg <= 0) ? 0xFFFFFFFFu : 0u) ^ flip) & 0x80000000u;
-                const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
-                s.msg[argslot] = __longlong_as_double((long long)b2);
-                s.msg[farslot] = 64.0; // re-arm
-            }
-        }
-        BPT(tc1);
-        const bool any = block_any<NT>(unsat, s);
-        BPT(tc2);
-#ifdef SWD_BPPROF
-        acc_cn += tc1 - tc0; acc_any += tc2 - tc1;
-        if (it > 0 && !any && !FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
-#endif
-        if (it > 0 && !any) { iters_done = it; return 1; }
-
-        const int slot_h = it & 3;
-        const bool record = record_all || it >= max_iter - 4;
-        // VN pass (osd_window.pyx:442-471).  (Reading the next VN's messages before this one's are written
-        // was tried and is slower.)
-#pragma unroll
-        for (int i = 0; i < VF; ++i) {
-            if (i < nch) { // wave-uniform
-                const int idx = s.vtid + i * NT;
-                const bool valid = idx < vcnt;
-                const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
-                double cc[DM], pre[DM];
-#pragma unroll
-                for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, c.ed[i][k]);
-                double temp = c.llr[i];
-#pragma unroll
-                for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
-                if constexpr (ACC) {
-                    if (it >= max_iter - 4) hs[i] = (it == max_iter - 4) ? temp : hs[i] + temp; // wave-uniform conditions
-                } else {
-                    if (record && valid) hist_b[slot_h * n + v] = temp;
-                }
-                const bool hd = valid && (temp <= 0);
-                ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
-                double suf = 0.0;
-#pragma unroll
-                for (int k = DM - 1; k >= 0; --k) {
-                    swd_msg_at(s, c.ed[i][k]) = pre[k] + suf;
-                    suf = suf + cc[k];
-                }
-                s.msg[zeroslot] = 0.0; // re-arm
-                if (hd) {
-#pragma unroll
-                    for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
-                        uint32_t pw = c.par[i][k2];
-                        asm volatile("" : "+v"(pw));
-                        atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u);
-                        if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
-                    }
-                }
-            }
-        }
-        BPT(tc3);
-        __syncthreads();
-#ifdef SWD_BPPROF
-        acc_vn += tc3 - tc2; acc_bar += clock64() - tc3;
-#endif
-    }
-#ifdef SWD_BPPROF
-    if (!FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
-#endif
-    bool unsat = force_unsat;
-    for (int l = tid; l < m; l += NT)
-        if (s.cn_val[l] >= 0 && s.par[l] != 0u) unsat = true;
-    const bool any = block_any<NT>(unsat, s);
-    iters_done = max_iter;
-    return any ? 0 : 1;
-}
-
-// bp_run for the tuned osd_window kernels: packed register caches (offsets unpacked where they are used), one parity byte per check
+// One routine for every kernel: the register caches keep LDS offsets packed two per register (unpacked where they are used);
+// PB: one parity byte per check, flipped by word atomics (tuned kernels of up to 256 threads), else one parity word.
 template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
@@ -2079,14 +1807,13 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
     // the tuned kernels use the packed caches and their overloads of the BP routines: byte offsets + parity bytes up to 256
     // threads, slot numbers + parity words in the 1024-thread kernels
-    constexpr bool PK = SWD_OSDW_TUNED && NT >= 1024 && DM % 2 == 0;
-    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, std::conditional_t<PK, VnCacheP<VF, DM, 3, false>, VnCache<VF, DM>>> vc;
+    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, VnCacheP<VF, DM, 3, false>> vc;
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
     // the check state and jptr written above are read below by OTHER threads (a check is served by the thread
     // whose ctid equals its lane number, which need not be the thread that initialised it)
     __syncthreads();
     bp_init<VF, DM>(s, vc);
-    std::conditional_t<SWD_P16(NT), CnCacheP<KG>, std::conditional_t<PK, CnCacheP<KG, 3>, CnCache<KG>>> cn;
+    std::conditional_t<SWD_P16(NT), CnCacheP<KG>, CnCacheP<KG, 3>> cn;
     if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)
         const uint32_t e = cn_map[s.ctid];
         cn_cache_load<NT, KG, true>(g, s, false, (e & 0xFFFFu) == 0xFFFFu ? -1 : (int)(e & 0xFFFFu), (int)((e >> 16) & 3u), (int)(e >> 18), cn);
@@ -2299,8 +2026,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // the variable-node pass of the shortened graph then touches consecutive cells instead of scattered slots)
     SwdGraphDev gp = g;
     bool renum = false;
-    constexpr bool kPackedVc = !std::is_same_v<decltype(vc), VnCache<VF, DM>>;
-    constexpr bool kRenum = (BIG || (SWD_POST_RENUM && SWD_P16(NT))) && kPackedVc;
+    constexpr bool kRenum = BIG || (SWD_POST_RENUM && SWD_P16(NT));
     if constexpr (kRenum) renum = L.post_lds != 0 && uselist;
     // the post phase proper, for a register cache of any depth: caches, (re)initialised messages, the iterations
     // (renum_tag: compile-time twin of `renum`, so that a BIG kernel's post-phase message pointer is an LDS pointer on every path
@@ -2333,7 +2059,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // normally <= 2 m <= 2 NT: a register cache of depth 2 keeps the iteration loop free of spills (128 VGPRs per thread)
     // (the host sets post_lds only for new_n <= 2 NT, so the renumbered form always runs at depth 2)
     bool post_done = false;
-    if constexpr (BIG && kPackedVc && VF > 2) {
+    if constexpr (BIG && VF > 2) {
         if (renum && g.new_n <= 2 * NT) {
             VnCacheP<2, DM, 3, false> vc2;
             double hs2[2] = {0.0, 0.0};
@@ -2343,6 +2069,16 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         }
     } else if constexpr (kRenum) {
         if (renum) { R.conv = run_post(vc, hs, std::integral_constant<int, VF>{}, std::true_type{}); post_done = true; }
+    } else if constexpr ((SWD_POST_DEPTH2 & (NT >= 1024 ? 1 : 2)) != 0 && VF > 2) {
+        // the depth-2 cache in the LDS-resident kernels too: bit 0 = the 1024-thread ones (on in the production build: [[288]] (4,1)
+        // 61.9 -> 60.5 ms per launch), bit 1 = those of up to 256 threads (experiment: no gain for the headline kernel)
+        if (g.new_n <= 2 * NT) {
+            std::conditional_t<SWD_P16(NT), VnCacheP<2, DM>, VnCacheP<2, DM, 3, false>> vc2;
+            double hs2[2] = {0.0, 0.0};
+            R.conv = run_post(vc2, hs2, std::integral_constant<int, 2>{}, std::false_type{});
+            hs[0] = hs2[0]; hs[1] = hs2[1];
+            post_done = true;
+        }
     }
     if (!post_done) R.conv = run_post(vc, hs, std::integral_constant<int, VF>{}, std::false_type{});
 #ifdef SWD_SHPROF
