@@ -598,7 +598,9 @@ __device__ __forceinline__ void gdg_sched(const SwdGdgPar &gp, const SwdDecodePa
 // One side branch (a saved snapshot) of a parked tree, run by whichever workgroup popped the item.  Uses the
 // workgroup's LDS from scratch and its own history scratch; reads the tree's context / snapshot, writes the branch
 // record back and runs the tree's scheduler.
-template <int NT, int VF, int DM, int KG>
+// VFP: depth of the register cache for the shortened graph (2 when every window keeps new_n <= 2 NT columns -- the plan decides,
+// Plan::post_depth2 -- else VF): the BP blocks of the post-processing only ever see the live nodes among the first new_n.
+template <int NT, int VF, int DM, int KG, int VFP = VF>
 __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, uint32_t payload, int ctid, int vtid) {
     const int tid = threadIdx.x;
     const SwdGdgPar &gp = a.gdgp;
@@ -665,15 +667,15 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
         __syncthreads();
         start_failed = s.scal[1] != 0;
         if (!start_failed) {
-            GdgVC<VF, DM> vc;
+            GdgVC<VFP, DM> vc;
             GdgCC<KG> cn;
             const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
             for (int j = 0; j < maxj; ++j) {
                 const int depth = alt + j;
-                const int nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
-                if (j == 0) { bp_init<VF, DM>(s, vc); __syncthreads(); }
+                const int nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vc, cn);
+                if (j == 0) { bp_init<VFP, DM>(s, vc); __syncthreads(); }
                 int it;
-                const int cv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+                const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
                 uint32_t sw = (uint32_t)it & 0xFFu;
                 nsteps = j + 1;
                 if (cv) {
@@ -767,7 +769,7 @@ __device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDeco
 template <int NT, int VF, int DM, int KG>
 __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                                  double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
-                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn) {
+                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn) { // (VF here = the caller's post-phase depth)
     const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
     const int Dp = P.max_tree_depth, S = P.max_side_depth;
     const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
@@ -891,7 +893,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
 // then R.exit_class = -2 on return and the result arrives later as a FINAL item (gdg_finalize).
 // ENS (kernel kind 7): bpgdg_decoder(multi_thread=True) -- the post-processing is the reference's threaded ensemble
 // (gdg_ensemble_ref) instead of gdg()'s tree walk.
-template <int NT, int VF, int DM, int KG, bool ENS = false>
+template <int NT, int VF, int DM, int KG, bool ENS = false, int VFP = VF>
 __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                                   const uint8_t *synd, double *hist_b, uint8_t *snap_b, WinResult &R,
                                                   const SwdPipeArgs *par = nullptr, uint32_t *acc = nullptr, int wi = 0, int b = 0) {
@@ -988,13 +990,14 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         R.exit_class = SWD_EXIT_FAIL_PEEL;
         return;
     }
-    int nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
-    bp_init<VF, DM>(s, vc);
+    GdgVC<VFP, DM> vcp; // the shortened graph's cache (the full graph's is dead from here on)
+    int nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+    bp_init<VFP, DM>(s, vcp);
     __syncthreads();
     if constexpr (ENS) {
         for (int j = tid; j < 64; j += NT) G.alt_depth[j] = -1;
         __syncthreads();
-        gdg_ensemble_ref<NT, VF, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vc, cn);
+        gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn);
         for (int v = tid; v < n; v += NT) s.hard[v] = 0;
         __syncthreads();
         for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
@@ -1028,8 +1031,8 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     }
     // ---- phase 1: main branch
     for (int depth = 0; depth < P.max_step; ++depth) {
-        if (depth > 0) nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
-        const int cv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        if (depth > 0) nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+        const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
         ++blocks; R.post_it += it;
         if (cv) {
             converge = 1; min_converge_depth = depth;
@@ -1104,9 +1107,9 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         if (s.scal[1]) continue;
         for (int j = 0; j < P.max_side_branch_step; ++j) {
             depth = G.alt_depth[i] + j;
-            nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
-            if (j == 0) { bp_init<VF, DM>(s, vc); __syncthreads(); } // set_masks re-initialises the messages
-            const int cv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+            nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+            if (j == 0) { bp_init<VFP, DM>(s, vcp); __syncthreads(); } // set_masks re-initialises the messages
+            const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
             ++blocks; R.post_it += it;
             if (cv) {
                 converge = 1;

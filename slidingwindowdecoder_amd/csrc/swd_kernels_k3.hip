@@ -1,7 +1,7 @@
 // Instantiations of swd::pipeline_kernel for kind 3 (osd_window windows, posterior history accumulated in registers) and
 // their launchers (swd_plan.h); one translation unit per kind so that the kernels compile in parallel.
 #ifndef SWD_POST_DEPTH2
-#define SWD_POST_DEPTH2 1 // depth-2 register cache for the shortened graph in the 1024-thread kernels (swd_osdw_kernel.h)
+#define SWD_POST_DEPTH2 3 // depth-2 register cache for the shortened graph (swd_osdw_kernel.h): bit 0 the 1024-thread kernels, bit 1 those of up to 256 threads
 #endif
 #define SWD_OSDW_TUNED 1 // packed register caches, three waves per SIMD where they fit (swd_osdw_kernel.h)
 #include "swd_plan.h"

@@ -8,7 +8,7 @@ namespace swd {
 #define SWD_IF_0(...)
 #define SWD_IF_1(...) __VA_ARGS__
 #define SWD_IF(c, ...) SWD_IF_##c(__VA_ARGS__)
-#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_IF(k1, SWD_DEFINE_LAUNCHER(7, nt, vf, dm, kg, sf))
+#define X(nt, vf, dm, kg, sf, k1, k2, k3) SWD_IF(k1, SWD_DEFINE_GDG_LAUNCHER(7, nt, vf, dm, kg, sf))
 SWD_VARIANTS(X)
 #undef X
 } // namespace swd

@@ -34,6 +34,9 @@
 #ifndef SWD_POST_DEPTH2
 #define SWD_POST_DEPTH2 0
 #endif
+#ifndef SWD_POST_KGP // groups of four check positions in the shortened graph's register cache (0: as many as for the full graph)
+#define SWD_POST_KGP 0
+#endif
 
 struct SwdLdsLayout {
     int32_t off_livemask, off_par, off_lv, off_jptr, off_lslot, off_cnval, off_cndeg, off_cndeg0, off_vnval, off_hard,
@@ -2031,8 +2034,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // the post phase proper, for a register cache of any depth: caches, (re)initialised messages, the iterations
     // (renum_tag: compile-time twin of `renum`, so that a BIG kernel's post-phase message pointer is an LDS pointer on every path
     // that reaches the iterations -- ds_read / ds_write instead of flat accesses)
-    auto run_post = [&](auto &vcx, double *hsx, auto vfx, auto renum_tag) {
-        constexpr int VFX = decltype(vfx)::value;
+    auto run_post = [&](auto &vcx, auto &cnx, double *hsx, auto vfx, auto kgx, auto renum_tag) {
+        constexpr int VFX = decltype(vfx)::value, KGX = decltype(kgx)::value;
         if constexpr (kRenum && decltype(renum_tag)::value) {
             {
                 uint16_t *remap = rc;
@@ -2048,39 +2051,45 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
                 __syncthreads();
             }
         } else vn_cache_load<NT, VFX, DM, false>(gp, s, nlive, vcx);
-        cn_cache_load<NT, KG, false>(gp, s, uselist, clc, csub, cgrp, cn);
+        cn_cache_load<NT, KGX, false>(gp, s, uselist, clc, csub, cgrp, cnx);
         __syncthreads(); // every lane has read its slot list before the messages are re-initialised
         bp_init<VFX, DM>(s, vcx);
         __syncthreads();
         R.t[4] = wall_clock64();
-        return bp_run<NT, VFX, DM, KG, false, false, HACC>(gp, P, s, P.post_iter, nlive, vcx, cn, hist_b, it, P.alpha, false, hsx);
+        return bp_run<NT, VFX, DM, KGX, false, false, HACC>(gp, P, s, P.post_iter, nlive, vcx, cnx, hist_b, it, P.alpha, false, hsx);
     };
-    // BIG kernels keep VF = 9 variable nodes per thread for the full graph; the shortened graph has at most new_n live ones,
-    // normally <= 2 m <= 2 NT: a register cache of depth 2 keeps the iteration loop free of spills (128 VGPRs per thread)
-    // (the host sets post_lds only for new_n <= 2 NT, so the renumbered form always runs at depth 2)
+    // The shortened graph needs less of both register caches than the full graph: at most new_n (normally <= 2 NT) live nodes,
+    // and -- heavy checks being shared by up to four threads -- at most T positions per thread, T = what cn_assign just chose
+    // (s.iaux[0]).  With depth 2 / KGP groups of four positions the iteration loop keeps 16 + 2 KGP registers of cache instead of
+    // 8 VF + 2 KG, its check pass is unrolled KGP times instead of KG times, and no reload sits in it.
+    constexpr int KGP = (SWD_POST_KGP > 0 && SWD_POST_KGP < KG) ? SWD_POST_KGP : KG;
+    const bool small_ok = g.new_n <= 2 * NT && (KGP == KG || s.iaux[0] <= 4 * KGP);
+    using VC2 = std::conditional_t<SWD_P16(NT), VnCacheP<2, DM>, VnCacheP<2, DM, 3, false>>;
+    using CC2 = std::conditional_t<SWD_P16(NT), CnCacheP<KGP>, CnCacheP<KGP, 3>>;
+    // (BIG kernels: the host sets post_lds only for new_n <= 2 NT, so the renumbered form always runs at depth 2)
     bool post_done = false;
     if constexpr (BIG && VF > 2) {
-        if (renum && g.new_n <= 2 * NT) {
-            VnCacheP<2, DM, 3, false> vc2;
+        if (renum && small_ok) {
+            VC2 vc2; CC2 cn2;
             double hs2[2] = {0.0, 0.0};
-            R.conv = run_post(vc2, hs2, std::integral_constant<int, 2>{}, std::true_type{});
+            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::true_type{});
             hs[0] = hs2[0]; hs[1] = hs2[1];
             post_done = true;
         }
     } else if constexpr (kRenum) {
-        if (renum) { R.conv = run_post(vc, hs, std::integral_constant<int, VF>{}, std::true_type{}); post_done = true; }
+        if (renum) { R.conv = run_post(vc, cn, hs, std::integral_constant<int, VF>{}, std::integral_constant<int, KG>{}, std::true_type{}); post_done = true; }
     } else if constexpr ((SWD_POST_DEPTH2 & (NT >= 1024 ? 1 : 2)) != 0 && VF > 2) {
-        // the depth-2 cache in the LDS-resident kernels too: bit 0 = the 1024-thread ones (on in the production build: [[288]] (4,1)
-        // 61.9 -> 60.5 ms per launch), bit 1 = those of up to 256 threads (experiment: no gain for the headline kernel)
-        if (g.new_n <= 2 * NT) {
-            std::conditional_t<SWD_P16(NT), VnCacheP<2, DM>, VnCacheP<2, DM, 3, false>> vc2;
+        // the LDS-resident kernels: bit 0 = the 1024-thread ones ([[288]] (4,1): 61.9 -> 60.5 ms per launch), bit 1 = those of up to
+        // 256 threads (headline, order 0: 10.25 -> 9.7 ms per launch); both on in the production build
+        if (small_ok) {
+            VC2 vc2; CC2 cn2;
             double hs2[2] = {0.0, 0.0};
-            R.conv = run_post(vc2, hs2, std::integral_constant<int, 2>{}, std::false_type{});
+            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::false_type{});
             hs[0] = hs2[0]; hs[1] = hs2[1];
             post_done = true;
         }
     }
-    if (!post_done) R.conv = run_post(vc, hs, std::integral_constant<int, VF>{}, std::false_type{});
+    if (!post_done) R.conv = run_post(vc, cn, hs, std::integral_constant<int, VF>{}, std::integral_constant<int, KG>{}, std::false_type{});
 #ifdef SWD_SHPROF
     if (tid == 0) { s.scal[20] = (int)(sh0 - R.t[3]); s.scal[21] = (int)(sh1 - sh0); s.scal[22] = (int)(sh2 - sh1); s.scal[23] = (int)(R.t[4] - sh2); }
 #endif
@@ -2205,7 +2214,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 // and commits nothing for it: the caller sees the fault (swd_pipeline_status) instead of a plausible wrong answer.
 // BIG (large graphs, osd_window only): the scratch region of the window's layout -- fp64 messages, sort keys, OSD arrays --
 // is the workgroup's region of a.big in HBM (served by L2 / the memory-side cache); LDS keeps the per-check and per-node state.
-template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false>
+// VFP (guessing decoders): depth of the register cache for the shortened graph, 2 or VF (swd_gdg_kernel.h)
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false, int VFP = VF>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2))) pipeline_kernel(const SwdPipeArgs a) {
     static_assert(!BIG || KIND == 0 || KIND == 3, "the HBM-resident scratch region exists for the osd_window kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2265,7 +2275,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         if (item == SWD_ITEM_EXIT) break;
         const uint32_t type = item >> 30;
         if (type == SWD_ITEM_SIDE) {
-            if constexpr (KIND == 2) gdg_run_task<NT, VF, DM, KG>(a, smem, item, s.ctid, s.vtid);
+            if constexpr (KIND == 2) gdg_run_task<NT, VF, DM, KG, VFP>(a, smem, item, s.ctid, s.vtid);
             continue;
         }
         if (type == SWD_ITEM_FINAL) {
@@ -2390,7 +2400,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 asm volatile("" ::: "memory"); dbg_tc = wall_clock64(); asm volatile("" ::: "memory");
 #endif
                 s.fpar = 0;
-                decode_window_gdg<NT, VF, DM, KG, KIND == 7>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
+                decode_window_gdg<NT, VF, DM, KG, KIND == 7, VFP>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, snap_b, R, (queued && !redo) ? &a : nullptr, acc, wi, b);
 #ifdef SWD_GDG_DEBUG
                 if (tid == 0 && queued) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(R.exit_class == -2 ? 9 : 10, 1); GDG_COUNT(R.exit_class == -2 ? 11 : 12, wall_clock64() - t_unit0); }
 #endif

@@ -58,6 +58,7 @@ struct Plan {
     int device = 0, nt = 256, vf = 7, dm = 8;
     const Variant *variant = nullptr;
     int num_det = 0, num_col = 0, nmax = 0, off_det = 0, lds_total = 0;
+    bool post_depth2 = false;  // guessing decoders: every window keeps new_n <= 2 nt columns -> depth-2 cache for the shortened graph
     bool big = false;          // large graphs: the layouts' scratch region lives in HBM (big_stride bytes per workgroup)
     int64_t big_stride = 0;
     DevBuf d_wins, d_chk, d_obs, d_cnmap;
@@ -197,6 +198,8 @@ struct Plan {
             break;
         }
         if (!variant) return -1;
+        post_depth2 = kind != 0 && !getenv("SWD_GDG_NO_DEPTH2");
+        for (auto &w : wins) post_depth2 = post_depth2 && w.new_n <= 2 * nt;
         if (status.reserve(64)) return -1; // word 0: fault flags; words 1..15: counters of diagnostic builds
         SWD_HIP(hipMemset(status.p, 0, 64));
         std::vector<SwdWindowDev> hw(wins.size());
@@ -245,14 +248,14 @@ struct Plan {
 
 
 
-template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false>
+template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false, int VFP = VF>
 int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     SwdPipeArgs a = a0;
     static std::mutex fn_mu; // the attribute and the occupancy answer belong to the function, not to a decoder
     std::lock_guard<std::mutex> fn_lock(fn_mu);
     static int lds_limit[64] = {0}; // per device, monotone
     if (d->lds_total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
+        SWD_HIP(hipFuncSetAttribute((const void *)pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG, VFP>, hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_total));
         lds_limit[d->device & 63] = d->lds_total;
     }
     // persistent grid: as many workgroups as fit the device at once (they draw work units until none is left)
@@ -260,7 +263,7 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     static int slots_lds[64] = {0};
     if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->lds_total) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG>, NT, (size_t)d->lds_total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG, VFP>, NT, (size_t)d->lds_total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         // the occupancy API accepts 54 592 B of LDS for three workgroups per CU; the hardware placed a third one up to 53 552 B
         // and not at 54 032 B (scripts/residency_check.py): count LDS in granules of 1280 B
@@ -333,7 +336,7 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         if (d->cur->snap.reserve(nscr * d->snap_stride + 8)) return -1;
         a.snap = d->cur->snap.as<uint8_t>(); a.snap_stride = d->snap_stride;
     }
-    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG>), dim3(grid), dim3(NT), d->lds_total, st, a);
+    hipLaunchKernelGGL((pipeline_kernel<NT, VF, DM, KG, KIND, SF, BIG, VFP>), dim3(grid), dim3(NT), d->lds_total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }
@@ -346,5 +349,12 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, 0)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, (kind) == 6 ? 3 : 0, false, true>(d, a, st); }
 #define SWD_DEFINE_LAUNCHER(kind, nt, vf, dm, kg, sf) \
     int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, kind, (sf) != 0>(d, a, st); }
+// guessing decoders: a second instantiation with a depth-2 register cache for the shortened graph, taken when every window of the
+// plan keeps new_n <= 2 nt columns (Plan::post_depth2)
+#define SWD_DEFINE_GDG_LAUNCHER(kind, nt, vf, dm, kg, sf)                                                                  \
+    int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *d, const SwdPipeArgs &a, hipStream_t st) {                        \
+        if constexpr ((vf) > 2) { if (d->post_depth2) return launch_nt<nt, vf, dm, kg, kind, (sf) != 0, false, 2>(d, a, st); } \
+        return launch_nt<nt, vf, dm, kg, kind, (sf) != 0>(d, a, st);                                                       \
+    }
 
 } // namespace swd

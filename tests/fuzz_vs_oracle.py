@@ -15,7 +15,7 @@ from slidingwindowdecoder_amd import osd_window  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 mlo, mhi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (6, 120)
-mode = sys.argv[5] if len(sys.argv) > 5 else "osdw"  # osdw | gdg | gd | bp
+mode = sys.argv[5] if len(sys.argv) > 5 else "osdw"  # osdw | gdg | gd | bp | ens (bpgdg_decoder(multi_thread=True), the threaded ensemble)
 nlo, nhi = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (0, 2000)  # column range (default: m + 4 .. min(6 m, 2000))
 bad = 0
 ran, threads_seen, osd_shots = 0, set(), 0
@@ -46,9 +46,13 @@ for t in range(trials):
                    max_iter_per_step=int(rng.integers(2, 8)), max_step=int(rng.integers(3, 20)), max_tree_depth=int(rng.integers(1, 4)),
                    max_side_depth=int(rng.integers(4, 10)), max_tree_branch_step=10, max_side_branch_step=int(rng.integers(3, 10)),
                    new_n=kw["new_n"], low_error_mode=bool(rng.integers(2)))
-        dc, oc = {"gdg": (bpgdg_decoder, O.bpgdg_decoder), "gd": (bpgd_decoder, O.bpgd_decoder), "bp": (bp_history_decoder, O.bp_history_decoder)}[mode]
-        if mode != "gdg":
+        dc, oc = {"gdg": (bpgdg_decoder, O.bpgdg_decoder), "gd": (bpgd_decoder, O.bpgd_decoder), "bp": (bp_history_decoder, O.bp_history_decoder),
+                  "ens": (bpgdg_decoder, O.bpgdg_decoder)}[mode]
+        if mode not in ("gdg", "ens"):
             okw.pop("low_error_mode")
+        if mode == "ens":  # the reference's threaded ensemble: tree depth 0..4, a few side threads, short tree / side walks
+            okw.update(multi_thread=True, max_tree_depth=int(rng.integers(0, 5)), max_tree_branch_step=int(rng.integers(1, 8)))
+            okw["max_side_depth"] = okw["max_tree_depth"] + int(rng.integers(0, 6))
         dev, ora = dc(H, **okw), oc(H, **okw)
         B = 48
         e = (rng.random((B, n)) < p * rng.uniform(0.5, 3.0)).astype(np.uint8)
@@ -69,7 +73,7 @@ for t in range(trials):
     except ValueError:
         continue
     dev = osd_window(H, **kw)
-    B = 256
+    B = 256 if m * n < 2_000_000 else 16  # (the oracle needs ~0.4 s per decode on the matrices of the large-graph kernels)
     e = (rng.random((B, n)) < p * rng.uniform(0.5, 3.0)).astype(np.uint8)
     synd = (e @ H.T) % 2
     synd[B // 2:] = (rng.random((B - B // 2, m)) < 0.3).astype(np.uint8)  # inconsistent half
