@@ -18,10 +18,13 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     int osd_bytes = align_up(L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16, 16);
     const int osd_bytes_at_aux = osd_bytes; // end of the arrays that start at off_aux (the higher-order sweep's may follow)
     // higher-order OSD arrays: over the dead sort keys when they fit there, else after the OSD-0 arrays
-    L.cs_par = std::min(nt, 256);
+    // candidates evaluated concurrently: as many threads as still let the sweep's arrays lie over the dead sort keys (at least 256):
+    // [[288]] (4,1) windows, OSD-CS 10: 621 candidates in one round of 640 threads instead of three rounds of 256
     const int kset = std::max(new_n - g.rank, 0);
-    const int cs_bytes = align_up(n * 2 + kset * 2 + g.rank * 4 + 64 + 8, 8) + g.rank * 8 +
-                         std::max(wm * L.cs_par, 64 + wm) * 8;
+    auto cs_need = [&](int cp) { return align_up(n * 2 + kset * 2 + g.rank * 4 + 64 + 8, 8) + g.rank * 8 + std::max(wm * cp, 64 + wm) * 8; };
+    L.cs_par = nt;
+    while (L.cs_par > std::min(nt, 256) && cs_need(L.cs_par) > npad * 8) L.cs_par -= 64;
+    const int cs_bytes = cs_need(L.cs_par);
     if (cs_bytes <= npad * 8) L.off_cs = 0;
     else { L.off_cs = osd_bytes; osd_bytes += align_up(cs_bytes, 16); }
     const int rare_bytes = L.off_aux + std::max(n * 2, 3 * 256 * 4); // failed-decimation positions / select histograms

@@ -45,7 +45,7 @@ struct SwdLdsLayout {
     int32_t off_idx;   // inside scratch: u16 idx[npad] after u64 key[npad]
     int32_t off_aux;   // inside scratch: first byte after the sort arrays
     int32_t off_cs;    // inside scratch: arrays of the higher-order OSD sweep
-    int32_t cs_par;    // threads that evaluate OSD candidates concurrently (<= 256)
+    int32_t cs_par;    // threads that evaluate OSD candidates concurrently (a multiple of 64, <= threads per shot)
     int32_t off_gdg;   // guessing decoders: persistent per-shot arrays (outside scratch), -1 if unused
     int32_t off_cord;  // inside scratch: degree histogram + check order of the post phase (clear of lslot and the keys' tail)
     int32_t off_rc;    // inside scratch: u16 row_col[E] staged for the shortening step
@@ -1572,53 +1572,69 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
     for (long base = 0; base < ncand; base += CP) {
         const long l = base + tid;
         if (tid < CP && l < ncand) {
-            int c1 = INF, c2 = INF;
+            double pm = 0.0;
             if (!exhaustive) {
+                // osd_cs: one or two extra columns.  Their row lists and priors are fetched once (not per word of y), the ordered
+                // sum runs in three stretches of the pivots (sorted by column) with the candidate's columns added in between.
+                int c1, c2 = INF;
                 if (l < kset) c1 = Ht[l];
                 else {
                     int rem = (int)(l - kset), i = 0;
                     while (rem >= order - 1 - i) { rem -= order - 1 - i; ++i; }
                     c1 = Ht[i]; c2 = Ht[i + 1 + rem];
                 }
-            }
-            for (int w = 0; w < wm; ++w) {
-                uint64_t yw = y0[w];
-                if (!exhaustive) {
-                    const int d1 = g.col_deg[c1];
-                    for (int k = 0; k < d1; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c1], w, g.m)];
-                    if (c2 != INF) {
-                        const int d2 = g.col_deg[c2];
-                        for (int k = 0; k < d2; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c2], w, g.m)];
+                const int d1 = g.col_deg[c1], d2 = (c2 != INF) ? (int)g.col_deg[c2] : 0;
+                int rw[2 * SWD_DMAX];
+#pragma unroll
+                for (int k = 0; k < SWD_DMAX; ++k) {
+                    rw[k] = (k < d1) ? (int)g.vn_row[k * n + c1] : -1;
+                    rw[SWD_DMAX + k] = (k < d2) ? (int)g.vn_row[k * n + c2] : -1;
+                }
+                const int cA = min(c1, c2), cB = max(c1, c2); // cB = INF for a single column
+                const double llrA = g.llr[cA], llrB = (cB != INF) ? g.llr[cB] : 0.0;
+                for (int w = 0; w < wm; ++w) {
+                    uint64_t yw = y0[w];
+#pragma unroll
+                    for (int k = 0; k < 2 * SWD_DMAX; ++k)
+                        if (rw[k] >= 0) yw ^= Tc[osd_tidx(rw[k], w, g.m)];
+                    ybuf[w * CP + tid] = yw;
+                }
+                // number of pivot columns below cA / cB (pcs ascending)
+                int posA = 0, posB = npiv;
+                { int lo = 0, hi = npiv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)pcs[mid] < cA) lo = mid + 1; else hi = mid; } posA = lo; }
+                if (cB != INF) { int lo = posA, hi = npiv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)pcs[mid] < cB) lo = mid + 1; else hi = mid; } posB = lo; }
+                auto stretch = [&](int i0, int i1) {
+                    for (int i = i0; i < i1; ++i) {
+                        const int r = prs[i];
+                        const bool on = (ybuf[(r >> 6) * CP + tid] >> (r & 63)) & 1ull;
+                        pm += on ? pllr[i] : 0.0; // x + 0.0 == x: the sum is the reference's, term by term
                     }
-                } else {
+                };
+                stretch(0, posA);
+                pm += llrA;
+                stretch(posA, posB);
+                if (cB != INF) pm += llrB;
+                stretch(posB, npiv);
+            } else {
+                for (int w = 0; w < wm; ++w) {
+                    uint64_t yw = y0[w];
                     for (int i = 0; i < order; ++i)
                         if ((l >> i) & 1) {
                             const int c = Ht[i], dc = g.col_deg[c];
                             for (int k = 0; k < dc; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c], w, g.m)];
                         }
+                    ybuf[w * CP + tid] = yw;
                 }
-                ybuf[w * CP + tid] = yw;
-            }
-            double pm = 0.0;
-            int cA = min(c1, c2), cB = max(c1, c2), q = 0;
-            for (int i = 0; i < npiv; ++i) {
-                const int pc = pcs[i];
-                if (!exhaustive) {
-                    if (cA < pc) { pm += g.llr[cA]; cA = cB; cB = INF; }
-                    if (cA < pc) { pm += g.llr[cA]; cA = cB; cB = INF; }
-                } else {
+                int q = 0;
+                for (int i = 0; i < npiv; ++i) {
+                    const int pc = pcs[i];
                     while (q < order && (int)hts_col[q] < pc) {
                         if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
                         ++q;
                     }
+                    const int r = prs[i];
+                    if ((ybuf[(r >> 6) * CP + tid] >> (r & 63)) & 1ull) pm += pllr[i];
                 }
-                const int r = prs[i];
-                if ((ybuf[(r >> 6) * CP + tid] >> (r & 63)) & 1ull) pm += pllr[i];
-            }
-            if (!exhaustive) {
-                if (cA != INF) { pm += g.llr[cA]; cA = cB; }
-                if (cA != INF) pm += g.llr[cA];
-            } else {
                 while (q < order) {
                     if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
                     ++q;
