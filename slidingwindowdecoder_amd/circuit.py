@@ -6,16 +6,16 @@ Stim for its detector error model and turns that into (chk, obs, priors)
 boxes, so this module derives the same model directly:
 
 * ``bb_memory_ops`` restates the gate / noise / measurement schedule of the reference
-  circuit as a flat op list (z-basis memory experiment, ``use_both=False``, ``HZH=False``
-  -- the variant every BASELINE config uses).
+  circuit as a flat op list (``use_both=False``, ``HZH=False``; ``z_basis=True`` -- the variant
+  every BASELINE config uses -- or ``z_basis=False``, build_circuit.py:147-152, 167-172, 204-221).
 * ``dem_from_ops`` sweeps that list BACKWARDS keeping, per qubit, the set of detectors
-  and observables an X flip at that point of time would toggle ("sensitivity"), which is
-  all that matters for Z-basis detectors: CX c,t -> sens[c] ^= sens[t]; MR -> sens = this
-  measurement's detectors; M -> sens ^= ...; R / MRX / H -> sens = 0.  Every noise channel
-  then contributes independent fault mechanisms with Stim's per-component probabilities
-  (DEPOLARIZE1: (1-sqrt(1-4p/3))/2 for each of X,Y,Z; DEPOLARIZE2: (1-(1-16p/15)^(1/8))/2
-  for each of the 15 Paulis) and mechanisms with identical symptoms are merged with
-  p <- p(1-q) + q(1-p).
+  and observables an X flip and a Z flip at that point of time would toggle (two
+  "sensitivities"): CX c,t -> sx[c] ^= sx[t], sz[t] ^= sz[c]; H swaps them; MR -> sx = this
+  measurement's detectors, sz = 0; M -> sx ^= ...; MRX / MX the same with the roles swapped;
+  R / RX -> both 0.  Every noise channel then contributes independent fault mechanisms with
+  Stim's per-component probabilities (DEPOLARIZE1: (1-sqrt(1-4p/3))/2 for each of X,Y,Z;
+  DEPOLARIZE2: (1-(1-16p/15)^(1/8))/2 for each of the 15 Paulis; a Y flips what X and Z flip)
+  and mechanisms with identical symptoms are merged with p <- p(1-q) + q(1-p).
 
 Host-side, runs once per experiment.  The structural known answers of the reference's
 notebooks (shape 936 x 8784 for 12 rounds of the [[144,12,12]] code, column-weight
@@ -32,12 +32,15 @@ import numpy as np
 import scipy.sparse as sp
 
 # op codes
-R, RX, H, CX, M, MR, MRX, XERR, DEP1, DEP2, DETECTOR, OBSERVABLE, MX = range(13)
+R, RX, H, CX, M, MR, MRX, XERR, DEP1, DEP2, DETECTOR, OBSERVABLE, MX, ZERR = range(14)
 
 
-def bb_memory_ops(code, A_list, B_list, p: float, num_repeat: int):
-    """Op list of the z-basis BB memory circuit.  Each op is a tuple
-    (kind, qubits..., prob) ; DETECTOR/OBSERVABLE carry absolute measurement indices."""
+def bb_memory_ops(code, A_list, B_list, p: float, num_repeat: int, z_basis: bool = True, return_segments: bool = False):
+    """Op list of the BB memory circuit (z- or x-basis experiment).  Each op is a tuple
+    (kind, qubits..., prob) ; DETECTOR/OBSERVABLE carry absolute measurement indices.
+    ``return_segments``: also the segment of every op -- 0 for the initialisation and the encoding round, k for the k-th
+    repetition of the round block (the reference appends it as ``(num_repeat - 1) * rep_circuit``, a REPEAT block), the last
+    value for the final data measurement: the units in which Stim's error analysis emits its mechanisms (dem_from_ops)."""
     n = code.N
     h = n // 2
     a1, a2, a3 = A_list
@@ -49,8 +52,9 @@ def bb_memory_ops(code, A_list, B_list, p: float, num_repeat: int):
     XC, LD, RD, ZC = 0, h, n, 3 * h  # qubit offsets: X ancillas, L data, R data, Z ancillas
 
     ops = []
+    seg_start = {}  # segment -> index of its first op
     nmeas = 0
-    zmeas_prev = None
+    zmeas_prev = xmeas_prev = None
 
     def cx(c, t):
         ops.append((CX, c, t))
@@ -62,15 +66,17 @@ def bb_memory_ops(code, A_list, B_list, p: float, num_repeat: int):
         ops.append((XERR, XC + i, p))
         ops.append((XERR, ZC + i, p))
     for i in range(n):
-        ops.append((R, LD + i))
-        ops.append((XERR, LD + i, p))
+        ops.append((R if z_basis else RX, LD + i))
+        ops.append((XERR if z_basis else ZERR, LD + i, p))
 
     for rnd in range(num_repeat):
         repeat = rnd > 0
         if repeat:
+            seg_start[rnd] = len(ops)
+        if repeat:
             for i in range(h):
                 ops.append((XERR, ZC + i, p))
-                # Z_ERROR on the X ancilla: invisible to Z-basis detectors
+                ops.append((ZERR, XC + i, p))  # (invisible to Z-basis detectors)
                 ops.append((DEP1, RD + i, p))
         else:
             for i in range(h):
@@ -100,26 +106,38 @@ def bb_memory_ops(code, A_list, B_list, p: float, num_repeat: int):
             ops.append((MR, ZC + i, nmeas))
             zmeas.append(nmeas)
             nmeas += 1
-        for i in range(h):
-            if repeat:
-                ops.append((DETECTOR, (zmeas[i], zmeas_prev[i])))
-            else:
-                ops.append((DETECTOR, (zmeas[i],)))
+        if z_basis:
+            for i in range(h):
+                ops.append((DETECTOR, (zmeas[i], zmeas_prev[i]) if repeat else (zmeas[i],)))
         zmeas_prev = zmeas
+        xmeas = []
         for i in range(h):  # layer 8
+            ops.append((ZERR, XC + i, p))
             ops.append((MRX, XC + i, nmeas))
+            xmeas.append(nmeas)
             nmeas += 1
+        if not z_basis:
+            for i in range(h):
+                ops.append((DETECTOR, (xmeas[i], xmeas_prev[i]) if repeat else (xmeas[i],)))
+        xmeas_prev = xmeas
 
+    seg_start[num_repeat] = len(ops)
     dmeas = []
     for i in range(n):
-        ops.append((M, LD + i, nmeas))
+        ops.append((M if z_basis else MX, LD + i, nmeas))
         dmeas.append(nmeas)
         nmeas += 1
-    for i, row in enumerate(code.hz):
-        ops.append((DETECTOR, tuple(dmeas[j] for j in np.flatnonzero(row)) + (zmeas_prev[i],)))
-    for i, row in enumerate(code.lz):
+    last = zmeas_prev if z_basis else xmeas_prev
+    for i, row in enumerate(code.hz if z_basis else code.hx):
+        ops.append((DETECTOR, tuple(dmeas[j] for j in np.flatnonzero(row)) + (last[i],)))
+    for i, row in enumerate(code.lz if z_basis else code.lx):
         ops.append((OBSERVABLE, tuple(dmeas[j] for j in np.flatnonzero(row))))
-    return ops
+    if not return_segments:
+        return ops
+    seg = np.zeros(len(ops), dtype=np.int32)
+    for k, i0 in seg_start.items():
+        seg[i0:] = k
+    return ops, seg
 
 
 @dataclass
@@ -129,7 +147,17 @@ class DEM:
     priors: np.ndarray
 
 
-def dem_from_ops(ops) -> DEM:
+def dem_from_ops(ops, segments=None) -> DEM:
+    """``segments is None``: columns in circuit order of first appearance, equal symptoms merged with p <- p(1-q) + q(1-p)
+    (the order every z-basis fixture and measurement of this repository was made with; for the z-basis circuits nothing the
+    reference computes depends on the order inside a region of columns).
+    ``segments`` (bb_memory_ops(..., return_segments=True)): the column order and priors of
+    ``dem_to_check_matrices(circuit.detector_error_model())`` (/root/reference/src/build_circuit.py:251-299) -- Stim analyses
+    the circuit backwards and flushes its mechanisms per unit (what precedes the REPEAT block, every iteration of it, what
+    follows), merged and sorted by symptom (detector ids ascending, observables last) inside a unit; the reference then walks
+    the flattened model and ADDS the probabilities of a symptom that several units emit (:262-270).  The x-basis windows of
+    osd.py:83, 105 cut INSIDE a region of columns (``c[1] + n``), so there the order matters: with it the notebook's
+    "prior for noisy syndrome 0.05900506726184526" (`Sliding Window OSD.ipynb`, x-basis (5,2) run) comes out to the last digit."""
     ndet = sum(1 for o in ops if o[0] == DETECTOR)
     nobs = sum(1 for o in ops if o[0] == OBSERVABLE)
     nq = 0
@@ -152,12 +180,21 @@ def dem_from_ops(ops) -> DEM:
                 meas_mask[mi] = meas_mask.get(mi, 0) ^ (1 << (ndet + k))
             k += 1
 
-    sens = [0] * nq
+    sx = [0] * nq  # detectors / observables an X flip on the qubit would toggle from here on
+    sz = [0] * nq  # ... a Z flip
     mech: dict[int, float] = {}  # symptom bitmask -> probability
     order: list[int] = []
 
+    cur_seg = 0
+    seg_mech: dict[tuple, float] = {}  # (segment, symptom) -> probability (Stim order)
+
     def emit(sym: int, q: float) -> None:
         if sym == 0:
+            return
+        if segments is not None:
+            key = (cur_seg, sym)
+            pp = seg_mech.get(key)
+            seg_mech[key] = q if pp is None else pp * (1.0 - q) + q * (1.0 - pp)
             return
         if sym in mech:
             pp = mech[sym]
@@ -166,34 +203,70 @@ def dem_from_ops(ops) -> DEM:
             mech[sym] = q
             order.append(sym)
 
-    for o in reversed(ops):
+    # the 15 two-qubit Paulis, (x-part, z-part) per qubit; grouped by their X pattern (first, second, both, none) so that a
+    # circuit whose detectors only see X flips yields its mechanisms in the order of the z-basis derivation of round 1
+    I_, X_, Y_, Z_ = (0, 0), (1, 0), (1, 1), (0, 1)
+    PAIRS = [(X_, I_), (Y_, I_), (X_, Z_), (Y_, Z_), (I_, X_), (I_, Y_), (Z_, X_), (Z_, Y_),
+             (X_, X_), (X_, Y_), (Y_, X_), (Y_, Y_), (Z_, I_), (I_, Z_), (Z_, Z_)]
+
+    for idx in range(len(ops) - 1, -1, -1):
+        o = ops[idx]
         kind = o[0]
+        if segments is not None:
+            cur_seg = int(segments[idx])
         if kind == CX:
-            sens[o[1]] ^= sens[o[2]]
+            sx[o[1]] ^= sx[o[2]]
+            sz[o[2]] ^= sz[o[1]]
         elif kind == DEP2:
             q = 0.5 * (1.0 - (1.0 - 16.0 * o[3] / 15.0) ** 0.125)
-            sa, sb = sens[o[1]], sens[o[2]]
-            for sym in (sa, sb, sa ^ sb):  # X-part on first / second / both; 4 Paulis each
-                for _ in range(4):
-                    emit(sym, q)
+            a, b = o[1], o[2]
+            for (xa, za), (xb, zb) in PAIRS:
+                emit((sx[a] if xa else 0) ^ (sz[a] if za else 0) ^ (sx[b] if xb else 0) ^ (sz[b] if zb else 0), q)
         elif kind == DEP1:
             q = 0.5 * (1.0 - (1.0 - 4.0 * o[2] / 3.0) ** 0.5)
-            emit(sens[o[1]], q)  # X
-            emit(sens[o[1]], q)  # Y
+            emit(sx[o[1]], q)             # X
+            emit(sx[o[1]] ^ sz[o[1]], q)  # Y
+            emit(sz[o[1]], q)             # Z
         elif kind == XERR:
-            emit(sens[o[1]], o[2])
+            emit(sx[o[1]], o[2])
+        elif kind == ZERR:
+            emit(sz[o[1]], o[2])
+        elif kind == H:
+            sx[o[1]], sz[o[1]] = sz[o[1]], sx[o[1]]
         elif kind == MR:
-            sens[o[1]] = meas_mask.get(o[2], 0)
+            sx[o[1]], sz[o[1]] = meas_mask.get(o[2], 0), 0
         elif kind == M:
-            sens[o[1]] ^= meas_mask.get(o[2], 0)
-        elif kind in (R, RX, MRX, H):
-            sens[o[1]] = 0
-        # MX: an X flip commutes with the X-basis measurement -- neither its outcome nor the state after it changes
-    # forward-circuit order of first appearance
-    order.reverse()
+            sx[o[1]] ^= meas_mask.get(o[2], 0)
+        elif kind == MRX:
+            sx[o[1]], sz[o[1]] = 0, meas_mask.get(o[2], 0)
+        elif kind == MX:
+            sz[o[1]] ^= meas_mask.get(o[2], 0)
+        elif kind in (R, RX):
+            sx[o[1]] = sz[o[1]] = 0
+    dmask = (1 << ndet) - 1
+    if segments is None:
+        order.reverse()  # forward-circuit order of first appearance
+    else:
+        def sort_key(sym: int):
+            ds, v = [], sym & dmask
+            while v:
+                low = v & -v
+                ds.append(low.bit_length() - 1)
+                v ^= low
+            v = sym >> ndet
+            while v:
+                low = v & -v
+                ds.append((1 << 40) + low.bit_length() - 1)
+                v ^= low
+            return tuple(ds)
+        first: dict[int, int] = {}
+        for (sg, sym), q in seg_mech.items():
+            if sym not in first or sg < first[sym]:
+                first[sym] = sg
+            mech[sym] = mech.get(sym, 0.0) + q
+        order = sorted(first, key=lambda sym: (first[sym], sort_key(sym)))
 
     rows, cols, orow, ocol = [], [], [], []
-    dmask = (1 << ndet) - 1
     for j, sym in enumerate(order):
         v = sym & dmask
         while v:
@@ -214,8 +287,17 @@ def dem_from_ops(ops) -> DEM:
     return DEM(chk, obs, priors)
 
 
-def bb_dem(code, A_list, B_list, p: float, num_repeat: int) -> DEM:
-    """(chk, obs, priors) of the z-basis BB memory experiment -- counterpart of
-    ``dem_to_check_matrices(build_circuit(...).detector_error_model())``
-    (/root/reference/osd.py:35-37)."""
-    return dem_from_ops(bb_memory_ops(code, A_list, B_list, p, num_repeat))
+def bb_dem(code, A_list, B_list, p: float, num_repeat: int, z_basis: bool = True, column_order: str | None = None) -> DEM:
+    """(chk, obs, priors) of the BB memory experiment -- counterpart of
+    ``dem_to_check_matrices(build_circuit(..., z_basis=z_basis).detector_error_model())``
+    (/root/reference/osd.py:35-37).  ``column_order``: "circuit" (first appearance in circuit order; default for z-basis, where
+    the reference's results do not depend on it) or "stim" (the reference's own order; default for x-basis, whose windows
+    are cut inside a column region -- dem_from_ops)."""
+    if column_order is None:
+        column_order = "circuit" if z_basis else "stim"
+    if column_order == "circuit":
+        return dem_from_ops(bb_memory_ops(code, A_list, B_list, p, num_repeat, z_basis))
+    if column_order != "stim":
+        raise ValueError("column_order: 'circuit' or 'stim'")
+    ops, seg = bb_memory_ops(code, A_list, B_list, p, num_repeat, z_basis, return_segments=True)
+    return dem_from_ops(ops, seg)

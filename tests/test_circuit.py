@@ -127,3 +127,34 @@ def test_merged_prior_is_per_row_like_the_reference():
     assert np.allclose(tail, want) and len(np.unique(np.round(tail, 12))) > 1
     plan2 = plan_windows(chk, obs, priors, h, 2, 1, method=1, noisy_prior=0.02)
     assert np.allclose(plan2.windows[0].prior[-h:], 0.02)
+
+
+def test_x_basis_experiment_known_answer():
+    """`Sliding Window OSD.ipynb` (x-basis run: N = 144, p = 0.004, 12 rounds, (W,F) = (5,2), method 1, z_basis=False) prints
+    "prior for noisy syndrome 0.05900506726184526".  The x-basis windows are cut `c[1] + n` columns into a region
+    (/root/reference/osd.py:83, 105), so the value depends on Stim's column order inside a region; the general two-sensitivity
+    sweep + the reference's column order (bb_dem(..., z_basis=False), default column_order="stim") reproduce it to the last digit."""
+    code, A, B = bb_code(144)
+    dem = bb_dem(code, A, B, 0.004, 12, z_basis=False)
+    assert dem.chk.shape == (936, 8784) and dem.obs.shape == (12, 8784)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 72, 5, 2, method=1, z_basis=False)
+    assert plan.noisy_prior == 0.05900506726184526
+    assert [w.mat.shape for w in plan.windows] == [(360, 3096)] * 4 + [(360, 3024)]
+    # the x-basis observables are the X logicals: every mechanism's observable flips follow from lx
+    assert not ((code.hz.astype(int) @ code.lx.T) % 2).any()
+
+
+def test_reference_column_order_reproduces_the_z_basis_known_answers_too():
+    """column_order="stim" for the z-basis circuit: same shape and weights, the three notebook priors to the last digit; the
+    priors of the few mechanisms that several loop iterations emit are SUMS there (build_circuit.py:262-270), i.e. up to 4e-5
+    above the XOR-merged values of the default order."""
+    code, A, B = bb_code(144)
+    for p, expect in ((0.003, 0.027499817877069083),):
+        d = bb_dem(code, A, B, p, 12, column_order="stim")
+        assert d.chk.shape == (936, 8784)
+        plan = plan_windows(d.chk, d.obs, d.priors, 72, 3, 1, method=1)
+        assert plan.noisy_prior == expect
+        c = bb_dem(code, A, B, p, 12)
+        key = lambda m: sorted(tuple(m.indices[m.indptr[j]:m.indptr[j + 1]]) for j in range(m.shape[1]))
+        assert key(sp.csc_matrix(d.chk)) == key(sp.csc_matrix(c.chk))  # the same mechanisms, another order
+        assert 0.0 <= np.sort(d.priors)[-1] - np.sort(c.priors)[-1] < 1e-4

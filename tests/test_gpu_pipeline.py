@@ -140,3 +140,39 @@ def test_plan_windows_methods_vs_oracle_host_loop(method, W, F, noisy):
     bad = np.flatnonzero((total != want).any(axis=1))
     assert bad.size == 0, f"shots {bad.tolist()} differ"
     assert len(np.unique(dec.last_stats[..., 0] & 0xFF)) >= 2
+
+
+def test_x_basis_sliding_window_experiment():
+    """The x-basis memory experiment of `Sliding Window OSD.ipynb` (N = 144, p = 0.004, 12 rounds, (W,F) = (5,2), method 1,
+    z_basis=False; notebook: 0 flagged, 140 / 10 000 logical errors -- with the third-party ldpc BP+OSD-CS 10 in the windows,
+    shorten=False, so that count is context, not a parity target): the 360 x 3096 windows on the device against the oracle host
+    loop (bit-exact), then 10 000 device-sampled shots with osd_window(osd_cs 10): no flagged shot, a logical error rate of the
+    notebook's order of magnitude."""
+    import torch
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import DemSampler, SlidingWindowDecoder
+    from slidingwindowdecoder_amd.circuit import bb_dem
+    from slidingwindowdecoder_amd.codes import bb_code
+    from slidingwindowdecoder_amd.windows import plan_windows, sample_dem, sliding_window_decode_host
+    code, A, B = bb_code(144)
+    dem = bb_dem(code, A, B, 0.004, 12, z_basis=False)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 72, 5, 2, method=1, z_basis=False)
+    assert plan.noisy_prior == 0.05900506726184526
+    kw = dict(pre_max_iter=8, post_max_iter=200, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=0)
+    dec = SlidingWindowDecoder(plan, **kw)
+    det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, 24, seed=9)
+    total = dec.decode(det)
+    want, _ = sliding_window_decode_host(plan, det, lambda w: O.osd_window(w.mat, channel_probs=w.prior, **kw))
+    assert np.array_equal(total, want)
+    shots, ref = 10000, 140
+    dec = SlidingWindowDecoder(plan, **dict(kw, osd_order=10))
+    d, flips = DemSampler(plan.chk, plan.obs, plan.priors).sample_device(shots, seed=20240318)
+    shot = torch.empty((shots, 2), dtype=torch.int32, device="cuda")
+    dec.decode_device(d, shot_result=shot)
+    dec.check_status()
+    sr = shot.cpu().numpy()
+    flagged = sr[:, 1] != 0
+    nerr = int((((sr[:, 0].astype(np.int64) & 0xFFFFFFFF) != (flips.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)) | flagged).sum())
+    print(f"x-basis (5,2) p=0.004: {nerr}/{shots} logical errors (notebook 140/10000), flagged {int(flagged.sum())}")
+    assert not flagged.any()
+    assert ref // 3 < nerr < 2 * ref, (nerr, ref)
