@@ -16,7 +16,7 @@ from slidingwindowdecoder_amd import SlidingWindowDecoder, bp4_osd
 from slidingwindowdecoder_amd.windows import sample_dem
 from slidingwindowdecoder_amd.codes import bb_code
 
-which = sys.argv[1:] or ["3", "3small", "3ens", "4", "5", "5w12", "bp4", "bp4shyps", "order10"]
+which = sys.argv[1:] or ["3", "3small", "3ens", "3mt", "4", "5", "5w12", "bp4", "bp4shyps", "order10"]
 
 
 def run_pipeline(name, plan, shots, reps, **kw):
@@ -49,6 +49,11 @@ if "3small" in which:  # small batch: side branches of a shot's decimation tree 
 if "3ens" in which:    # the 64-hypothesis ensemble (multi_thread semantics, no parity target)
     run_pipeline("configs[2], hypotheses=64 ensemble (D=5, S=6, every leaf scored), 2048 shots per launch", bench.build_problem(), 2048, 3,
                  **dict(GDG_KW, hypotheses=64))
+if "3mt" in which:   # the reference's threaded ensemble (multi_thread=True: main + 7 tree + 7 side threads), one workgroup per (shot, window)
+    run_pipeline("configs[2], bpgdg_decoder(multi_thread=True) = the reference's threaded ensemble (D=3, S=10: 15 thread bodies per window), 4096 shots per launch",
+                 bench.build_problem(), 4096, 3, **dict(GDG_KW, multi_thread=True))
+    run_pipeline("configs[2], threaded ensemble with D=5, S=6 (31 tree threads with two leaves each + main + 1 side: 64 hypotheses), 4096 shots per launch",
+                 bench.build_problem(), 4096, 3, **dict(GDG_KW, multi_thread=True, max_tree_depth=5, max_side_depth=6))
 if "4" in which:
     run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 4096, 2,
                  **dict(bench.DECODER_KW, osd_order=0))

@@ -27,6 +27,7 @@
 #pragma once
 
 #define SWD_GDG_SLOTS 64     // snapshots per (shot, window) the parallel form can hold; beyond: serial fallback
+#define SWD_GDG_MAXGUESS 160 // snapshot stack of the serial form (max_guess = 2 (2^D - 1) + S - D, bp_guessing_decoder.pyx:181: D = 6, S <= 40)
 #define SWD_GDG_MAXSTEP 64   // max_side_branch_step the parallel form records
 #define SWD_GDG_REC_BYTES (16 + 4 * SWD_GDG_MAXSTEP)
 #define SWD_GDG_HDR_BYTES 256
@@ -141,11 +142,11 @@ __device__ __forceinline__ int ring_pop(uint32_t *r, uint32_t mask, uint32_t *pa
 struct GdgLds {
     uint16_t *pos_lv;  // [new_n] sorted position -> column
     uint16_t *plist;   // [new_n] scratch list of positions (ordered sums, decimation queue)
-    int16_t *dec_vn;   // [64] snapshot stack: guessed position
-    int16_t *alt_depth;// [64]
+    int16_t *dec_vn;   // [SWD_GDG_MAXGUESS] snapshot stack: guessed position
+    int16_t *alt_depth;// [SWD_GDG_MAXGUESS]
     uint8_t *best_err; // [new_n] bpgd_error
     uint8_t *bp_hard;  // [n] pre-processing BP decisions (returned if BPGD::reset fails)
-    int8_t *dec_val;   // [64]
+    int8_t *dec_val;   // [SWD_GDG_MAXGUESS]
     uint8_t *cat;      // [new_n] select_vn classification per position
 };
 
@@ -153,11 +154,11 @@ __device__ __forceinline__ void gdg_bind(GdgLds &G, char *smem, const SwdLdsLayo
     char *b = smem + L.off_gdg;
     G.pos_lv = (uint16_t *)b; b += new_n * 2;
     G.plist = (uint16_t *)b; b += new_n * 2;
-    G.dec_vn = (int16_t *)b; b += 64 * 2;
-    G.alt_depth = (int16_t *)b; b += 64 * 2;
+    G.dec_vn = (int16_t *)b; b += SWD_GDG_MAXGUESS * 2;
+    G.alt_depth = (int16_t *)b; b += SWD_GDG_MAXGUESS * 2;
     G.best_err = (uint8_t *)b; b += new_n;
     G.bp_hard = (uint8_t *)b; b += n;
-    G.dec_val = (int8_t *)b; b += 64;
+    G.dec_val = (int8_t *)b; b += SWD_GDG_MAXGUESS;
     G.cat = (uint8_t *)b;
 }
 
@@ -891,6 +892,13 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
 // s.hard[0..n) is the returned vector.
 // par != nullptr (parallel form): a tree with side branches is parked in a context and its side branches are queued;
 // then R.exit_class = -2 on return and the result arrives later as a FINAL item (gdg_finalize).
+#ifdef SWD_GDGPROF // diagnostic build (scripts/gdg_phase_profile.py): 100 MHz ticks per kind of work inside a tree walk
+#define GPT0() long long gp_t_ = wall_clock64()
+#define GPT(k) do { const long long gp_n_ = wall_clock64(); R.gp[k] += gp_n_ - gp_t_; gp_t_ = gp_n_; } while (0)
+#else
+#define GPT0() do { } while (0)
+#define GPT(k) do { } while (0)
+#endif
 // ENS (kernel kind 7): bpgdg_decoder(multi_thread=True) -- the post-processing is the reference's threaded ensemble
 // (gdg_ensemble_ref) instead of gdg()'s tree walk.
 template <int NT, int VF, int DM, int KG, bool ENS = false, int VFP = VF>
@@ -902,6 +910,9 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     gdg_bind(G, s.scratch, L, n, new_n);
 #pragma unroll
     for (int i = 0; i < 9; ++i) R.t[i] = 0;
+#ifdef SWD_GDGPROF
+    for (int i = 0; i < 5; ++i) R.gp[i] = 0;
+#endif
     R.t[0] = wall_clock64();
     for (int l = tid; l < m; l += NT) {
         const int d = g.row_deg[l];
@@ -951,11 +962,36 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     // values this buffer still holds there must not leak into select_vn / decimate_vn_reliable.
     if (P.max_iter_per_step < 4)
         for (int i = P.max_iter_per_step * n + tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
-    sort_pairs<NT>(key, idx, L.npad);
-    for (int i = tid; i < n; i += NT) {
-        const int v = idx[i];
-        if (i < new_n) G.pos_lv[i] = (uint16_t)v;
-        else { s.vn_val[v] = 0; s.hard[v] = 0; G.bp_hard[v] = 0; }
+    // Only the first new_n sorted positions are ever looked at (the rest is decided 0): select the new_n smallest (key, index)
+    // pairs -- ties to the lowest indices, like the stable sort -- and sort those alone (57 -> ~25 us per window that goes into
+    // the tree walk; the full sort remains when the scratch region cannot hold the second pair of arrays).
+    int npad2 = 2;
+    while (npad2 < new_n) npad2 <<= 1;
+    if (new_n < n && L.off_aux + 3072 + npad2 * 10 <= (g.E + 1) * 8) {
+        select_smallest<NT>(key, n, new_n, (int *)s.aux, s); // vn_val[v] = 0 for everything but the new_n smallest; ends with a barrier
+        uint64_t *key2 = (uint64_t *)(s.aux + 3072);
+        uint16_t *idx2 = (uint16_t *)(key2 + npad2);
+        const int ch = (n + NT - 1) / NT;
+        const int v0 = tid * ch, v1 = min(n, v0 + ch);
+        int cnt = 0;
+        for (int v = v0; v < v1; ++v) cnt += (s.vn_val[v] == -1) ? 1 : 0;
+        int tot;
+        int pos = block_exscan<NT>(cnt, s, tot);
+        for (int v = v0; v < v1; ++v) {
+            if (s.vn_val[v] == -1) { key2[pos] = key[v]; idx2[pos] = (uint16_t)v; ++pos; }
+            else { s.hard[v] = 0; G.bp_hard[v] = 0; }
+        }
+        for (int i = new_n + tid; i < npad2; i += NT) { key2[i] = ~0ull; idx2[i] = 0xFFFF; }
+        __syncthreads();
+        sort_pairs<NT>(key2, idx2, npad2);
+        for (int i = tid; i < new_n; i += NT) G.pos_lv[i] = idx2[i];
+    } else {
+        sort_pairs<NT>(key, idx, L.npad);
+        for (int i = tid; i < n; i += NT) {
+            const int v = idx[i];
+            if (i < new_n) G.pos_lv[i] = (uint16_t)v;
+            else { s.vn_val[v] = 0; s.hard[v] = 0; G.bp_hard[v] = 0; }
+        }
     }
     __syncthreads();
     bool dead_unsat = false;
@@ -995,7 +1031,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     bp_init<VFP, DM>(s, vcp);
     __syncthreads();
     if constexpr (ENS) {
-        for (int j = tid; j < 64; j += NT) G.alt_depth[j] = -1;
+        for (int j = tid; j < SWD_GDG_MAXGUESS; j += NT) G.alt_depth[j] = -1;
         __syncthreads();
         gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn);
         for (int v = tid; v < n; v += NT) s.hard[v] = 0;
@@ -1030,18 +1066,23 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
 #endif
     }
     // ---- phase 1: main branch
+    GPT0();
     for (int depth = 0; depth < P.max_step; ++depth) {
         if (depth > 0) nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+        GPT(0);
         const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        GPT(1);
         ++blocks; R.post_it += it;
         if (cv) {
             converge = 1; min_converge_depth = depth;
             min_pm = gdg_get_pm<NT>(g, s, G);
             for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
+            GPT(4);
             break;
         }
         const int rc = gdg ? gdg_select_vn<NT>(g, P, s, G, hist_b, false, depth, min_converge_depth, used_guess, snap_b)
                            : gdg_decimate_reliable<NT>(g, s, G, hist_b);
+        GPT(2);
         if (rc == -1) break;
     }
     if (!converge)
@@ -1104,12 +1145,15 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();
+        GPT(3);
         if (s.scal[1]) continue;
         for (int j = 0; j < P.max_side_branch_step; ++j) {
             depth = G.alt_depth[i] + j;
             nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
             if (j == 0) { bp_init<VFP, DM>(s, vcp); __syncthreads(); } // set_masks re-initialises the messages
+            GPT(0);
             const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
+            GPT(1);
             ++blocks; R.post_it += it;
             if (cv) {
                 converge = 1;
@@ -1122,9 +1166,12 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
                 break;
             }
             if (depth > min_converge_depth + 2) break;
-            if (gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, min_converge_depth, used_guess, snap_b) == -1) break;
+            const int rc2 = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, min_converge_depth, used_guess, snap_b);
+            GPT(2);
+            if (rc2 == -1) break;
         }
         __syncthreads();
+        GPT(4);
     }
     __syncthreads();
     if (!replayed) {

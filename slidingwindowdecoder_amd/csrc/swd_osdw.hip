@@ -62,7 +62,7 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     L.off_gdg = -1;
     if (kind != 0) {
         L.off_gdg = o;
-        o = align_up(o + new_n * 2 * 2 + 64 * 2 * 2 + new_n + n + 64 + new_n, 8);
+        o = align_up(o + new_n * 2 * 2 + SWD_GDG_MAXGUESS * 2 * 2 + new_n + n + SWD_GDG_MAXGUESS + new_n, 8);
         L.off_lslot = o;
         o = align_up(o + g.K * m * 2, 8);
     }

@@ -1775,6 +1775,9 @@ struct WinResult {
     int exit_class, conv, total_it, pre_it, post_it, live_vn, live_cn, live_e, osd_rowadds;
     double pm;
     long long t[9]; // phase boundaries (wall_clock64 ticks): init, pre, sort, shorten, post, osd sort, elim, sweep
+#ifdef SWD_GDGPROF
+    long long gp[5]; // guessing decoders, diagnostic build: cache rebuilds, BP blocks, select_vn, branch starts, path metrics
+#endif
 };
 
 // scratch: where the scratch region of this workgroup starts -- the LDS block itself, or (BIG kernels) its region in HBM, in which
@@ -2490,6 +2493,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
 #endif
 #ifdef SWD_TSPROF
                 pr[5] = t_unit0; pr[6] = tend; // absolute ticks of the unit (diagnostic build)
+#endif
+#ifdef SWD_GDGPROF
+                pr[0] = R.t[2] - R.t[0]; pr[1] = (R.t[3] ? R.t[3] : R.t[2]) - R.t[2];
+                pr[2] = R.gp[0]; pr[3] = R.gp[1]; pr[4] = R.gp[2]; pr[5] = R.gp[3]; pr[6] = R.gp[4]; pr[7] = tend - R.t[0];
 #endif
 #ifdef SWD_BPPROF
                 pr[0] = s.scal[24]; pr[5] = s.scal[25]; pr[6] = s.scal[26]; pr[7] = s.scal[27];

@@ -134,13 +134,14 @@ struct Plan {
         if (kind != 0) {
             max_guess = ((1 << gp.max_tree_depth) - 1) * 2 + gp.max_side_depth - gp.max_tree_depth; // bp_guessing_decoder.pyx:181
             if (max_guess < 0) max_guess = 0;
-            if (max_guess > 64) { set_error("max_guess=%d exceeds the device limit of 64 snapshots", max_guess); return -1; }
+            if (max_guess > SWD_GDG_MAXGUESS) { set_error("max_guess=%d exceeds the device limit of %d snapshots", max_guess, SWD_GDG_MAXGUESS); return -1; }
             // parallel form of the tree search (swd_gdg_kernel.h): needs its record formats to hold the parameters
             // (and its work items to hold the unit: item_unit packs the window in 8 bits and the shot in 22, swd_gdg_kernel.h)
-            if (gp.multi_thread == 1 && (gp.max_side_depth - gp.max_tree_depth > 62 || gp.max_tree_depth > 6)) {
-                set_error("multi_thread: at most 62 side threads and tree depth 6 on the device"); return -1;
+            if (gp.multi_thread == 1 && (gp.max_side_depth - gp.max_tree_depth > SWD_GDG_MAXGUESS - 2 || gp.max_tree_depth > 6)) {
+                set_error("multi_thread: at most %d side threads and tree depth 6 on the device", SWD_GDG_MAXGUESS - 2); return -1;
             }
-            gdg_parallel = kind == 1 && gp.multi_thread != 1 && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
+            // (... and a tree of at most SWD_GDG_SLOTS snapshots: deeper trees take the serial walk)
+            gdg_parallel = kind == 1 && gp.multi_thread != 1 && max_guess <= SWD_GDG_SLOTS && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
                            wins.size() <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_GDG_SERIAL");
             snap_stride = 0;
             for (auto &w : wins) {

@@ -277,6 +277,30 @@ def test_threaded_ensemble_weight2_known_answer():
     assert got == [tuple(int(x) for x in r) for r in k["multi"]] == [(0, 72, 14), (1, 73, 14)]
 
 
+def test_deep_trees_beyond_64_snapshots_vs_oracle():
+    """max_tree_depth 5, max_side_depth 12: max_guess = 2 (2^5 - 1) + 12 - 5 = 69 snapshots -- more than the parallel tree search
+    holds per tree (64), so the plan takes the serial walk (160 snapshots); single-thread gdg() and the threaded ensemble vs the oracle"""
+    import slidingwindowdecoder_amd as S
+    from oracle import oracle as O
+    f = fx.load("bb72_capacity.npz")
+    mat, _ = fx.graph(f, "gdg_")
+    rng = np.random.default_rng(5)
+    priors = rng.uniform(0.04, 0.09, size=72)
+    kw = dict(max_iter=6, ms_scaling_factor=1.0, max_iter_per_step=4, max_step=20, max_tree_depth=5, max_side_depth=12,
+              max_tree_branch_step=6, max_side_branch_step=8, gdg_factor=1.0)
+    H = mat.toarray().astype(np.int64)
+    synd = np.array([(H @ (rng.random(72) < priors * 1.4).astype(np.int64) % 2) for _ in range(160)], dtype=np.uint8)
+    dev, ora = S.bpgdg_decoder(mat, channel_probs=priors, **kw), O.bpgdg_decoder(mat, channel_probs=priors, **kw)
+    out = dev.decode_batch(synd)
+    deep = 0
+    for k in range(len(synd)):
+        ora.clear_history()
+        assert np.array_equal(out[k], ora.decode(synd[k])) and bool(dev.last_status[k] & 0x100) == bool(ora.converge), k
+        deep = max(deep, int(dev.last_stats[k, 4]))
+    print("largest number of snapshots pushed by one tree:", deep)
+    _ensemble_vs_oracle(mat, priors, kw, synd[:100], 20)
+
+
 def test_pipeline_with_more_than_256_windows_takes_the_serial_form():
     """The parallel tree search packs the window number of a work item into 8 bits (swd_gdg_kernel.h, item_unit): a plan with more
     windows must run the serial walk (Plan::finalize) -- a 300-round block-banded detector error model, (2,1) windows ->
