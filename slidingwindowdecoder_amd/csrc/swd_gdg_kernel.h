@@ -755,7 +755,7 @@ __device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDeco
 
 // The reference's threaded ensemble (bpgdg_decoder(multi_thread=True): bp_guessing_decoder.pyx:238-251 over
 // BPGD_main_thread / BPGD_tree_thread / BPGD_side_thread::do_work, bpgd.cpp:435-688) on one workgroup, the thread bodies in
-// the order main, tree threads by id, side threads by index -- the order of oracle/swd_oracle.c:gdg_multi_run, which is
+// the order main, tree threads by id, side threads by index -- the order of the test oracle's restatement (gdg_multi_run), which is
 // pinned to the reference's real threads.  Every body is a pure function of its inputs; only the strict-< update of the
 // shared best depends on thread timing in the reference, and only when two converged hypotheses carry the same path metric
 // with different vectors (statistics word 7 counts those: such shots have no single reference answer).
