@@ -579,6 +579,28 @@ def main():
         cfg[f"osd_cs_order{side}_windows_per_s"] = total_shots * W * k2 / (time.perf_counter() - t0)
         e2.check_status()
 
+    if rank == 0 and world == 1 and headline and not args.no_side_order:
+        # deployment-mode side figure: consecutive batches on two streams with their own output buffers -- the persistent grid of the
+        # next launch fills the workgroup slots that the tail of the previous one leaves empty (the headline `value` keeps one launch
+        # at a time, which is what the kernel-level roofline and the committed rocprof profile describe)
+        import torch as _t
+        e3 = [GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order) for _ in range(2)]
+        for e in e3[1:]:
+            e.dec = e3[0].dec  # ONE decoder handle: its launch slots keep concurrent launches apart
+        streams = [_t.cuda.Stream() for _ in range(2)]
+        k3 = max(4, min(args.steps, 40))
+        for i in range(4):
+            with _t.cuda.stream(streams[i % 2]):
+                e3[i % 2].step(i)
+        _t.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k3):
+            with _t.cuda.stream(streams[i % 2]):
+                e3[i % 2].step(i)
+        _t.cuda.synchronize()
+        cfg["two_stream_windows_per_s"] = total_shots * W * k3 / (time.perf_counter() - t0)
+        e3[0].check_status()
+
     if rank == 0:
         line["config"] = cfg
         line["roofline"] = roofline(args.workload, kernel, alg_bytes, lds_alg, avg_kernel_s, irr)

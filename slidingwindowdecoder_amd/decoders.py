@@ -630,7 +630,10 @@ class DemSampler:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            _lib.lib().swd_sampler_destroy(self._h)
+            try:
+                _lib.lib().swd_sampler_destroy(self._h)
+            except Exception:  # interpreter shutdown: the module globals may be gone already
+                pass
             self._h = None
 
     def sample(self, shots, seed=20240318, first_shot=0, return_faults=False):
