@@ -210,10 +210,10 @@ __device__ __forceinline__ bool block_any(bool p, Lds &s) {
     unsigned long long b = __ballot(p);
     if ((threadIdx.x & 63) == 0) s.flags[par * 16 + (threadIdx.x >> 6)] = (b != 0ull);
     __syncthreads();
-    bool r = false;
+    int r = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) r |= (s.flags[par * 16 + w] != 0);
-    return r;
+    for (int w = 0; w < NW; ++w) r |= s.flags[par * 16 + w];
+    return __builtin_amdgcn_readfirstlane(r) != 0; // the same on every lane: callers branch on it with scalar branches
 }
 
 // exclusive prefix sum over the block; `total` = sum of all. Two barriers.
@@ -534,7 +534,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     const int l = cn.l >= 0 ? cn.l : 0;      // NT >= m: at most one check per thread
     const int cv = (cn.l >= 0) ? (int)s.cn_val[l] : -1;
     const int cnt = cn.cnt;
-    const int wmax = wave_max(cnt);
+    const int wmax = __builtin_amdgcn_readfirstlane(wave_max(cnt)); // (scalar: the groups of four positions are skipped by scalar branches)
     const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
     constexpr int K4 = KG * 4;
     constexpr int NR = (K4 + 31) / 32;       // sign shift registers
@@ -2311,6 +2311,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
     if (ticket >= nunits) break;
     wi = (int)(ticket / (uint32_t)a.B); b = (int)(ticket % (uint32_t)a.B);
     }
+    // (wi / b as explicit scalars -- readfirstlane -- were tried: the kernel already spills 267 SGPRs, no gain)
     __syncthreads();
     // LDS holds the residual syndrome of the window's own rows only (whole words: [dbase, dbase + dlen)); the rest of
     // the shot's residual syndrome stays in the state record in HBM
