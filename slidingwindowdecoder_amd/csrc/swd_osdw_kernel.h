@@ -213,7 +213,11 @@ __device__ __forceinline__ bool block_any(bool p, Lds &s) {
     int r = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) r |= s.flags[par * 16 + w];
+#ifdef SWD_NO_SCALAR_ANY
+    return r != 0;
+#else
     return __builtin_amdgcn_readfirstlane(r) != 0; // the same on every lane: callers branch on it with scalar branches
+#endif
 }
 
 // exclusive prefix sum over the block; `total` = sum of all. Two barriers.
@@ -534,7 +538,11 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     const int l = cn.l >= 0 ? cn.l : 0;      // NT >= m: at most one check per thread
     const int cv = (cn.l >= 0) ? (int)s.cn_val[l] : -1;
     const int cnt = cn.cnt;
+#ifdef SWD_NO_SCALAR_WMAX
+    const int wmax = wave_max(cnt);
+#else
     const int wmax = __builtin_amdgcn_readfirstlane(wave_max(cnt)); // (scalar: the groups of four positions are skipped by scalar branches)
+#endif
     const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
     constexpr int K4 = KG * 4;
     constexpr int NR = (K4 + 31) / 32;       // sign shift registers

@@ -7,6 +7,8 @@
 #pragma once
 #ifdef SWD_HEADLINE_ONLY // development builds: only the [[144,12,12]] kernels
 #define SWD_VARIANTS(X) X(256, 7, 6, 9, 0, 1, 1, 1)
+#elif defined(SWD_V7816_ONLY) // development builds: the <256, 7, 8, 16> kernels
+#define SWD_VARIANTS(X) X(256, 7, 8, 16, 0, 1, 1, 0)
 #elif defined(SWD_BB288_ONLY) // development builds: only the [[288,12,18]] kernels
 #define SWD_VARIANTS(X) X(1024, 5, 6, 6, 1, 0, 0, 1) X(1024, 5, 6, 9, 0, 1, 0, 1)
 #else
