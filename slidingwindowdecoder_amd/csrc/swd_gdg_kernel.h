@@ -559,7 +559,10 @@ __device__ __forceinline__ bool gdg_sched_step(const SwdGdgPar &gp, const SwdDec
         ++i;
     }
     const int fin = (int)ag_ld(&h[19]);
-    for (int k = i; k < nseq && launched - fin < gp.inflight_max; ++k) {
+    // (workgroups waiting for an item: every branch that may still count is queued -- speculation costs nothing then)
+    // (diagnostics, SWD_GDG_ADAPTIVE=0: inflight_max negated = fixed bound)
+    const int lim = gp.inflight_max < 0 ? -gp.inflight_max : (((int32_t)(ag_ld(&gp.q[1]) - ag_ld(&gp.q[0])) < 0) ? SWD_GDG_SLOTS : gp.inflight_max);
+    for (int k = i; k < nseq && launched - fin < lim; ++k) {
         const int b = seq_get(k);
         if ((lmask >> b) & 1ull) continue;
         if ((int)(ag_ld(&gdg_rec(c, b)[0]) & 0xFFu) > (ens ? mcd0 : mcd)) continue;

@@ -145,6 +145,7 @@ struct SwdPipeArgs {
     int32_t slot_scratch;     // hist / snap are private to the workgroup (indexed by blockIdx.x), not to the shot
     uint8_t *big;             // BIG kernels: [gridDim.x][big_stride] scratch regions of the workgroups in HBM
     int64_t big_stride;
+    const uint32_t *order;    // nullable [B]: the shots in the order they are started (heaviest syndrome first: shot_order_kernel)
     SwdGdgPar gdgp;
 };
 
@@ -320,33 +321,41 @@ __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E 
 // remap != nullptr (shortened graph, BIG kernels with the post-phase messages in LDS): the messages are renumbered one column of
 // cells per live variable node -- cell(k, i) = k * nlive + i for edge position k of the i-th live node, so that the threads of a
 // wave touch consecutive cells in the variable-node pass -- and remap[old slot] = cell for the check side (g.E = D * nlive here).
+// All global loads are issued unconditionally and before anything depends on them (the edge table is padded with SWD_PAD_EDGE
+// beyond a column's degree, rows beyond g.D do not exist: clamped): one memory latency per call instead of two per variable node.
 template <int NT, int VF, int DM, bool FULL, int SH, bool PB>
 __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr) {
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
+    const int D = g.D;
+    uint32_t ev[VF][DM];
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         const int idx = s.vtid + i * NT;
-        c.llr[i] = 0.0;
+        const int v = (idx < cnt) ? (FULL ? idx : (int)s.lv[idx]) : 0;
+        c.llr[i] = (n > 0) ? g.llr[v] : 0.0; // (n, D: uniform)
+#pragma unroll
+        for (int k = 0; k < DM; ++k) ev[i][k] = (n > 0) ? g.vn_edge[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
+    }
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        const bool valid = idx < cnt;
+        if (!valid) c.llr[i] = 0.0;
 #pragma unroll
         for (int k = 0; k < DM; ++k) c.set_ed(i, k, dead);
 #pragma unroll
         for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
-        if (idx < cnt) {
-            const int v = FULL ? idx : (int)s.lv[idx];
-            const int deg = g.col_deg[v];
-            c.llr[i] = g.llr[v];
 #pragma unroll
-            for (int k = 0; k < DM; ++k) {
-                if (k < deg) {
-                    const uint32_t e = g.vn_edge[k * n + v];
-                    if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
-                        uint32_t slot = swd_edge_slot(e);
-                        if (!FULL && remap) { const uint32_t cell = (uint32_t)(k * nlive + idx); remap[slot] = (uint16_t)cell; slot = cell; }
-                        c.set_ed(i, k, slot << 3);
-                        c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
-                                                   : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
-                    }
+        for (int k = 0; k < DM; ++k) {
+            const uint32_t e = ev[i][k];
+            if (valid && k < D && e != SWD_PAD_EDGE) {
+                if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
+                    uint32_t slot = swd_edge_slot(e);
+                    if (!FULL && remap) { const uint32_t cell = (uint32_t)(k * nlive + idx); remap[slot] = (uint16_t)cell; slot = cell; }
+                    c.set_ed(i, k, slot << 3);
+                    c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
+                                               : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
                 }
             }
         }
@@ -1838,11 +1847,24 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // the tuned kernels use the packed caches and their overloads of the BP routines: byte offsets + parity bytes up to 256
     // threads, slot numbers + parity words in the 1024-thread kernels
     std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, VnCacheP<VF, DM, 3, false>> vc;
+#ifdef SWD_INITPROF
+    const long long ip0 = wall_clock64();
+#endif
     vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
+#ifdef SWD_INITPROF
+    asm volatile("" : "+v"(vc.edp[VF - 1][0]), "+v"(vc.llr[0]));
+    const long long ip1 = wall_clock64();
+#endif
     // the check state and jptr written above are read below by OTHER threads (a check is served by the thread
     // whose ctid equals its lane number, which need not be the thread that initialised it)
     __syncthreads();
+#ifdef SWD_INITPROF
+    const long long ip2 = wall_clock64();
+#endif
     bp_init<VF, DM>(s, vc);
+#ifdef SWD_INITPROF
+    const long long ip3 = wall_clock64();
+#endif
     std::conditional_t<SWD_P16(NT), CnCacheP<KG>, CnCacheP<KG, 3>> cn;
     if constexpr (SF) { // heavy checks are shared by 2 or 4 threads in the full-graph phase too (host-built map)
         const uint32_t e = cn_map[s.ctid];
@@ -1857,6 +1879,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     R.live_vn = n; R.live_cn = m; R.live_e = g.E; R.osd_rowadds = 0;
     uint16_t *list0 = (uint16_t *)s.scratch;
     R.t[1] = wall_clock64();
+#ifdef SWD_INITPROF // diagnostic build: where the set-up of a window goes (reset loops | cache loads | barrier | bp_init | check caches)
+    if (tid == 0) { s.scal[20] = (int)(ip0 - R.t[0]); s.scal[21] = (int)(ip1 - ip0); s.scal[22] = (int)(ip2 - ip1); s.scal[23] = (int)(ip3 - ip2); s.scal[24] = (int)(R.t[1] - ip3); }
+#endif
 
     double hs[VF]; // HACC: summed posterior history of this thread's variable nodes
 #pragma unroll
@@ -2242,6 +2267,44 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 // BIG (large graphs, osd_window only): the scratch region of the window's layout -- fp64 messages, sort keys, OSD arrays --
 // is the workgroup's region of a.big in HBM (served by L2 / the memory-side cache); LDS keeps the per-check and per-node state.
 // VFP (guessing decoders): depth of the register cache for the shortened graph, 2 or VF (swd_gdg_kernel.h)
+// Order in which a launch starts its shots: by decreasing syndrome weight (counting sort, ties in any order).  Decoding time
+// grows with the weight, and what a persistent grid loses at the end of a launch is the time its last-started shots still
+// need: the light ones go last.  A shot's result does not depend on when it is decoded.
+// wt_order: [2 B] words -- weights (scratch), then the order.
+template <int NT>
+__global__ void __launch_bounds__(NT) shot_weight_kernel(const uint8_t *det, int64_t det_stride, int num_det, int B, uint32_t *wt) {
+    const int b = (int)blockIdx.x * (NT / 64) + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const uint8_t *d = det + (int64_t)b * det_stride;
+    int c = 0;
+    for (int r = lane; r < num_det; r += 64) c += d[r] ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) wt[b] = (uint32_t)min(c, 1023);
+}
+template <int NT>
+__global__ void __launch_bounds__(NT) shot_order_kernel(const uint32_t *wt, int B, uint32_t *order) {
+    static_assert(NT == 1024, "one bin per thread");
+    __shared__ uint32_t bin[2][1024];
+    const int t = threadIdx.x;
+    bin[0][t] = 0;
+    __syncthreads();
+    for (int b = t; b < B; b += NT) atomicAdd(&bin[0][1023 - wt[b]], 1u);
+    __syncthreads();
+    const uint32_t own = bin[0][t];
+    int cur = 0;
+    for (int o = 1; o < 1024; o <<= 1) { // inclusive scan
+        bin[cur ^ 1][t] = bin[cur][t] + (t >= o ? bin[cur][t - o] : 0u);
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t excl = bin[cur][t] - own;
+    __syncthreads();
+    bin[0][t] = excl;
+    __syncthreads();
+    for (int b = t; b < B; b += NT) order[atomicAdd(&bin[0][1023 - wt[b]], 1u)] = (uint32_t)b;
+}
+
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false, int VFP = VF>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2))) pipeline_kernel(const SwdPipeArgs a) {
     static_assert(!BIG || KIND == 0 || KIND == 3, "the HBM-resident scratch region exists for the osd_window kernels");
@@ -2288,7 +2351,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 // to what keeps the grid busy and no further -- every queued item waits behind the whole ring)
                 if ((int32_t)(ag_ld(&a.gdgp.q[1]) - ag_ld(&a.gdgp.q[0])) <= 0) {
                     const uint32_t nb = shots0 + atomicAdd(a.sched, 1u);
-                    if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit((int)nb, 0));
+                    if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit(a.order ? (int)a.order[nb] : (int)nb, 0));
                 }
                 acc[2] = ring_pop_wait(a.gdgp.q, a.gdgp.qmask, a.status); acc[3] = 0u;
             }
@@ -2313,11 +2376,15 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         } else { wi = (int)((item >> 22) & 0xFFu); b = (int)(item & 0x3FFFFFu); }
     } else {
     __syncthreads();
-    if (tid == 0) { acc[2] = atomicAdd(a.sched, 1u); acc[3] = 0u; }
+    if (tid == 0) {
+        const uint32_t t = atomicAdd(a.sched, 1u);
+        acc[2] = t; acc[3] = 0u;
+        if (a.order && t < nunits) acc[1] = a.order[t % (uint32_t)a.B]; // (every round of tickets walks the shots in the same order)
+    }
     __syncthreads();
     const uint32_t ticket = acc[2];
     if (ticket >= nunits) break;
-    wi = (int)(ticket / (uint32_t)a.B); b = (int)(ticket % (uint32_t)a.B);
+    wi = (int)(ticket / (uint32_t)a.B); b = a.order ? (int)acc[1] : (int)(ticket % (uint32_t)a.B);
     }
     // (wi / b as explicit scalars -- readfirstlane -- were tried: the kernel already spills 267 SGPRs, no gain)
     __syncthreads();
@@ -2382,6 +2449,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
     double *hist_b = a.hist + (int64_t)sidx * a.hist_stride;
     s.fpar = 0;
     __syncthreads();
+#ifdef SWD_TSPROF // diagnostic build: when the unit started (a parked tree's commit happens in another iteration of this loop)
+    if (a.prof && tid == 0 && final_ctx < 0) a.prof[((int64_t)b * a.W + wi) * 8 + 4] = wall_clock64();
+#endif
 #ifdef SWD_GDG_DEBUG
     asm volatile("" ::: "memory"); dbg_tb = wall_clock64(); asm volatile("" ::: "memory");
     if (queued && tid == 0) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(13, dbg_tb - t_unit0); GDG_COUNT(14, 1); }
@@ -2488,6 +2558,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 int64_t *pr = a.prof + ((int64_t)b * a.W + wi) * 8;
                 const long long tend = wall_clock64();
                 long long prev = R.t[0];
+#ifdef SWD_TSPROF
+                const int64_t ts_start = pr[4];
+#endif
 #pragma unroll
                 for (int i = 1; i <= 7; ++i) {
                     const long long cur = R.t[i] ? R.t[i] : prev;
@@ -2501,7 +2574,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 pr[0] += R.t[0] - t_unit0; // ticket, wait for the previous window, state load
 #endif
 #ifdef SWD_TSPROF
-                pr[5] = t_unit0; pr[6] = tend; // absolute ticks of the unit (diagnostic build)
+                pr[5] = t_unit0; pr[6] = tend; pr[4] = ts_start; // absolute ticks: start of the iteration that committed, commit, start of the unit
 #endif
 #ifdef SWD_GDGPROF
                 pr[0] = R.t[2] - R.t[0]; pr[1] = (R.t[3] ? R.t[3] : R.t[2]) - R.t[2];
@@ -2510,6 +2583,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
 #ifdef SWD_BPPROF
                 pr[0] = s.scal[24]; pr[5] = s.scal[25]; pr[6] = s.scal[26]; pr[7] = s.scal[27];
                 pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
+#endif
+#ifdef SWD_INITPROF
+                pr[0] = R.t[0] - t_unit0; pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23]; pr[5] = s.scal[24];
+                pr[6] = tend - R.t[1]; pr[7] = tend - (R.t[7] ? R.t[7] : tend);
 #endif
 #ifdef SWD_SHPROF
                 pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
@@ -2548,7 +2625,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
             if (queued && tid == 0) {
                 if (wi == a.W - 1) { // the shot is finished: admit the next one
                     const uint32_t nb = shots0 + atomicAdd(a.sched, 1u);
-                    if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit((int)nb, 0));
+                    if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit(a.order ? (int)a.order[nb] : (int)nb, 0));
                 }
                 if (atomicAdd(&a.gdgp.q[2], 1u) + 1u == nunits) // the launch's last unit: release every workgroup
                     for (uint32_t k = 0; k < gridDim.x; ++k) ring_push(a.gdgp.q, a.gdgp.qmask, SWD_ITEM_EXIT);

@@ -74,6 +74,33 @@ def test_bb144_gdg_pipeline():
     assert bad.size == 0, f"{bad.size} shots differ: {bad[:8]}"
 
 
+def test_gdg_pipeline_more_shots_than_workgroups():
+    """Launches with more shots than the persistent grid holds start their shots heaviest syndrome first (shot_order_kernel) --
+    parallel form (work items) and serial form (tickets): every shot still gets the reference's recorded result."""
+    import os
+    import slidingwindowdecoder_amd as S
+    from tests.test_gpu_pipeline import load_plan
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    reps = 9  # 1728 shots: more than two (parallel form) or three (serial form) workgroups per CU x 256 CUs
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(192 * reps)
+    det = np.tile(fx.unpack(f["det"], plan.chk.shape[0]), (reps, 1))[perm]
+    want = np.tile(fx.unpack(f["gdg_total"], plan.chk.shape[1]), (reps, 1))[perm]
+    for serial in (False, True):
+        if serial:
+            os.environ["SWD_GDG_SERIAL"] = "1"
+        try:
+            dec = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", **kw)
+        finally:
+            os.environ.pop("SWD_GDG_SERIAL", None)
+        total = dec.decode(det)
+        bad = np.flatnonzero((total != want).any(axis=1))
+        assert bad.size == 0, f"serial={serial}: {bad.size} shots differ: {bad[:8]}"
+
+
 def test_bb288_weight_two_kat():
     """Syndrome code.ipynb cell 6 (see tests/test_kat_syndrome_code.py): the device follows the
     deterministic single-thread search and reproduces its 22 converging syndromes vector for vector."""
