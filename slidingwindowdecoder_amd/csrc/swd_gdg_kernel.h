@@ -247,10 +247,9 @@ __device__ __forceinline__ double gdg_get_pm(const SwdGraphDev &g, Lds &s, const
         if (s.hard[G.pos_lv[j]]) G.plist[pos++] = G.pos_lv[j];
     __syncthreads();
     double *dres = s.dbl;
-    if (threadIdx.x == 0) {
-        double pm = 0;
-        for (int i = 0; i < total; ++i) pm += g.llr[G.plist[i]];
-        *dres = pm;
+    if (threadIdx.x < 64) {
+        const double pm = ordered_llr_sum_wave(g.llr, G.plist, total);
+        if (threadIdx.x == 0) *dres = pm;
     }
     __syncthreads();
     return *dres;
@@ -332,42 +331,67 @@ __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDe
     const double C = 30.0, D = 3.0;
     double best_all = 10000.0, best_neg = 10000.0;
     int pos_all = 0x7fffffff, pos_neg = 0x7fffffff;
-    for (int j = tid; j < new_n; j += NT) {
-        const int v = G.pos_lv[j];
-        uint8_t cat = 0;
-        if (s.vn_val[v] == -1) {
-            const int deg = g.col_deg[v];
-            if (deg > 2) {
-                int num_flip = 0;
-                for (int k = 0; k < deg; ++k) {
-                    const uint32_t e = g.vn_edge[k * n + v];
-                    const int l = swd_edge_lane(e);
-                    if (s.cn_val[l] >= 0 && s.par[l] != 0u) ++num_flip;
-                }
-                bool smaller_A = true, all_neg = true, larger_C = true, larger_D = true;
-                double hsum = 0.0;
+    // two positions per round, every global load of both (edge table rows -- padded beyond a column's degree --, the four
+    // history slots) issued before anything depends on them
+    const int Dg = g.D;
+    for (int jb = tid; jb < new_n; jb += 2 * NT) {
+        int vv[2];
+        bool act[2];
+        uint32_t ev[2][SWD_DMAX];
+        double hl[2][4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double llr = hist_b[i * n + v];
-                    hsum += llr;
-                    if (llr < C) larger_C = false;
-                    if (llr < D) larger_D = false;
-                    if (llr > A) smaller_A = false;
-                    if (llr > 0.0) all_neg = false;
+        for (int u = 0; u < 2; ++u) {
+            const int j = jb + u * NT;
+            const int v = G.pos_lv[min(j, new_n - 1)];
+            vv[u] = v;
+            act[u] = j < new_n && s.vn_val[v] == -1;
+#pragma unroll
+            for (int k = 0; k < SWD_DMAX; ++k) ev[u][k] = (k < Dg) ? g.vn_edge[k * n + v] : SWD_PAD_EDGE; // (k < Dg: uniform)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hl[u][i] = hist_b[i * n + v];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = jb + u * NT;
+            if (j >= new_n) continue;
+            uint8_t cat = 0;
+            if (act[u]) {
+                int deg = 0, num_flip = 0;
+#pragma unroll
+                for (int k = 0; k < SWD_DMAX; ++k) {
+                    const uint32_t e = ev[u][k];
+                    if (e != SWD_PAD_EDGE) {
+                        ++deg;
+                        const int l = swd_edge_lane(e);
+                        if (s.cn_val[l] >= 0 && s.par[l] != 0u) ++num_flip;
+                    }
                 }
-                const bool aggr = !P.low_error_mode;
-                if (aggr && larger_C && depth < 4) cat = 1;                 // decide 0
-                else if (aggr && num_flip >= 3 && larger_D) cat = 1;        // decide 0
-                else if (aggr && smaller_A && hsum < A_sum) cat = 2;        // decide 1
-                else {
-                    cat = 3;
-                    // positions ascend inside a thread, so strict "<" keeps the earliest minimum
-                    if (hsum < best_all) { best_all = hsum; pos_all = j; }
-                    if (all_neg && hsum < best_neg) { best_neg = hsum; pos_neg = j; }
+                if (deg > 2) {
+                    bool smaller_A = true, all_neg = true, larger_C = true, larger_D = true;
+                    double hsum = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double llr = hl[u][i];
+                        hsum += llr;
+                        if (llr < C) larger_C = false;
+                        if (llr < D) larger_D = false;
+                        if (llr > A) smaller_A = false;
+                        if (llr > 0.0) all_neg = false;
+                    }
+                    const bool aggr = !P.low_error_mode;
+                    if (aggr && larger_C && depth < 4) cat = 1;                 // decide 0
+                    else if (aggr && num_flip >= 3 && larger_D) cat = 1;        // decide 0
+                    else if (aggr && smaller_A && hsum < A_sum) cat = 2;        // decide 1
+                    else {
+                        cat = 3;
+                        // positions ascend inside a thread, so strict "<" keeps the earliest minimum
+                        if (hsum < best_all) { best_all = hsum; pos_all = j; }
+                        if (all_neg && hsum < best_neg) { best_neg = hsum; pos_neg = j; }
+                    }
                 }
             }
+            G.cat[j] = cat;
         }
-        G.cat[j] = cat;
     }
     // thresholds of the reference are strict "<" against the running minimum initialised to 10000:
     // a candidate with sum >= 10000 never becomes the minimum
@@ -392,7 +416,7 @@ __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDe
                 const int j = G.plist[i];
                 bad = gdg_set_value_wave(g, s, G.pos_lv[j], G.cat[j] == 2 ? 1 : 0);
             }
-            if (!bad) bad = peel_wave(g, s);
+            if (!bad) bad = peel_wave<false, NT>(g, s);
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();
@@ -448,7 +472,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
     __syncthreads();
     if (tid < 64) {
         bool bad = gdg_set_value_wave(g, s, G.pos_lv[guess_pos], favor);
-        if (!bad) bad = peel_wave(g, s);
+        if (!bad) bad = peel_wave<false, NT>(g, s);
         if (tid == 0) s.scal[1] = bad ? 1 : 0;
     }
     __syncthreads();
@@ -476,7 +500,7 @@ __device__ __forceinline__ int gdg_decimate_reliable(const SwdGraphDev &g, Lds &
     __syncthreads();
     if (tid < 64) {
         bool bad = gdg_set_value_wave(g, s, v, val);
-        if (!bad) bad = peel_wave(g, s);
+        if (!bad) bad = peel_wave<false, NT>(g, s);
         if (tid == 0) s.scal[1] = bad ? 1 : 0;
     }
     __syncthreads();
@@ -665,7 +689,7 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
         gdg_snap_load<NT>(g, s, G, sp.ctx.snap + (int64_t)slot * gdg_snap_bytes(m, new_n));
         if (tid < 64) {
             bool bad = (gpos < 0) ? true : gdg_set_value_wave(g, s, G.pos_lv[gpos], dval);
-            if (!bad) bad = peel_wave(g, s);
+            if (!bad) bad = peel_wave<false, NT>(g, s);
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();
@@ -792,7 +816,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
         __syncthreads();
         if (tid < 64) {
             bool bad = (pos == NONE) ? true : gdg_set_value_wave(g, s, G.pos_lv[pos], val);
-            if (!bad) bad = peel_wave(g, s);
+            if (!bad) bad = peel_wave<false, NT>(g, s);
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();
@@ -1017,7 +1041,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     dead_unsat = block_any<NT>(dead_unsat, s);
     R.t[3] = wall_clock64();
     if (tid < 64) {
-        const bool bad = peel_wave(g, s);
+        const bool bad = peel_wave<false, NT>(g, s);
         if (tid == 0) s.scal[1] = bad ? 1 : 0;
     }
     __syncthreads();
@@ -1144,7 +1168,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         if (tid < 64) {
             const int gp = G.dec_vn[i];
             bool bad = (gp < 0) ? true : gdg_set_value_wave(g, s, G.pos_lv[gp], G.dec_val[i]);
-            if (!bad) bad = peel_wave(g, s);
+            if (!bad) bad = peel_wave<false, NT>(g, s);
             if (tid == 0) s.scal[1] = bad ? 1 : 0;
         }
         __syncthreads();

@@ -885,6 +885,23 @@ __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int 
     __syncthreads();
 }
 
+// llr[list[0]] + llr[list[1]] + ... added one by one in list order (what the reference's loops do), by one wave: the loads of 64
+// entries are in flight together, the additions walk the lanes.  Every lane returns the sum.
+__device__ __forceinline__ double ordered_llr_sum_wave(const double *llr, const uint16_t *list, int total) {
+    const int lane = threadIdx.x & 63;
+    double pm = 0.0;
+    for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        const long long xb = __double_as_longlong((i < total) ? llr[list[i]] : 0.0);
+        const int cnt = min(64, total - base);
+        for (int k = 0; k < cnt; ++k) { // k wave-uniform
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)xb, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(xb >> 32), k);
+            pm += __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        }
+    }
+    return pm;
+}
+
 // sum of llr[v] over hard[v]==1 in ascending v (min_pm, osd_window.pyx:168-169 / 233-235).
 // `list` must hold n u16.  Result valid on every thread.
 template <int NT>
@@ -900,10 +917,9 @@ __device__ __forceinline__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint1
         if (s.hard[v]) list[pos++] = (uint16_t)v;
     __syncthreads();
     double *dres = s.dbl;
-    if (threadIdx.x == 0) {
-        double pm = 0.0;
-        for (int i = 0; i < total; ++i) pm += g.llr[list[i]];
-        *dres = pm;
+    if (threadIdx.x < 64) {
+        const double pm = ordered_llr_sum_wave(g.llr, list, total);
+        if (threadIdx.x == 0) *dres = pm;
     }
     __syncthreads();
     return *dres;
@@ -915,11 +931,11 @@ __device__ __forceinline__ double ordered_pm(const SwdGraphDev &g, Lds &s, uint1
 template <bool D = false>
 __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, int vn, int value) {
     const int lane = threadIdx.x & 63;
-    const int deg = g.col_deg[vn];
+    // (the edge table is padded beyond a column's degree: no load of the degree in front of the edge loads)
+    const uint32_t e = (lane < g.D) ? g.vn_edge[lane * g.n + vn] : SWD_PAD_EDGE;
     if (lane == 0) vn_decide<D>(s, vn, value);
     bool bad = false;
-    if (lane < deg) {
-        const uint32_t e = g.vn_edge[lane * g.n + vn];
+    if (e != SWD_PAD_EDGE) {
         const int l = swd_edge_lane(e), j = swd_edge_j(e);
         int cv = s.cn_val[l];
         if (cv >= 0) {
@@ -941,27 +957,47 @@ __device__ __forceinline__ bool vn_set_value_wave(const SwdGraphDev &g, Lds &s, 
 // peel (osd_window.pyx:306-338) on wave 0, reproducing the reference's sweep order: the next
 // check handled is the lowest original index >= sweep pointer with live degree 1, wrapping to
 // a new sweep when the current one is exhausted.  Returns true on contradiction.
-template <bool D = false>
+template <bool D = false, int NT = SWD_MAX_M> // NT: threads of the workgroup (>= m: bounds the checks per lane)
 __device__ __forceinline__ bool peel_wave(const SwdGraphDev &g, Lds &s) {
     const int lane = threadIdx.x & 63;
     int ptr = 0;
+    // original index << 16 | lane number of the checks this lane scans: loaded when the first sweep finds something to do
+    // (most calls find nothing), kept for the later sweeps of the call; the minimum over the packed word brings the lane
+    // number along with the index
+    constexpr int PW = NT / 64;
+    uint32_t pk[PW];
+    bool loaded = false;
     for (;;) {
-        int best_ge = 0x7fffffff, best_all = 0x7fffffff;
-        for (int l = lane; l < g.m; l += 64) {
-            if (s.cn_val[l] >= 0 && s.cn_deg[l] == 1) {
-                const int c = g.perm[l];
-                best_all = min(best_all, c);
-                if (c >= ptr) best_ge = min(best_ge, c);
+        uint32_t ones = 0; // bit k: check lane + 64 k is live with degree 1
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int l = lane + 64 * k;
+            if (l < g.m && s.cn_val[l] >= 0 && s.cn_deg[l] == 1) ones |= 1u << k;
+        }
+        if (__ballot(ones != 0u) == 0ull) return false;
+        if (!loaded) {
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                const int l = lane + 64 * k;
+                pk[k] = (64 * k < g.m) ? (((uint32_t)g.perm[min(l, g.m - 1)] << 16) | (uint32_t)l) : 0u; // (64 k < m: wave-uniform)
+            }
+            loaded = true;
+        }
+        uint32_t best_ge = 0xFFFFFFFFu, best_all = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            if ((ones >> k) & 1u) {
+                best_all = min(best_all, pk[k]);
+                if ((int)(pk[k] >> 16) >= ptr) best_ge = min(best_ge, pk[k]);
             }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
-            best_ge = min(best_ge, __shfl_xor(best_ge, d, 64));
-            best_all = min(best_all, __shfl_xor(best_all, d, 64));
+            best_ge = min(best_ge, (uint32_t)__shfl_xor((int)best_ge, d, 64));
+            best_all = min(best_all, (uint32_t)__shfl_xor((int)best_all, d, 64));
         }
-        if (best_all == 0x7fffffff) return false;
-        const int c = (best_ge != 0x7fffffff) ? best_ge : best_all;
-        const int l = g.iperm[c];
+        const uint32_t pick = (best_ge != 0xFFFFFFFFu) ? best_ge : best_all;
+        const int c = (int)(pick >> 16), l = (int)(pick & 0xFFFFu);
         const uint64_t mk = lm_get<D>(s, l);
         const int j = __ffsll((long long)mk) - 1;
         const int vn = g.row_col[s.jptr[j] + l];
@@ -2019,7 +2055,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
             }
             __syncthreads();
             if (tid < 64) {
-                const bool b2 = peel_wave<DIET>(g, s);
+                const bool b2 = peel_wave<DIET, NT>(g, s);
                 if (tid == 0) s.scal[1] = b2 ? 1 : 0;
             }
         } else if (tid == 0) s.scal[1] = 0;
