@@ -96,6 +96,13 @@ __device__ __forceinline__ uint32_t *gdg_rec(const GdgCtx &c, int slot) { return
 #else
 #define GDG_COUNT(word, v) do { } while (0)
 #endif
+#ifdef SWD_SELPROF // diagnostic build: 100 MHz ticks inside select_vn / the cache rebuild, summed per unit in s.scal[20..27]
+#define SEL_T0() long long sel_t_ = wall_clock64()
+#define SEL_T(k) do { const long long sel_n_ = wall_clock64(); if (threadIdx.x == 0) s.scal[20 + (k)] += (int)(sel_n_ - sel_t_); sel_t_ = sel_n_; } while (0)
+#else
+#define SEL_T0() do { } while (0)
+#define SEL_T(k) do { } while (0)
+#endif
 #ifdef SWD_GDG_CHECKS // diagnostic build: invariant violations are reported in the status word (bits 8..) instead of followed
 #define GDG_CHECK(cond, code) do { if (!(cond)) atomicOr(chk_status, 1u << (8 + (code))); } while (0)
 #else
@@ -196,18 +203,137 @@ __device__ __forceinline__ void block_argmin(double &key, int &pos, Lds &s) {
     __syncthreads();
 }
 
+// two lexicographic minima at once (same barriers as one)
+template <int NT>
+__device__ __forceinline__ void block_argmin2(double &k1, int &p1, double &k2, int &p2, Lds &s) {
+    if constexpr (NT / 64 > 8) { // (the per-wave staging area holds 16 keys)
+        block_argmin<NT>(k1, p1, s);
+        block_argmin<NT>(k2, p2, s);
+    } else {
+        constexpr int NW = NT / 64;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const double o1 = __shfl_xor(k1, d, 64), o2 = __shfl_xor(k2, d, 64);
+            const int q1 = __shfl_xor(p1, d, 64), q2 = __shfl_xor(p2, d, 64);
+            if (o1 < k1 || (o1 == k1 && q1 < p1)) { k1 = o1; p1 = q1; }
+            if (o2 < k2 || (o2 == k2 && q2 < p2)) { k2 = o2; p2 = q2; }
+        }
+        double *wk = s.dbl + 4; // [16]: first keys, then second keys
+        int *wp = s.iaux;       // [16]
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            wk[w] = k1; wp[w] = p1; wk[NW + w] = k2; wp[NW + w] = p2;
+        }
+        __syncthreads();
+        double b1 = wk[0], b2 = wk[NW];
+        int c1 = wp[0], c2 = wp[NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const double o1 = wk[w], o2 = wk[NW + w];
+            const int q1 = wp[w], q2 = wp[NW + w];
+            if (o1 < b1 || (o1 == b1 && q1 < c1)) { b1 = o1; c1 = q1; }
+            if (o2 < b2 || (o2 == b2 && q2 < c2)) { b2 = o2; c2 = q2; }
+        }
+        k1 = b1; p1 = c1; k2 = b2; p2 = c2;
+        __syncthreads();
+    }
+}
+
 // Compact the still-active selected VNs (position order) into s.lv and (re)build the per-phase
 // register caches.  Messages are untouched (they persist across decimation steps, bpgd.cpp:97-197).
 // BP register caches of the guessing decoders: 16-bit slot numbers, two per register, classic parity words
 template <int VF, int DM> using GdgVC = VnCacheP<VF, DM, 3, false>;
 template <int KG> using GdgCC = CnCacheP<KG, 3>;
 
+// The check cache of a lane straight from the check's live-position mask (one thread per check, every live position in walk
+// order): slot of position j = jptr[j] + lane.  Groups of four beyond the wave's largest live degree are filled without
+// looking at the mask.
+template <int NT, int KG, int SH>
+__device__ __forceinline__ void gdg_cn_cache_from_mask(const SwdGraphDev &g, Lds &s, int lc, CnCacheP<KG, SH> &cc) {
+    const int dummy = swd_slot_far(g);
+    const bool act = (lc >= 0) && (lc < g.m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
+    const int l = act ? lc : 0;
+    cc.l = act ? lc : -1;
+    cc.sub = 0;
+    cc.grp = 1;
+    uint64_t mk = act ? s.livemask[l] : 0ull;
+    const int cnt = act ? (int)s.cn_deg[l] : 0;
+    cc.cnt = cnt;
+    cc.live = cnt;
+    const int wmax = __builtin_amdgcn_readfirstlane(wave_max(cnt));
+#pragma unroll
+    for (int gq = 0; gq < KG; ++gq) {
+        if (gq * 4 < wmax) { // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int sv = dummy;
+                if (mk) {
+                    const int j = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    sv = (int)s.jptr[j] + l;
+                }
+                cc.set_slot(gq * 4 + u, sv);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cc.set_slot(gq * 4 + u, dummy);
+        }
+    }
+}
+
+// Static form of the shortened graph's node cache (depth-2 caches: new_n <= 2 NT): position vtid + i NT belongs to this thread
+// for the whole tree walk, with EVERY edge of its column (gdg_static_load, one gather per window / task); after a decimation
+// the working cache is re-derived from it and the state arrays in LDS -- a decided node or an edge to a deactivated check
+// turns into dead positions -- without compaction, prefix sums or loads from the graph in HBM.  The node list then holds n
+// at the places of decided nodes (bp_run<..., SPARSE>).
+struct GdgNoStatic {};
+template <int NT, int VF, int DM>
+__device__ __forceinline__ void gdg_static_load(const SwdGraphDev &g, Lds &s, const GdgLds &G, GdgVC<VF, DM> &st) {
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        if (idx < g.new_n) s.lv[idx] = G.pos_lv[idx]; // (read back by this thread only)
+    }
+    vn_cache_load<NT, VF, DM, false, true>(g, s, g.new_n, st);
+}
+template <int NT, int VF, int DM, int KG>
+__device__ __forceinline__ int gdg_refresh_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, const GdgVC<VF, DM> &st, GdgVC<VF, DM> &vc, GdgCC<KG> &cn) {
+    const int m = g.m, n = g.n, new_n = g.new_n;
+    const uint32_t deadslot = (uint32_t)swd_slot_zero<NT>(g);
+    SEL_T0();
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        const bool inr = idx < new_n;
+        const int v = inr ? (int)G.pos_lv[idx] : 0;
+        const bool alive = inr && s.vn_val[v] == -1;
+        if (inr) s.lv[idx] = (uint16_t)(alive ? v : n);
+        vc.llr[i] = alive ? st.llr[i] : 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < DM / 2; ++k2) {
+            const uint32_t pw = st.par[i][k2], ew = st.edp[i][k2];
+            const int l0 = (int)(pw & 0xFFFFu), l1 = (int)(pw >> 16);
+            const bool live0 = alive && l0 < m && s.cn_val[min(l0, m - 1)] >= 0;
+            const bool live1 = alive && l1 < m && s.cn_val[min(l1, m - 1)] >= 0;
+            vc.edp[i][k2] = (live0 ? (ew & 0xFFFFu) : deadslot) | ((live1 ? (ew >> 16) : deadslot) << 16);
+            vc.par[i][k2] = (uint32_t)(live0 ? l0 : m) | ((uint32_t)(live1 ? l1 : m) << 16);
+        }
+    }
+    SEL_T(6);
+    gdg_cn_cache_from_mask<NT>(g, s, s.ctid < m ? s.ctid : -1, cn);
+    __syncthreads();
+    SEL_T(7);
+    return new_n;
+}
+
 template <int NT, int VF, int DM, int KG, class VC, class CC>
 __device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, VC &vc, CC &cn) {
-    const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
+    const int tid = threadIdx.x, new_n = g.new_n;
     const int ch = (new_n + NT - 1) / NT;
     const int j0 = tid * ch, j1 = min(new_n, j0 + ch);
     int cnt = 0;
+    SEL_T0();
     for (int j = j0; j < j1; ++j) cnt += (s.vn_val[G.pos_lv[j]] == -1) ? 1 : 0;
     int nlive;
     int pos = block_exscan<NT>(cnt, s, nlive);
@@ -215,22 +341,29 @@ __device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, co
         const int v = G.pos_lv[j];
         if (s.vn_val[v] == -1) s.lv[pos++] = (uint16_t)v;
     }
-    for (int l = tid; l < m; l += NT)
-        if (s.cn_val[l] >= 0) {
-            uint64_t mk = s.livemask[l];
-            int k = 0;
-            while (mk) {
-                const int j = __ffsll((long long)mk) - 1;
-                mk &= mk - 1;
-                s.lslot[k * m + l] = (uint16_t)(s.jptr[j] + l);
-                ++k;
-            }
-        }
     __syncthreads();
+    SEL_T(5);
     vn_cache_load<NT, VF, DM, false>(g, s, nlive, vc);
-    cn_cache_load<NT, KG, false>(g, s, true, s.ctid < g.m ? s.ctid : -1, 0, 1, cn);
+#ifdef SWD_SELPROF
+    asm volatile("" : "+v"(vc.edp[0][0]), "+v"(vc.llr[0]));
+#endif
+    SEL_T(6);
+    gdg_cn_cache_from_mask<NT>(g, s, s.ctid < g.m ? s.ctid : -1, cn);
     __syncthreads();
+    SEL_T(7);
     return nlive;
+}
+
+// the static cache type of a tree walk with register caches of depth VF, and the cache (re)build that goes with it
+template <int VF, int DM> using GdgStatic = std::conditional_t<(VF <= 2), GdgVC<(VF <= 2 ? VF : 1), DM>, GdgNoStatic>;
+template <int NT, int VF, int DM, int KG, class ST>
+__device__ __forceinline__ int gdg_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, const ST &st, GdgVC<VF, DM> &vc, GdgCC<KG> &cn) {
+    if constexpr (std::is_same_v<ST, GdgNoStatic>) return gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
+    else return gdg_refresh_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn);
+}
+template <int NT, int VF, int DM, class ST>
+__device__ __forceinline__ void gdg_static_init(const SwdGraphDev &g, Lds &s, const GdgLds &G, ST &st) {
+    if constexpr (!std::is_same_v<ST, GdgNoStatic>) gdg_static_load<NT, VF, DM>(g, s, G, st);
 }
 
 // get_pm (bpgd.cpp:250-256): sum of llr_prior over error == 1 in POSITION order
@@ -324,13 +457,77 @@ struct GdgSpec {
 // them, and the candidate to guess -- shared by the Cython routine above and by BPGD::select_vn (bpgd.cpp:288-355, thresholds
 // A / A_sum of the calling thread; C = 30, D = 3).  Returns -1 when a decimation or the peeling fails; else guess_pos (0x7fffffff:
 // no candidate) and the favoured value.
-template <int NT>
+template <int NT, class ST = GdgNoStatic>
 __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
-                                               const double *hist_b, double A, double A_sum, int depth, int &guess_pos, int &favor) {
+                                               const double *hist_b, double A, double A_sum, int depth, int &guess_pos, int &favor,
+                                               const ST &st = ST{}) {
     const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
     const double C = 30.0, D = 3.0;
     double best_all = 10000.0, best_neg = 10000.0;
     int pos_all = 0x7fffffff, pos_neg = 0x7fffffff;
+    SEL_T0();
+    // classification of one active position from the four history values, its degree and its number of unsatisfied live checks
+    auto classify = [&](int j, const double (&hl)[4], int deg, int num_flip) {
+        uint8_t cat = 0;
+        if (deg > 2) {
+            bool smaller_A = true, all_neg = true, larger_C = true, larger_D = true;
+            double hsum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double llr = hl[i];
+                hsum += llr;
+                if (llr < C) larger_C = false;
+                if (llr < D) larger_D = false;
+                if (llr > A) smaller_A = false;
+                if (llr > 0.0) all_neg = false;
+            }
+            const bool aggr = !P.low_error_mode;
+            if (aggr && larger_C && depth < 4) cat = 1;                 // decide 0
+            else if (aggr && num_flip >= 3 && larger_D) cat = 1;        // decide 0
+            else if (aggr && smaller_A && hsum < A_sum) cat = 2;        // decide 1
+            else {
+                cat = 3;
+                // positions ascend inside a thread, so strict "<" keeps the earliest minimum
+                if (hsum < best_all) { best_all = hsum; pos_all = j; }
+                if (all_neg && hsum < best_neg) { best_neg = hsum; pos_neg = j; }
+            }
+        }
+        return cat;
+    };
+    if constexpr (!std::is_same_v<ST, GdgNoStatic>) {
+        // the thread's own positions (static cache: every edge of the column, check numbers in the parity fields)
+        constexpr int VFS = (int)(sizeof(st.llr) / sizeof(double)), DMS = (int)(sizeof(st.edp[0]) / sizeof(uint32_t)) * 2;
+        int vv[VFS];
+        bool act[VFS];
+        double hl[VFS][4];
+#pragma unroll
+        for (int u = 0; u < VFS; ++u) {
+            const int j = s.vtid + u * NT;
+            vv[u] = G.pos_lv[min(j, new_n - 1)];
+            act[u] = j < new_n && s.vn_val[vv[u]] == -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hl[u][i] = hist_b[i * n + vv[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < VFS; ++u) {
+            const int j = s.vtid + u * NT;
+            if (j >= new_n) continue;
+            uint8_t cat = 0;
+            if (act[u]) {
+                int deg = 0, num_flip = 0;
+#pragma unroll
+                for (int k = 0; k < DMS; ++k) {
+                    const int l = (int)((st.par[u][k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                    if (l < g.m) {
+                        ++deg;
+                        if (s.cn_val[l] >= 0 && s.par[l] != 0u) ++num_flip;
+                    }
+                }
+                cat = classify(j, hl[u], deg, num_flip);
+            }
+            G.cat[j] = cat;
+        }
+    } else {
     // two positions per round, every global load of both (edge table rows -- padded beyond a column's degree --, the four
     // history slots) issued before anything depends on them
     const int Dg = g.D;
@@ -366,78 +563,61 @@ __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDe
                         if (s.cn_val[l] >= 0 && s.par[l] != 0u) ++num_flip;
                     }
                 }
-                if (deg > 2) {
-                    bool smaller_A = true, all_neg = true, larger_C = true, larger_D = true;
-                    double hsum = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double llr = hl[u][i];
-                        hsum += llr;
-                        if (llr < C) larger_C = false;
-                        if (llr < D) larger_D = false;
-                        if (llr > A) smaller_A = false;
-                        if (llr > 0.0) all_neg = false;
-                    }
-                    const bool aggr = !P.low_error_mode;
-                    if (aggr && larger_C && depth < 4) cat = 1;                 // decide 0
-                    else if (aggr && num_flip >= 3 && larger_D) cat = 1;        // decide 0
-                    else if (aggr && smaller_A && hsum < A_sum) cat = 2;        // decide 1
-                    else {
-                        cat = 3;
-                        // positions ascend inside a thread, so strict "<" keeps the earliest minimum
-                        if (hsum < best_all) { best_all = hsum; pos_all = j; }
-                        if (all_neg && hsum < best_neg) { best_neg = hsum; pos_neg = j; }
-                    }
-                }
+                cat = classify(j, hl[u], deg, num_flip);
             }
             G.cat[j] = cat;
         }
+    }
     }
     // thresholds of the reference are strict "<" against the running minimum initialised to 10000:
     // a candidate with sum >= 10000 never becomes the minimum
     if (!(best_all < 10000.0)) { best_all = 10000.0; pos_all = 0x7fffffff; }
     if (!(best_neg < 10000.0)) { best_neg = 10000.0; pos_neg = 0x7fffffff; }
-    block_argmin<NT>(best_all, pos_all, s);
-    block_argmin<NT>(best_neg, pos_neg, s);
-    // ordered queue of the aggressive decimations
-    {
-        const int ch = (new_n + NT - 1) / NT;
-        const int j0 = tid * ch, j1 = min(new_n, j0 + ch);
-        int cnt = 0;
-        for (int j = j0; j < j1; ++j) cnt += (G.cat[j] == 1 || G.cat[j] == 2) ? 1 : 0;
-        int total;
-        int pos = block_exscan<NT>(cnt, s, total);
-        for (int j = j0; j < j1; ++j)
-            if (G.cat[j] == 1 || G.cat[j] == 2) G.plist[pos++] = (uint16_t)j;
-        __syncthreads();
-        if (tid < 64) {
-            bool bad = false;
-            for (int i = 0; i < total && !bad; ++i) {
-                const int j = G.plist[i];
-                bad = gdg_set_value_wave(g, s, G.pos_lv[j], G.cat[j] == 2 ? 1 : 0);
-            }
-            if (!bad) bad = peel_wave<false, NT>(g, s);
-            if (tid == 0) s.scal[1] = bad ? 1 : 0;
+    SEL_T(0);
+    block_argmin2<NT>(best_all, pos_all, best_neg, pos_neg, s); // (its barriers also publish G.cat)
+    SEL_T(1);
+    // the aggressive decimations in position order, then the peeling: wave 0 walks the classification itself (lane q owns the
+    // positions [q CH, (q + 1) CH); the next one to apply is the smallest pending position of the first lane that has any)
+    if (tid < 64) {
+        const int CH = (new_n + 63) >> 6, jend = min(new_n, (tid + 1) * CH);
+        auto pending = [&](int from) { // smallest position >= from of this lane's chunk that is to be decimated
+            for (int j = from; j < jend; ++j) { const uint8_t c = G.cat[j]; if (c == 1 || c == 2) return j; }
+            return 0x7fffffff;
+        };
+        int next = pending(tid * CH);
+        bool bad = false;
+        for (;;) {
+            const unsigned long long have = __ballot(next != 0x7fffffff);
+            if (have == 0ull) break;
+            const int src = __ffsll((long long)have) - 1;
+            const int j = __builtin_amdgcn_readlane(next, src);
+            bad = gdg_set_value_wave(g, s, G.pos_lv[j], G.cat[j] == 2 ? 1 : 0);
+            if (bad) break;
+            if (tid == src) next = pending(j + 1);
         }
-        __syncthreads();
-        if (s.scal[1]) return -1;
+        if (!bad) bad = peel_wave<false, NT>(g, s);
+        if (tid == 0) s.scal[1] = bad ? 1 : 0;
     }
+    __syncthreads();
+    SEL_T(2);
+    if (s.scal[1]) return -1;
     if (pos_neg != 0x7fffffff) { guess_pos = pos_neg; favor = 1; }
     else { guess_pos = pos_all; favor = (best_all > 0) ? 0 : 1; }
     return 0;
 }
 
-template <int NT>
+template <int NT, class ST = GdgNoStatic>
 __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                              const double *hist_b, bool side, int depth, int min_converge_depth,
-                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr) {
+                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr, const ST &st = ST{}) {
     const int tid = threadIdx.x, new_n = g.new_n;
     const double A = side ? 0.0 : -3.0;
     double A_sum = side ? -10.0 : -12.0;
     if (depth == 0) A_sum = -16.0;
     int guess_pos, favor;
-    if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, guess_pos, favor) == -1) { if (sp) sp->fail_before = 1; return -1; }
+    if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, guess_pos, favor, st) == -1) { if (sp) sp->fail_before = 1; return -1; }
     bool guess = true;
+    SEL_T0();
     if (depth > min_converge_depth) guess = false;
     if (!side && depth >= P.max_side_depth) guess = false;
     if (side && depth > P.max_tree_depth) guess = false;
@@ -467,6 +647,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
         gdg_snap_save<NT>(g, s, G, snap_b + (int64_t)used_guess * gdg_snap_bytes(g.m, new_n));
         used_guess += 1;
     }
+    SEL_T(3);
     if (sp) sp->fail_after = 1; // cleared below when the favoured value goes through
     if (guess_pos == 0x7fffffff) return -1; // no candidate left (the reference would index vn_mask[-1])
     __syncthreads();
@@ -476,6 +657,7 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
         if (tid == 0) s.scal[1] = bad ? 1 : 0;
     }
     __syncthreads();
+    SEL_T(4);
     if (sp && !s.scal[1]) sp->fail_after = 0;
     return s.scal[1] ? -1 : 0;
 }
@@ -697,13 +879,16 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
         if (!start_failed) {
             GdgVC<VFP, DM> vc;
             GdgCC<KG> cn;
+            using ST = GdgStatic<VFP, DM>;
+            ST vst;
+            gdg_static_init<NT, VFP, DM>(g, s, G, vst);
             const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
             for (int j = 0; j < maxj; ++j) {
                 const int depth = alt + j;
-                const int nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vc, cn);
+                const int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vc, cn);
                 if (j == 0) { bp_init<VFP, DM>(s, vc); __syncthreads(); }
                 int it;
-                const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+                const int cv = bp_run<NT, VFP, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
                 uint32_t sw = (uint32_t)it & 0xFFu;
                 nsteps = j + 1;
                 if (cv) {
@@ -722,7 +907,7 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
                 if (depth > bound + 2) { if (tid == 0) ag_st(&rec[4 + j], sw); break; }
                 sp.fail_before = sp.fail_after = 0; sp.child = -1;
                 int dummy = 0;
-                const int rc = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, bound, dummy, nullptr, &sp);
+                const int rc = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, bound, dummy, nullptr, &sp, vst);
                 sw |= (sp.fail_before ? 0x100u : 0u) | (sp.fail_after ? 0x200u : 0u) | ((uint32_t)(sp.child + 1) << 16);
                 if (tid == 0) ag_st(&rec[4 + j], sw);
                 if (rc == -1) break;
@@ -794,10 +979,10 @@ __device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDeco
 //   side   thresholds (0, -10): the handed-over masks, messages = priors, the unfavoured value, max_side_branch_step steps
 // Snapshot slots in snap_b: 0 = state after BPGD::reset, 1 = the tree thread's saved masks, 2 + j = side thread j's.
 // Entered with the state after reset (peeled, caches built, messages initialised).  Leaves the winner in G.best_err.
-template <int NT, int VF, int DM, int KG>
+template <int NT, int VF, int DM, int KG, class ST>
 __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                                  double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
-                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn) { // (VF here = the caller's post-phase depth)
+                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const ST &st) { // (VF here = the caller's post-phase depth)
     const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
     const int Dp = P.max_tree_depth, S = P.max_side_depth;
     const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
@@ -806,9 +991,9 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
     double best = 10000.0;
     int winner = -1, ties = 0, blocks = 0, ran = 1, it = 0;
     auto block = [&](bool first) { // one min_sum_log call (bpgd.cpp:97-197); first: the messages start from the priors
-        const int nlive = gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
+        const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn);
         if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
-        const int cv = bp_run<NT, VF, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        const int cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
         ++blocks; R.post_it += it;
         return cv;
     };
@@ -841,7 +1026,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
     for (int depth = 0; depth < P.max_step; ++depth) {
         const int cv = block(false);
         int gpos = NONE, favor = 0;
-        const int rc = gdg_select_core<NT>(g, P, s, G, hist_b, -3.0, depth == 0 ? -16.0 : -12.0, depth, gpos, favor);
+        const int rc = gdg_select_core<NT>(g, P, s, G, hist_b, -3.0, depth == 0 ? -16.0 : -12.0, depth, gpos, favor, st);
         if (cv || rc == -1 || gpos == NONE) {
             if (cv) { main_conv = true; offer(0); }
             break;
@@ -870,7 +1055,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
             if (depth > 0 && !on_side) A_sum = -12.0;
             if (block(depth == 0)) { own_pm = offer(id); done = true; break; }
             int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor) == -1 || gpos == NONE) break;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st) == -1 || gpos == NONE) break;
             if (depth < Dp) {
                 if ((id >> (Dp - 1 - depth)) & 1) { on_side = true; A = 0.0; A_sum = -10.0; favor = 1 - favor; }
             } else if (depth == Dp) {
@@ -890,7 +1075,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
                 break;
             }
             int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor) == -1 || gpos == NONE) break;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st) == -1 || gpos == NONE) break;
             if (set_value(gpos, favor)) break;
             ++depth;
         }
@@ -905,7 +1090,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
         for (int i = 0; i < P.max_side_branch_step; ++i) {
             if (block(i == 0)) { offer(1 + T + j); break; }
             int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, 0.0, -10.0, depth, gpos, favor) == -1 || gpos == NONE) break;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, 0.0, -10.0, depth, gpos, favor, st) == -1 || gpos == NONE) break;
             if (set_value(gpos, favor)) break;
             ++depth;
         }
@@ -1054,13 +1239,17 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         return;
     }
     GdgVC<VFP, DM> vcp; // the shortened graph's cache (the full graph's is dead from here on)
-    int nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+    using ST = GdgStatic<VFP, DM>;
+    constexpr bool SPARSE = !std::is_same_v<ST, GdgNoStatic>;
+    ST vst;
+    gdg_static_init<NT, VFP, DM>(g, s, G, vst);
+    int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
     bp_init<VFP, DM>(s, vcp);
     __syncthreads();
     if constexpr (ENS) {
         for (int j = tid; j < SWD_GDG_MAXGUESS; j += NT) G.alt_depth[j] = -1;
         __syncthreads();
-        gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn);
+        gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst);
         for (int v = tid; v < n; v += NT) s.hard[v] = 0;
         __syncthreads();
         for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
@@ -1095,9 +1284,9 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     // ---- phase 1: main branch
     GPT0();
     for (int depth = 0; depth < P.max_step; ++depth) {
-        if (depth > 0) nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+        if (depth > 0) nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
         GPT(0);
-        const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
         GPT(1);
         ++blocks; R.post_it += it;
         if (cv) {
@@ -1107,7 +1296,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
             GPT(4);
             break;
         }
-        const int rc = gdg ? gdg_select_vn<NT>(g, P, s, G, hist_b, false, depth, min_converge_depth, used_guess, snap_b)
+        const int rc = gdg ? gdg_select_vn<NT>(g, P, s, G, hist_b, false, depth, min_converge_depth, used_guess, snap_b, nullptr, vst)
                            : gdg_decimate_reliable<NT>(g, s, G, hist_b);
         GPT(2);
         if (rc == -1) break;
@@ -1176,10 +1365,10 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         if (s.scal[1]) continue;
         for (int j = 0; j < P.max_side_branch_step; ++j) {
             depth = G.alt_depth[i] + j;
-            nlive = gdg_build_caches<NT, VFP, DM, KG>(g, s, G, vcp, cn);
+            nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
             if (j == 0) { bp_init<VFP, DM>(s, vcp); __syncthreads(); } // set_masks re-initialises the messages
             GPT(0);
-            const int cv = bp_run<NT, VFP, DM, KG, false>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
+            const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
             GPT(1);
             ++blocks; R.post_it += it;
             if (cv) {
@@ -1193,7 +1382,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
                 break;
             }
             if (depth > min_converge_depth + 2) break;
-            const int rc2 = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, min_converge_depth, used_guess, snap_b);
+            const int rc2 = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, min_converge_depth, used_guess, snap_b, nullptr, vst);
             GPT(2);
             if (rc2 == -1) break;
         }

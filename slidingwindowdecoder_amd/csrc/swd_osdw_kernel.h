@@ -323,7 +323,8 @@ __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E 
 // wave touch consecutive cells in the variable-node pass -- and remap[old slot] = cell for the check side (g.E = D * nlive here).
 // All global loads are issued unconditionally and before anything depends on them (the edge table is padded with SWD_PAD_EDGE
 // beyond a column's degree, rows beyond g.D do not exist: clamped): one memory latency per call instead of two per variable node.
-template <int NT, int VF, int DM, bool FULL, int SH, bool PB>
+// ALLEDGES (with !FULL): the listed nodes with every edge of theirs, whatever the state of the checks.
+template <int NT, int VF, int DM, bool FULL, bool ALLEDGES = false, int SH, bool PB>
 __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr) {
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
@@ -350,7 +351,7 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
         for (int k = 0; k < DM; ++k) {
             const uint32_t e = ev[i][k];
             if (valid && k < D && e != SWD_PAD_EDGE) {
-                if (FULL || s.cn_val[swd_edge_lane(e)] >= 0) {
+                if (FULL || ALLEDGES || s.cn_val[swd_edge_lane(e)] >= 0) {
                     uint32_t slot = swd_edge_slot(e);
                     if (!FULL && remap) { const uint32_t cell = (uint32_t)(k * nlive + idx); remap[slot] = (uint16_t)cell; slot = cell; }
                     c.set_ed(i, k, slot << 3);
@@ -537,7 +538,9 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // that order and the 4 x n ring in HBM is neither written nor read.
 // One routine for every kernel: the register caches keep LDS offsets packed two per register (unpacked where they are used);
 // PB: one parity byte per check, flipped by word atomics (tuned kernels of up to 256 threads), else one parity word.
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, int SH, bool PB>
+// SPARSE (with !FULL): the node list may hold n = "no node here" (the guessing decoders keep a position's thread for the whole
+// tree walk instead of compacting the live nodes after every decimation).
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr) {
@@ -694,8 +697,9 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         for (int i = 0; i < VF; ++i) {
             if (i < nch) { // wave-uniform
                 const int idx = s.vtid + i * NT;
-                const bool valid = idx < vcnt;
+                bool valid = idx < vcnt;
                 const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
+                if constexpr (SPARSE) valid = v < n;
                 double cc[DM], pre[DM];
                 uint32_t ad[DM];
                 c.get_ed(i, ad);
@@ -2498,6 +2502,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         const SwdLdsLayout &L = w.L;
         lds_bind(s, smem, L, BIG ? (char *)(a.big + (int64_t)blockIdx.x * a.big_stride) : smem);
         WinResult R;
+#ifdef SWD_SELPROF
+        if (tid < 8) s.scal[20 + tid] = 0;
+        __syncthreads();
+#endif
 #ifdef SWD_BPPROF
         if (tid == 0) { s.scal[24] = s.scal[25] = s.scal[26] = s.scal[27] = 0; s.scal[20] = s.scal[21] = s.scal[22] = 0; }
 #endif
@@ -2623,6 +2631,9 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
 #ifdef SWD_INITPROF
                 pr[0] = R.t[0] - t_unit0; pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23]; pr[5] = s.scal[24];
                 pr[6] = tend - R.t[1]; pr[7] = tend - (R.t[7] ? R.t[7] : tend);
+#endif
+#ifdef SWD_SELPROF
+                for (int k = 0; k < 8; ++k) { pr[k] = s.scal[20 + k]; s.scal[20 + k] = 0; }
 #endif
 #ifdef SWD_SHPROF
                 pr[1] = s.scal[20]; pr[2] = s.scal[21]; pr[3] = s.scal[22]; pr[4] = s.scal[23];
