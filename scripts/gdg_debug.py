@@ -35,7 +35,8 @@ def run(dec):
         if c[1]:
             print(f"  tasks {c[1]} (pruned at start {c[5]}), steps {c[4]}, task ms total {c[2] / 1e5:.1f} ({c[2] / 1e2 / max(c[1], 1):.0f} us each), "
                   f"scheduler ms total {c[3] / 1e5:.1f} ({c[3] / 1e2 / max(c[1], 1):.0f} us each); loop: empty polls {c[6]}, items {c[7]}, "
-                  f"get-work ms {c[8] / 1e5:.1f}; until state loaded {c[13] / 1e2 / max(c[14], 1):.0f} us per unit; units parked {c[9]} ({c[11] / 1e2 / max(c[9], 1):.0f} us each), inline {c[10]} ({c[12] / 1e2 / max(c[10], 1):.0f} us each)")
+                  f"get-work ms {c[8] / 1e5:.1f}; until state loaded {c[13] / 1e2 / max(c[14], 1):.0f} us per unit; units parked {c[9]} ({c[11] / 1e2 / max(c[9], 1):.0f} us each), inline {c[10]} ({c[12] / 1e2 / max(c[10], 1):.0f} us each); "
+                  f"waits for an item longer than 50 us: {c[6]}, {c[15] / 1e5:.1f} ms in total")
     try:
         dec.check_status()
     except RuntimeError as e:

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Sub-phase split of the shortening step (diagnostic build libswd_hip_bpprof.so built with -DSWD_SHPROF)."""
+"""Sub-phase split of the shortening step (diagnostic build: SWD_DEV_OUT=libswd_hip_dev.so scripts/devbuild.sh -DSWD_SHPROF,
+SWD_LIB=libswd_hip_dev.so)."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slidingwindowdecoder_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libswd_hip_bpprof.so")
+if os.environ.get("SWD_LIB"): _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["SWD_LIB"])
 import bench
 from slidingwindowdecoder_amd import SlidingWindowDecoder
 from slidingwindowdecoder_amd.windows import sample_dem

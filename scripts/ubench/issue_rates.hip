@@ -3,6 +3,9 @@
 //   mix 0: 32 v_add_f64            mix 1: 16 v_add_f64 + 16 s_add_u32 (interleaved)      mix 2: 32 s_add_u32
 //   mix 3: 24 v_add_f64 + 8 ds_read_b64 (one waitcnt per block)          mix 4: 32 v_add_u32 (32-bit VALU)
 //   mix 5: 32 ds_read_b64 (waitcnt per 8)   mix 6: 32 ds_write_b64   mix 7: 16 ds_read_b64 + 16 ds_write_b64 (the BP passes' LDS mix)
+//   mix 8: 32 ds_read_b128                  mix 9: what a "one record per check" check pass would issue for the same 8 edges as
+//   mix 7: 8 + 8 ds_read_b64 (check pass reads; variable-node pass re-reads its own messages) + 8 ds_read_b128 (the checks' records:
+//   two minima) + 8 ds_write_b64 (variable-node pass) + 1 ds_write_b128 (one record per ~8 edges) = 33 instructions
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -63,6 +66,26 @@ __global__ void __launch_bounds__(1024) k(long long *cycles, double *sink) {
                 asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:512\n ds_read_b64 %0, %2 offset:1024\n ds_read_b64 %1, %2 offset:1536\n s_waitcnt lgkmcnt(0)\n"
                              "ds_write_b64 %2, %3 offset:2048\n ds_write_b64 %2, %3 offset:2560\n ds_write_b64 %2, %3 offset:3072\n ds_write_b64 %2, %3 offset:3584\n s_waitcnt lgkmcnt(0)\n"
                              : "=&v"(l0), "=&v"(l1) : "v"(la), "v"(a1) : "memory");
+        } else if constexpr (MIX == 8) {
+            double q0, q1, q2, q3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n ds_read_b128 %0, %2 offset:2048\n ds_read_b128 %1, %2 offset:3072\n"
+                             "ds_read_b128 %0, %2 offset:4096\n ds_read_b128 %1, %2 offset:5120\n ds_read_b128 %0, %2 offset:6144\n ds_read_b128 %1, %2 offset:7168\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(*(__attribute__((ext_vector_type(2))) double *)&q0), "=&v"(*(__attribute__((ext_vector_type(2))) double *)&q2) : "v"(la * 2));
+            (void)q1; (void)q3;
+        } else if constexpr (MIX == 9) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 q0, q1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                asm volatile("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:512\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(l0), "=&v"(l1) : "v"(la));
+                asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b64 %2, %5 offset:2048\n ds_read_b64 %3, %5 offset:2560\n s_waitcnt lgkmcnt(0)\n"
+                             "ds_write_b64 %5, %6 offset:3072\n ds_write_b64 %5, %6 offset:3584\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(l0), "=&v"(l1) : "v"(la * 2), "v"(la), "v"(a1) : "memory");
+            }
+            asm volatile("ds_write_b128 %0, %1 offset:8192\n s_waitcnt lgkmcnt(0)\n" : : "v"(la * 2), "v"(q0) : "memory");
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -100,6 +123,8 @@ int main() {
     if (run<3>("24 v_add_f64 + 8 ds_read_b64 + waitcnt")) return 1;
     if (run<5>("32 ds_read_b64")) return 1;
     if (run<6>("32 ds_write_b64")) return 1;
-    if (run<7>("16 ds_read_b64 + 16 ds_write_b64")) return 1;
+    if (run<7>("message form, 8 edges: 16 rd b64 + 16 wr b64")) return 1;
+    if (run<8>("32 ds_read_b128")) return 1;
+    if (run<9>("record form, 8 edges: 16 rd b64 + 8 rd b128 + 8 wr b64 + 1 wr b128")) return 1;
     return 0;
 }

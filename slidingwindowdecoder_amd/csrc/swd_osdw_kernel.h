@@ -2400,7 +2400,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         }
 #ifdef SWD_GDG_DEBUG
         asm volatile("" ::: "memory"); dbg_ta = wall_clock64(); asm volatile("" ::: "memory");
-        if (tid == 0) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(7, 1); GDG_COUNT(8, dbg_ta - t_unit0); }
+        if (tid == 0) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(7, 1); GDG_COUNT(8, dbg_ta - t_unit0); if (dbg_ta - t_unit0 > 5000) { GDG_COUNT(6, 1); GDG_COUNT(15, dbg_ta - t_unit0); } }
 #endif
         if (item == SWD_ITEM_EXIT) break;
         const uint32_t type = item >> 30;

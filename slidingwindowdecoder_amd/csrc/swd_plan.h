@@ -280,7 +280,8 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         a.slot_scratch = 1;
         static const int inflight = getenv("SWD_GDG_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_INFLIGHT"))) : 6;
         unsigned nctx = 64;
-        while (nctx < 2u * grid) nctx <<= 1;
+        static const unsigned nctx_mult = getenv("SWD_GDG_NCTX_MULT") ? (unsigned)std::max(1, atoi(getenv("SWD_GDG_NCTX_MULT"))) : 2u; // diagnostics
+        while (nctx < nctx_mult * grid) nctx <<= 1;
         // shots admitted at a time, in percent of the workgroups of the grid (a finished shot admits the next): every queued item
         // waits behind the whole ring, so a shot's chain of dependent items (unit -> side branches -> final -> next window)
         // finishes the sooner the fewer other shots are under way -- as long as the side branches keep the grid busy
