@@ -460,7 +460,7 @@ struct GdgSpec {
 template <int NT, class ST = GdgNoStatic>
 __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                                const double *hist_b, double A, double A_sum, int depth, int &guess_pos, int &favor,
-                                               const ST &st = ST{}) {
+                                               const ST &st = ST{}, const double (*h4)[4] = nullptr) { // h4: the history values of this thread's positions (static cache)
     const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
     const double C = 30.0, D = 3.0;
     double best_all = 10000.0, best_neg = 10000.0;
@@ -506,7 +506,7 @@ __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDe
             vv[u] = G.pos_lv[min(j, new_n - 1)];
             act[u] = j < new_n && s.vn_val[vv[u]] == -1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hl[u][i] = hist_b[i * n + vv[u]];
+            for (int i = 0; i < 4; ++i) hl[u][i] = h4[u][i];
         }
 #pragma unroll
         for (int u = 0; u < VFS; ++u) {
@@ -609,13 +609,13 @@ __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDe
 template <int NT, class ST = GdgNoStatic>
 __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                              const double *hist_b, bool side, int depth, int min_converge_depth,
-                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr, const ST &st = ST{}) {
+                                             int &used_guess, uint8_t *snap_b, GdgSpec *sp = nullptr, const ST &st = ST{}, const double (*h4)[4] = nullptr) {
     const int tid = threadIdx.x, new_n = g.new_n;
     const double A = side ? 0.0 : -3.0;
     double A_sum = side ? -10.0 : -12.0;
     if (depth == 0) A_sum = -16.0;
     int guess_pos, favor;
-    if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, guess_pos, favor, st) == -1) { if (sp) sp->fail_before = 1; return -1; }
+    if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, guess_pos, favor, st, h4) == -1) { if (sp) sp->fail_before = 1; return -1; }
     bool guess = true;
     SEL_T0();
     if (depth > min_converge_depth) guess = false;
@@ -663,23 +663,44 @@ __device__ __forceinline__ int gdg_select_vn(const SwdGraphDev &g, const SwdDeco
 }
 
 // BPGD::decimate_vn_reliable (bpgd.cpp:258-286): largest |posterior of slot 3| among active VNs
-template <int NT>
-__device__ __forceinline__ int gdg_decimate_reliable(const SwdGraphDev &g, Lds &s, const GdgLds &G, const double *hist_b) {
+template <int NT, class ST = GdgNoStatic>
+__device__ __forceinline__ int gdg_decimate_reliable(const SwdGraphDev &g, Lds &s, const GdgLds &G, const double *hist_b,
+                                                     const ST &st = ST{}, const double (*h4)[4] = nullptr) {
     const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
     double best = 0.0; // stored negated so that block_argmin (a minimum) finds the largest magnitude
     int bpos = 0x7fffffff;
-    for (int j = tid; j < new_n; j += NT) {
-        const int v = G.pos_lv[j];
-        if (s.vn_val[v] != -1) continue;
-        const double a = fabs(hist_b[3 * n + v]);
-        if (a > -best) { best = -a; bpos = j; } // strict ">" (bpgd.cpp:270), earliest position wins ties
+    [[maybe_unused]] double own3 = 0.0; // static cache: slot 3 of the candidate this thread offers
+    if constexpr (!std::is_same_v<ST, GdgNoStatic>) {
+        constexpr int VFS = (int)(sizeof(st.llr) / sizeof(double));
+#pragma unroll
+        for (int u = 0; u < VFS; ++u) {
+            const int j = s.vtid + u * NT;
+            if (j >= new_n || s.vn_val[G.pos_lv[j]] != -1) continue;
+            const double a = fabs(h4[u][3]);
+            if (a > -best) { best = -a; bpos = j; own3 = h4[u][3]; }
+        }
+    } else {
+        for (int j = tid; j < new_n; j += NT) {
+            const int v = G.pos_lv[j];
+            if (s.vn_val[v] != -1) continue;
+            const double a = fabs(hist_b[3 * n + v]);
+            if (a > -best) { best = -a; bpos = j; } // strict ">" (bpgd.cpp:270), earliest position wins ties
+        }
     }
     if (!(best < 0.0)) { best = 0.0; bpos = 0x7fffffff; }
+    const int mypos = bpos;
     block_argmin<NT>(best, bpos, s);
     if (bpos == 0x7fffffff) return -1;
     const int v = G.pos_lv[bpos];
-    const int val = (hist_b[3 * n + v] > 0) ? 0 : 1;
-    __syncthreads();
+    int val;
+    if constexpr (!std::is_same_v<ST, GdgNoStatic>) {
+        if (mypos == bpos) s.scal[5] = (own3 > 0) ? 0 : 1; // (one thread owns the position)
+        __syncthreads();
+        val = s.scal[5];
+    } else {
+        val = (hist_b[3 * n + v] > 0) ? 0 : 1;
+        __syncthreads();
+    }
     if (tid < 64) {
         bool bad = gdg_set_value_wave(g, s, v, val);
         if (!bad) bad = peel_wave<false, NT>(g, s);
@@ -882,13 +903,14 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
             using ST = GdgStatic<VFP, DM>;
             ST vst;
             gdg_static_init<NT, VFP, DM>(g, s, G, vst);
+            double h4[VFP][4] = {}; // history of the last four iterations of a block, for this thread's positions (static cache only)
             const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
             for (int j = 0; j < maxj; ++j) {
                 const int depth = alt + j;
                 const int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vc, cn);
                 if (j == 0) { bp_init<VFP, DM>(s, vc); __syncthreads(); }
                 int it;
-                const int cv = bp_run<NT, VFP, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+                const int cv = bp_run<NT, VFP, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
                 uint32_t sw = (uint32_t)it & 0xFFu;
                 nsteps = j + 1;
                 if (cv) {
@@ -907,7 +929,7 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
                 if (depth > bound + 2) { if (tid == 0) ag_st(&rec[4 + j], sw); break; }
                 sp.fail_before = sp.fail_after = 0; sp.child = -1;
                 int dummy = 0;
-                const int rc = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, bound, dummy, nullptr, &sp, vst);
+                const int rc = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, bound, dummy, nullptr, &sp, vst, h4);
                 sw |= (sp.fail_before ? 0x100u : 0u) | (sp.fail_after ? 0x200u : 0u) | ((uint32_t)(sp.child + 1) << 16);
                 if (tid == 0) ag_st(&rec[4 + j], sw);
                 if (rc == -1) break;
@@ -990,10 +1012,11 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
     const int NONE = 0x7fffffff;
     double best = 10000.0;
     int winner = -1, ties = 0, blocks = 0, ran = 1, it = 0;
+    double h4[VF][4] = {}; // (static cache: the history of a block stays with the threads of the positions)
     auto block = [&](bool first) { // one min_sum_log call (bpgd.cpp:97-197); first: the messages start from the priors
         const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn);
         if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
-        const int cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        const int cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
         ++blocks; R.post_it += it;
         return cv;
     };
@@ -1026,7 +1049,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
     for (int depth = 0; depth < P.max_step; ++depth) {
         const int cv = block(false);
         int gpos = NONE, favor = 0;
-        const int rc = gdg_select_core<NT>(g, P, s, G, hist_b, -3.0, depth == 0 ? -16.0 : -12.0, depth, gpos, favor, st);
+        const int rc = gdg_select_core<NT>(g, P, s, G, hist_b, -3.0, depth == 0 ? -16.0 : -12.0, depth, gpos, favor, st, h4);
         if (cv || rc == -1 || gpos == NONE) {
             if (cv) { main_conv = true; offer(0); }
             break;
@@ -1055,7 +1078,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
             if (depth > 0 && !on_side) A_sum = -12.0;
             if (block(depth == 0)) { own_pm = offer(id); done = true; break; }
             int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st) == -1 || gpos == NONE) break;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st, h4) == -1 || gpos == NONE) break;
             if (depth < Dp) {
                 if ((id >> (Dp - 1 - depth)) & 1) { on_side = true; A = 0.0; A_sum = -10.0; favor = 1 - favor; }
             } else if (depth == Dp) {
@@ -1075,7 +1098,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
                 break;
             }
             int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st) == -1 || gpos == NONE) break;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st, h4) == -1 || gpos == NONE) break;
             if (set_value(gpos, favor)) break;
             ++depth;
         }
@@ -1090,7 +1113,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
         for (int i = 0; i < P.max_side_branch_step; ++i) {
             if (block(i == 0)) { offer(1 + T + j); break; }
             int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, 0.0, -10.0, depth, gpos, favor, st) == -1 || gpos == NONE) break;
+            if (gdg_select_core<NT>(g, P, s, G, hist_b, 0.0, -10.0, depth, gpos, favor, st, h4) == -1 || gpos == NONE) break;
             if (set_value(gpos, favor)) break;
             ++depth;
         }
@@ -1243,6 +1266,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     constexpr bool SPARSE = !std::is_same_v<ST, GdgNoStatic>;
     ST vst;
     gdg_static_init<NT, VFP, DM>(g, s, G, vst);
+    double h4[VFP][4] = {}; // history of the last four iterations of a block, for this thread's positions (static cache only)
     int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
     bp_init<VFP, DM>(s, vcp);
     __syncthreads();
@@ -1286,7 +1310,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     for (int depth = 0; depth < P.max_step; ++depth) {
         if (depth > 0) nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
         GPT(0);
-        const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
+        const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
         GPT(1);
         ++blocks; R.post_it += it;
         if (cv) {
@@ -1296,8 +1320,8 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
             GPT(4);
             break;
         }
-        const int rc = gdg ? gdg_select_vn<NT>(g, P, s, G, hist_b, false, depth, min_converge_depth, used_guess, snap_b, nullptr, vst)
-                           : gdg_decimate_reliable<NT>(g, s, G, hist_b);
+        const int rc = gdg ? gdg_select_vn<NT>(g, P, s, G, hist_b, false, depth, min_converge_depth, used_guess, snap_b, nullptr, vst, h4)
+                           : gdg_decimate_reliable<NT>(g, s, G, hist_b, vst, h4);
         GPT(2);
         if (rc == -1) break;
     }
@@ -1368,7 +1392,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
             nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
             if (j == 0) { bp_init<VFP, DM>(s, vcp); __syncthreads(); } // set_masks re-initialises the messages
             GPT(0);
-            const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat);
+            const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
             GPT(1);
             ++blocks; R.post_it += it;
             if (cv) {
@@ -1382,7 +1406,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
                 break;
             }
             if (depth > min_converge_depth + 2) break;
-            const int rc2 = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, min_converge_depth, used_guess, snap_b, nullptr, vst);
+            const int rc2 = gdg_select_vn<NT>(g, P, s, G, hist_b, true, depth, min_converge_depth, used_guess, snap_b, nullptr, vst, h4);
             GPT(2);
             if (rc2 == -1) break;
         }

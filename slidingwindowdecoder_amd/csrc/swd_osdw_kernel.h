@@ -539,11 +539,13 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // One routine for every kernel: the register caches keep LDS offsets packed two per register (unpacked where they are used);
 // PB: one parity byte per check, flipped by word atomics (tuned kernels of up to 256 threads), else one parity word.
 // SPARSE (with !FULL): the node list may hold n = "no node here" (the guessing decoders keep a position's thread for the whole
-// tree walk instead of compacting the live nodes after every decimation).
+// tree walk instead of compacting the live nodes after every decimation), and the posterior history goes to registers of the
+// node's thread -- h4[i][slot] for its i-th node -- instead of the ring in HBM: the thread that runs a position's node is the one
+// that classifies the position afterwards, and without the stores the iteration barriers no longer wait for HBM.
 template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
-                      double alpha, bool force_unsat = false, double *hs = nullptr) {
+                      double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
     const bool record_all = P.record_all != 0;
@@ -710,6 +712,10 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
                 if constexpr (ACC) {
                     if (it >= max_iter - 4) hs[i] = (it == max_iter - 4) ? temp : hs[i] + temp; // wave-uniform conditions
+                } else if constexpr (SPARSE) {
+                    if (record) { // (uniform; the slot too)
+                        if (slot_h == 0) h4[i][0] = temp; else if (slot_h == 1) h4[i][1] = temp; else if (slot_h == 2) h4[i][2] = temp; else h4[i][3] = temp;
+                    }
                 } else {
                     if (record && valid) hist_b[slot_h * n + v] = temp;
                 }
