@@ -246,21 +246,39 @@ __device__ __forceinline__ void block_argmin2(double &k1, int &p1, double &k2, i
 template <int VF, int DM> using GdgVC = VnCacheP<VF, DM, 3, false>;
 template <int KG> using GdgCC = CnCacheP<KG, 3>;
 
-// The check cache of a lane straight from the check's live-position mask (one thread per check, every live position in walk
-// order): slot of position j = jptr[j] + lane.  Groups of four beyond the wave's largest live degree are filled without
-// looking at the mask.
+// Which check a thread serves during a tree walk: thread `sub` of the `grp` (1, 2 or 4 adjacent lanes) that share check `lc`
+// takes the live positions number sub, sub + grp, ...  Chosen once per window (or per task) by gdg_cn_map -- checks dealt by
+// decreasing live degree, heavy ones shared, exactly like the osd_window post phase (cn_assign) -- and kept while the tree is
+// walked: degrees only go down from there, so the bound on a thread's walk stays valid, and the order stays roughly sorted.
+struct GdgCnMap { int lc, sub, grp; };
+template <int NT, int KG>
+__device__ __forceinline__ GdgCnMap gdg_cn_map(const SwdGraphDev &g, Lds &s, const GdgLds &G) {
+    GdgCnMap mp{s.ctid < g.m ? s.ctid : -1, 0, 1};
+    // scratch for the counting sort: the position list of the path-metric sums (free until a block converges)
+    int *dhist = (int *)(((uintptr_t)G.plist + 3) & ~(uintptr_t)3);
+    uint16_t *cord = (uint16_t *)(dhist + 66);
+    if ((char *)(cord + g.m) <= (char *)(G.plist + g.new_n)) // (uniform)
+        cn_assign<NT, KG>(g, s, dhist, cord, true, false, -1, mp.lc, mp.sub, mp.grp);
+    return mp;
+}
+
+// The check cache of a thread straight from the check's live-position mask: slot of position j = jptr[j] + lane.  Groups of four
+// beyond the wave's longest walk are filled without looking at the mask.
 template <int NT, int KG, int SH>
-__device__ __forceinline__ void gdg_cn_cache_from_mask(const SwdGraphDev &g, Lds &s, int lc, CnCacheP<KG, SH> &cc) {
+__device__ __forceinline__ void gdg_cn_cache_from_mask(const SwdGraphDev &g, Lds &s, const GdgCnMap &mp, CnCacheP<KG, SH> &cc) {
     const int dummy = swd_slot_far(g);
+    const int lc = mp.lc;
     const bool act = (lc >= 0) && (lc < g.m) && (s.cn_val[lc >= 0 ? lc : 0] >= 0);
     const int l = act ? lc : 0;
     cc.l = act ? lc : -1;
-    cc.sub = 0;
-    cc.grp = 1;
+    cc.sub = mp.sub;
+    cc.grp = mp.grp;
     uint64_t mk = act ? s.livemask[l] : 0ull;
-    const int cnt = act ? (int)s.cn_deg[l] : 0;
+    const int live = act ? (int)s.cn_deg[l] : 0;
+    const int cnt = (live > mp.sub) ? (live - mp.sub + mp.grp - 1) / mp.grp : 0;
     cc.cnt = cnt;
-    cc.live = cnt;
+    cc.live = live;
+    for (int k = 0; k < mp.sub; ++k) mk &= mk - 1; // this thread's first position: the sub-th live one (0 stays 0)
     const int wmax = __builtin_amdgcn_readfirstlane(wave_max(cnt));
 #pragma unroll
     for (int gq = 0; gq < KG; ++gq) {
@@ -270,8 +288,10 @@ __device__ __forceinline__ void gdg_cn_cache_from_mask(const SwdGraphDev &g, Lds
                 int sv = dummy;
                 if (mk) {
                     const int j = __ffsll((long long)mk) - 1;
-                    mk &= mk - 1;
                     sv = (int)s.jptr[j] + l;
+                    mk &= mk - 1;
+                    if (mp.grp >= 2) mk &= mk - 1; // (the positions in between belong to the check's other threads)
+                    if (mp.grp == 4) { mk &= mk - 1; mk &= mk - 1; }
                 }
                 cc.set_slot(gq * 4 + u, sv);
             }
@@ -298,7 +318,7 @@ __device__ __forceinline__ void gdg_static_load(const SwdGraphDev &g, Lds &s, co
     vn_cache_load<NT, VF, DM, false, true>(g, s, g.new_n, st);
 }
 template <int NT, int VF, int DM, int KG>
-__device__ __forceinline__ int gdg_refresh_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, const GdgVC<VF, DM> &st, GdgVC<VF, DM> &vc, GdgCC<KG> &cn) {
+__device__ __forceinline__ int gdg_refresh_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, const GdgVC<VF, DM> &st, GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const GdgCnMap &mp) {
     const int m = g.m, n = g.n, new_n = g.new_n;
     const uint32_t deadslot = (uint32_t)swd_slot_zero<NT>(g);
     SEL_T0();
@@ -321,14 +341,14 @@ __device__ __forceinline__ int gdg_refresh_caches(const SwdGraphDev &g, Lds &s, 
         }
     }
     SEL_T(6);
-    gdg_cn_cache_from_mask<NT>(g, s, s.ctid < m ? s.ctid : -1, cn);
+    gdg_cn_cache_from_mask<NT>(g, s, mp, cn);
     __syncthreads();
     SEL_T(7);
     return new_n;
 }
 
 template <int NT, int VF, int DM, int KG, class VC, class CC>
-__device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, VC &vc, CC &cn) {
+__device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, VC &vc, CC &cn, const GdgCnMap &mp) {
     const int tid = threadIdx.x, new_n = g.new_n;
     const int ch = (new_n + NT - 1) / NT;
     const int j0 = tid * ch, j1 = min(new_n, j0 + ch);
@@ -348,7 +368,7 @@ __device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, co
     asm volatile("" : "+v"(vc.edp[0][0]), "+v"(vc.llr[0]));
 #endif
     SEL_T(6);
-    gdg_cn_cache_from_mask<NT>(g, s, s.ctid < g.m ? s.ctid : -1, cn);
+    gdg_cn_cache_from_mask<NT>(g, s, mp, cn);
     __syncthreads();
     SEL_T(7);
     return nlive;
@@ -357,9 +377,9 @@ __device__ __forceinline__ int gdg_build_caches(const SwdGraphDev &g, Lds &s, co
 // the static cache type of a tree walk with register caches of depth VF, and the cache (re)build that goes with it
 template <int VF, int DM> using GdgStatic = std::conditional_t<(VF <= 2), GdgVC<(VF <= 2 ? VF : 1), DM>, GdgNoStatic>;
 template <int NT, int VF, int DM, int KG, class ST>
-__device__ __forceinline__ int gdg_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, const ST &st, GdgVC<VF, DM> &vc, GdgCC<KG> &cn) {
-    if constexpr (std::is_same_v<ST, GdgNoStatic>) return gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn);
-    else return gdg_refresh_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn);
+__device__ __forceinline__ int gdg_caches(const SwdGraphDev &g, Lds &s, const GdgLds &G, const ST &st, GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const GdgCnMap &mp) {
+    if constexpr (std::is_same_v<ST, GdgNoStatic>) return gdg_build_caches<NT, VF, DM, KG>(g, s, G, vc, cn, mp);
+    else return gdg_refresh_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn, mp);
 }
 template <int NT, int VF, int DM, class ST>
 __device__ __forceinline__ void gdg_static_init(const SwdGraphDev &g, Lds &s, const GdgLds &G, ST &st) {
@@ -904,10 +924,11 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
             ST vst;
             gdg_static_init<NT, VFP, DM>(g, s, G, vst);
             double h4[VFP][4] = {}; // history of the last four iterations of a block, for this thread's positions (static cache only)
+            const GdgCnMap cmap = gdg_cn_map<NT, KG>(g, s, G);
             const int maxj = min(P.max_side_branch_step, SWD_GDG_MAXSTEP);
             for (int j = 0; j < maxj; ++j) {
                 const int depth = alt + j;
-                const int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vc, cn);
+                const int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vc, cn, cmap);
                 if (j == 0) { bp_init<VFP, DM>(s, vc); __syncthreads(); }
                 int it;
                 const int cv = bp_run<NT, VFP, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
@@ -1004,7 +1025,7 @@ __device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDeco
 template <int NT, int VF, int DM, int KG, class ST>
 __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
                                                  double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
-                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const ST &st) { // (VF here = the caller's post-phase depth)
+                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const ST &st, const GdgCnMap &cmap) { // (VF here = the caller's post-phase depth)
     const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
     const int Dp = P.max_tree_depth, S = P.max_side_depth;
     const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
@@ -1014,7 +1035,7 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
     int winner = -1, ties = 0, blocks = 0, ran = 1, it = 0;
     double h4[VF][4] = {}; // (static cache: the history of a block stays with the threads of the positions)
     auto block = [&](bool first) { // one min_sum_log call (bpgd.cpp:97-197); first: the messages start from the priors
-        const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn);
+        const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn, cmap);
         if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
         const int cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
         ++blocks; R.post_it += it;
@@ -1267,13 +1288,14 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     ST vst;
     gdg_static_init<NT, VFP, DM>(g, s, G, vst);
     double h4[VFP][4] = {}; // history of the last four iterations of a block, for this thread's positions (static cache only)
-    int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
+    const GdgCnMap cmap = gdg_cn_map<NT, KG>(g, s, G); // (the degrees after reset + peeling bound every later state of this window)
+    int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn, cmap);
     bp_init<VFP, DM>(s, vcp);
     __syncthreads();
     if constexpr (ENS) {
         for (int j = tid; j < SWD_GDG_MAXGUESS; j += NT) G.alt_depth[j] = -1;
         __syncthreads();
-        gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst);
+        gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst, cmap);
         for (int v = tid; v < n; v += NT) s.hard[v] = 0;
         __syncthreads();
         for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
@@ -1308,7 +1330,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     // ---- phase 1: main branch
     GPT0();
     for (int depth = 0; depth < P.max_step; ++depth) {
-        if (depth > 0) nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
+        if (depth > 0) nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn, cmap);
         GPT(0);
         const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
         GPT(1);
@@ -1389,7 +1411,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
         if (s.scal[1]) continue;
         for (int j = 0; j < P.max_side_branch_step; ++j) {
             depth = G.alt_depth[i] + j;
-            nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn);
+            nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn, cmap);
             if (j == 0) { bp_init<VFP, DM>(s, vcp); __syncthreads(); } // set_masks re-initialises the messages
             GPT(0);
             const int cv = bp_run<NT, VFP, DM, KG, false, false, false, SPARSE>(g, P, s, P.max_iter_per_step, nlive, vcp, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
