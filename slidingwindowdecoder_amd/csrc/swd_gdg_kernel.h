@@ -203,8 +203,9 @@ __device__ __forceinline__ void block_argmin(double &key, int &pos, Lds &s) {
     __syncthreads();
 }
 
-// two lexicographic minima at once (same barriers as one)
-template <int NT>
+// two lexicographic minima at once (same barriers as one).  LEAN: the caller guarantees a barrier between any earlier access to the
+// staging words and this call, and another one after it before they are touched again -- only the middle barrier remains.
+template <int NT, bool LEAN = false>
 __device__ __forceinline__ void block_argmin2(double &k1, int &p1, double &k2, int &p2, Lds &s) {
     if constexpr (NT / 64 > 8) { // (the per-wave staging area holds 16 keys)
         block_argmin<NT>(k1, p1, s);
@@ -220,7 +221,7 @@ __device__ __forceinline__ void block_argmin2(double &k1, int &p1, double &k2, i
         }
         double *wk = s.dbl + 4; // [16]: first keys, then second keys
         int *wp = s.iaux;       // [16]
-        __syncthreads();
+        if constexpr (!LEAN) __syncthreads();
         if ((threadIdx.x & 63) == 0) {
             const int w = threadIdx.x >> 6;
             wk[w] = k1; wp[w] = p1; wk[NW + w] = k2; wp[NW + w] = p2;
@@ -236,7 +237,7 @@ __device__ __forceinline__ void block_argmin2(double &k1, int &p1, double &k2, i
             if (o2 < b2 || (o2 == b2 && q2 < c2)) { b2 = o2; c2 = q2; }
         }
         k1 = b1; p1 = c1; k2 = b2; p2 = c2;
-        __syncthreads();
+        if constexpr (!LEAN) __syncthreads();
     }
 }
 
@@ -594,7 +595,9 @@ __device__ __forceinline__ int gdg_select_core(const SwdGraphDev &g, const SwdDe
     if (!(best_all < 10000.0)) { best_all = 10000.0; pos_all = 0x7fffffff; }
     if (!(best_neg < 10000.0)) { best_neg = 10000.0; pos_neg = 0x7fffffff; }
     SEL_T(0);
-    block_argmin2<NT>(best_all, pos_all, best_neg, pos_neg, s); // (its barriers also publish G.cat)
+    // (the staging words were last touched before the block that just ran -- barriers in between -- and the barrier after wave 0's
+    // section below comes before anything else touches them; the remaining barrier also publishes G.cat)
+    block_argmin2<NT, true>(best_all, pos_all, best_neg, pos_neg, s);
     SEL_T(1);
     // the aggressive decimations in position order, then the peeling: wave 0 walks the classification itself (lane q owns the
     // positions [q CH, (q + 1) CH); the next one to apply is the smallest pending position of the first lane that has any)
@@ -873,7 +876,7 @@ __device__ __forceinline__ void gdg_run_task(const SwdPipeArgs &a, char *smem, u
     const int wi = (int)ag_ld(&sp.ctx.hdr[4]);
     const bool dead_unsat = ag_ld(&sp.ctx.hdr[6]) != 0u;
     const SwdWindowDev &w = a.wins[wi];
-    const SwdGraphDev &g = w.g;
+    const SwdGraphDev &g = w.g; // (a task of three or four steps does not repay staging row_col / perm in LDS: measured)
     const SwdLdsLayout &L = w.L;
     const SwdDecodeParams &P = a.P;
     const int m = g.m, n = g.n, new_n = g.new_n;
@@ -1155,12 +1158,29 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
 #define GPT0() do { } while (0)
 #define GPT(k) do { } while (0)
 #endif
+// The window's edge columns (row_col) and check order (perm) staged in LDS, in the slot-list region the guessing decoders no
+// longer use: the reset after the sort chases slot -> column for every position of every check and the peeling sweeps look both
+// up for every check they fire -- from L2 that was one memory latency per look-up.  gl: the graph descriptor the tree walk uses
+// from here on (pointers into LDS; generic loads).  The caller's next barrier publishes the copies.
+template <int NT>
+__device__ __forceinline__ void gdg_stage_graph(SwdGraphDev &gl, const SwdGraphDev &g, Lds &s) {
+    const int E = g.E, m = g.m, Ee = (E + 1) & ~1;
+    if ((Ee + m) * 2 <= g.K * m * 2) { // (uniform; E <= K m always, the check order needs m entries more)
+        uint16_t *rc = s.lslot, *pm = rc + Ee;
+        for (int e = threadIdx.x; e < E; e += NT) rc[e] = g.row_col[e];
+        for (int l = threadIdx.x; l < m; l += NT) pm[l] = g.perm[l];
+        gl.row_col = rc; gl.perm = pm;
+    }
+}
+
 // ENS (kernel kind 7): bpgdg_decoder(multi_thread=True) -- the post-processing is the reference's threaded ensemble
 // (gdg_ensemble_ref) instead of gdg()'s tree walk.
 template <int NT, int VF, int DM, int KG, bool ENS = false, int VFP = VF>
-__device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+__device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                                   const uint8_t *synd, double *hist_b, uint8_t *snap_b, WinResult &R,
                                                   const SwdPipeArgs *par = nullptr, uint32_t *acc = nullptr, int wi = 0, int b = 0) {
+    SwdGraphDev g_loc = g_in; // (row_col / perm move into LDS for the tree walk: gdg_stage_graph)
+    const SwdGraphDev &g = g_loc;
     const int tid = threadIdx.x, m = g.m, n = g.n, new_n = g.new_n;
     GdgLds G;
     gdg_bind(G, s.scratch, L, n, new_n);
@@ -1203,6 +1223,9 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g, const Sw
     uint64_t *key = (uint64_t *)s.scratch;
     uint16_t *idx = (uint16_t *)(s.scratch + L.off_idx);
     __syncthreads();
+    // (serial form only: 16384 shots 1.70 -> 1.76 M windows/s; in the parallel form the owner runs the main branch alone and parks
+    // the tree -- staging 13 KB for that costs more than it saves, 1.21 -> 1.20 M at 4096 shots -- and neither do the tasks repay it)
+    if (!par) gdg_stage_graph<NT>(g_loc, g_in, s);
     for (int v = tid; v < L.npad; v += NT) {
         if (v < n) {
             const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
