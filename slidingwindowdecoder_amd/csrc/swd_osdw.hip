@@ -208,7 +208,7 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     int rc;
     // guessing decoders: the parallel form (side branches as work items) shortens the critical path of a batch that
     // cannot fill the device with whole shots; large batches keep the serial walk (no speculation, no queue traffic)
-    static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 6144; // measured (parallel vs serial): 5120 shots 69 vs 77 ms, 6144 shots 76 vs 78 ms, 7168 shots 88 vs 79 ms
+    static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 4608; // measured, [[144]] GDG windows (parallel vs serial): 4096 shots 37.5 vs 47 ms, 4608 shots 47.3 vs 47.2, 5120 shots 51.3 vs 47.9, 8192 shots 76.6 vs 54.9 (round 2, before the serial form got faster: 6144)
     const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots && a.B < SWD_GDG_ITEM_MAX_SHOTS;
     // osd_window: when the posterior history is only consumed as its slot-order sum (no history in or out, both
     // iteration caps multiples of four) the kernel that accumulates the sum in registers runs: no 4 x n ring in HBM

@@ -278,7 +278,7 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     const unsigned grid = (unsigned)std::min<long long>(units, std::max(1, slots[d->device & 63] * grid_pct / 100));
     if constexpr (KIND == 2) { // work-item ring + contexts of parked trees (swd_gdg_kernel.h); items need per-workgroup scratch
         a.slot_scratch = 1;
-        static const int inflight = getenv("SWD_GDG_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_INFLIGHT"))) : 6;
+        static const int inflight = getenv("SWD_GDG_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_INFLIGHT"))) : 4; // (4096 shots: 3, 4: 1.202 M windows/s; 6: 1.191; 8: 1.179; 12: 1.175 -- every branch is queued anyway while workgroups wait)
         unsigned nctx = 64;
         static const unsigned nctx_mult = getenv("SWD_GDG_NCTX_MULT") ? (unsigned)std::max(1, atoi(getenv("SWD_GDG_NCTX_MULT"))) : 2u; // diagnostics
         while (nctx < nctx_mult * grid) nctx <<= 1;
