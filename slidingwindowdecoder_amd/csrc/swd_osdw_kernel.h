@@ -323,6 +323,47 @@ __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E 
 // wave touch consecutive cells in the variable-node pass -- and remap[old slot] = cell for the check side (g.E = D * nlive here).
 // All global loads are issued unconditionally and before anything depends on them (the edge table is padded with SWD_PAD_EDGE
 // beyond a column's degree, rows beyond g.D do not exist: clamped): one memory latency per call instead of two per variable node.
+// Full graph, in two halves: vn_cache_issue starts every load (raw edge words + priors), vn_cache_pack builds the cache from them --
+// whatever the caller does in between runs while the loads are in flight.
+template <int NT, int VF, int DM>
+struct VnRaw { uint32_t ev[VF][DM]; double llr[VF]; };
+template <int NT, int VF, int DM>
+__device__ __forceinline__ void vn_cache_issue(const SwdGraphDev &g, const Lds &s, VnRaw<NT, VF, DM> &r) {
+    const int n = g.n, D = g.D;
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        const int v = (idx < n) ? idx : 0;
+        r.llr[i] = (n > 0) ? g.llr[v] : 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) r.ev[i][k] = (n > 0) ? g.vn_edge[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
+    }
+}
+template <int NT, int VF, int DM, int SH, bool PB>
+__device__ __forceinline__ void vn_cache_pack(const SwdGraphDev &g, const Lds &s, const VnRaw<NT, VF, DM> &r, VnCacheP<VF, DM, SH, PB> &c) {
+    const int n = g.n, D = g.D;
+    const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        const bool valid = idx < n;
+        c.llr[i] = valid ? r.llr[i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) c.set_ed(i, k, dead);
+#pragma unroll
+        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            const uint32_t e = r.ev[i][k];
+            if (valid && k < D && e != SWD_PAD_EDGE) {
+                c.set_ed(i, k, swd_edge_slot(e) << 3);
+                c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
+                                           : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
+            }
+        }
+    }
+}
+
 // ALLEDGES (with !FULL): the listed nodes with every edge of theirs, whatever the state of the checks.
 template <int NT, int VF, int DM, bool FULL, bool ALLEDGES = false, int SH, bool PB>
 __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr) {
@@ -1878,6 +1919,11 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     for (int i = 0; i < 9; ++i) R.t[i] = 0;
     R.t[0] = wall_clock64();
 
+    // kernels of up to 256 threads: the cache's loads are in flight during the reset loops (headline 9.95 -> 9.84 ms per launch at
+    // order 0; the 1024-thread kernels lose by it -- [[288]] 63.2 -> 64.0 ms -- and load where they always did)
+    constexpr bool kSplitLoad = NT <= 256;
+    [[maybe_unused]] VnRaw<NT, kSplitLoad ? VF : 1, DM> vraw;
+    if constexpr (kSplitLoad) vn_cache_issue<NT, VF, DM>(g, s, vraw);
     // reset (osd_window.pyx:288-303)
     for (int l = tid; l < m; l += NT) {
         const int d = g.row_deg[l];
@@ -1896,7 +1942,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 #ifdef SWD_INITPROF
     const long long ip0 = wall_clock64();
 #endif
-    vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
+    if constexpr (kSplitLoad) vn_cache_pack<NT, VF, DM>(g, s, vraw, vc);
+    else vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
 #ifdef SWD_INITPROF
     asm volatile("" : "+v"(vc.edp[VF - 1][0]), "+v"(vc.llr[0]));
     const long long ip1 = wall_clock64();
