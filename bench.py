@@ -478,7 +478,10 @@ def main():
         torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:  # (only a one-process job can get here without one: any free port will do)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if STUB:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

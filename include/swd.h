@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SWD_ABI_VERSION 2
+#define SWD_ABI_VERSION 3
 
 /* exit class of one window decode, low byte of status[]; bit 8 = converge flag */
 enum {
@@ -249,6 +249,39 @@ int swd_pipeline_decode_dev(swd_pipeline *pl, int32_t B, const uint8_t *det, int
  * work-item loop found nothing to do for 20 s while units were still outstanding and left -- results incomplete).  Synchronises the device, so call it
  * after the asynchronous swd_pipeline_decode_dev launches it should cover; swd_pipeline_decode checks it itself. */
 int swd_pipeline_status(swd_pipeline *pl, uint32_t *flags);
+
+/* total_e_hat bit-packed: total_bits [B * ((num_col + 7) / 8)], bit (c & 7) of byte (c >> 3) of a shot's row = column c
+ * (numpy: np.unpackbits(bits, axis=1, count=num_col, bitorder="little")).  1098 B per shot instead of 8784 for the [[144,12,12]]
+ * experiment -- the per-shot output SURVEY section 8(e) counts.  Host pointers; otherwise as swd_pipeline_decode. */
+int swd_pipeline_decode_packed(swd_pipeline *pl, int32_t B, const uint8_t *det, uint8_t *total_bits,
+                               int32_t *stats, double *min_pm, int32_t *shot_result);
+
+/* ---- streaming form of the window loop -------------------------------------------------------
+ * Consecutive batches through ONE pipeline, two in flight (what a deployment, or the shots loop of the reference harness
+ * /root/reference/osd.py:130-191 cut into batches, does): a stream object owns two lanes, each with its own HIP stream, launch
+ * slot, device buffers and page-locked staging.  Batch k + 1 is copied in and launched while batch k still runs: its persistent
+ * grid takes the workgroup slots that the tail of batch k leaves empty, and the copy-out / unpacking of batch k overlaps the
+ * launch of k + 1.  Results are those of swd_pipeline_decode, batch by batch, in push order.
+ *   flags  SWD_STREAM_PACKED    total_e_hat is returned bit-packed (layout of swd_pipeline_decode_packed)
+ *          SWD_STREAM_NO_STATS  per-window stats / min_pm are not copied back (pop takes NULL for them)
+ * Host form: push(det [B*num_det]) enqueues copy-in + launch + copy-out on the next lane and returns at once; pop() waits for
+ * the OLDEST batch in flight and fills the caller's arrays (total [B*num_col] bytes, or [B*((num_col+7)/8)] with
+ * SWD_STREAM_PACKED; stats / min_pm / shot_result nullable), returns its B.  At most two batches in flight: a third push without a
+ * pop fails.  A scheduling fault of the batch (see swd_pipeline_status) makes its pop fail.
+ * Device form: push_dev launches on the next lane with the caller's device buffers (the caller keeps one set of output buffers
+ * per lane, i.e. alternates between two); `after` (hipStream_t, nullable) = a stream whose work so far must precede the launch
+ * (e.g. the producer of det).  wait(stream): `stream` waits for both lanes (device-side), or with NULL the host does. */
+typedef struct swd_stream swd_stream;
+#define SWD_STREAM_PACKED 1
+#define SWD_STREAM_NO_STATS 2
+swd_stream *swd_pipeline_stream_create(swd_pipeline *pl, int32_t max_shots, int32_t flags);
+void swd_pipeline_stream_destroy(swd_stream *s);
+int swd_pipeline_stream_push(swd_stream *s, int32_t B, const uint8_t *det);
+int swd_pipeline_stream_pop(swd_stream *s, uint8_t *total, int32_t *stats, double *min_pm, int32_t *shot_result);
+int swd_pipeline_stream_pending(swd_stream *s); /* host batches pushed and not yet popped (0..2) */
+int swd_pipeline_stream_push_dev(swd_stream *s, int32_t B, const uint8_t *det, int64_t det_stride, uint8_t *total,
+                                 int64_t total_stride, int32_t *stats, double *min_pm, int32_t *shot_result, void *after);
+int swd_pipeline_stream_wait(swd_stream *s, void *stream);
 
 /* Threading and streams: every entry point may be called from any host thread.  Launches of ONE decoder /
  * pipeline handle are serialised on the host while they are prepared; on the device, launches on different streams

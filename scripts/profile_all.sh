@@ -3,7 +3,7 @@
 # gpurun_out/<tag>_<workload>/):  kernel-trace statistics of the bench command, FETCH_SIZE and WRITE_SIZE in separate --pmc
 # passes, two SQ passes.      usage: scripts/profile_all.sh <tag> <workload> [extra bench.py arguments]
 # Summaries (afterwards, anywhere): scripts/summarize_profiles.py <tag> <workload>
-TAG=${1:-r03}; WL=${2:-headline}; shift 2
+TAG=${1:-r04}; WL=${2:-headline}; shift $(( $# < 2 ? $# : 2 ))
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${TAG}_${WL}
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does overlapping consecutive launches (two streams, two sets of output buffers) hide the tail of the persistent grid?
-python scripts/overlap_test.py [order]"""
+python scripts/two_stream_overlap.py [order]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

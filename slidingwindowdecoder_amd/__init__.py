@@ -3,7 +3,7 @@
 Host-side problem construction (codes, circuit, windows) is pure numpy/scipy and importable
 anywhere; the decoder classes need libswd_hip.so and a gfx950 GPU and raise otherwise.
 """
-from .decoders import (DemSampler, SlidingWindowDecoder, bp4_osd, bp_history_decoder, bpgd_decoder,  # noqa: F401
+from .decoders import (DemSampler, SlidingWindowDecoder, SlidingWindowStream, bp4_osd, bp_history_decoder, bpgd_decoder,  # noqa: F401
                        bpgdg_decoder, osd_window)
 
 # The reference's classes imitate the `ldpc` v1 names (error text of osd_window.pyx:197, BASELINE north star):
@@ -13,4 +13,4 @@ bp_decoder = bp_history_decoder
 bposd_decoder = osd_window
 
 __all__ = ["osd_window", "bpgdg_decoder", "bpgd_decoder", "bp_history_decoder", "bp4_osd", "SlidingWindowDecoder",
-           "bp_decoder", "bposd_decoder", "DemSampler"]
+           "SlidingWindowStream", "bp_decoder", "bposd_decoder", "DemSampler"]

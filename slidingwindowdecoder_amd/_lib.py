@@ -74,6 +74,14 @@ SYMBOLS = [
     ("swd_pipeline_set_observables", C.c_int, [_vp, C.POINTER(GraphDesc)]),
     ("swd_pipeline_decode", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("swd_pipeline_decode_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_decode_packed", C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_stream_create", _vp, [_vp, _i32, _i32]),
+    ("swd_pipeline_stream_destroy", None, [_vp]),
+    ("swd_pipeline_stream_push", C.c_int, [_vp, _i32, _vp]),
+    ("swd_pipeline_stream_pop", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_stream_pending", C.c_int, [_vp]),
+    ("swd_pipeline_stream_push_dev", C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    ("swd_pipeline_stream_wait", C.c_int, [_vp, _vp]),
     ("swd_pipeline_status", C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     ("swd_pipeline_set_profiling", C.c_int, [_vp, _i32]),
     ("swd_pipeline_get_profile", C.c_int, [_vp, _i32, _vp]),
@@ -87,6 +95,7 @@ SYMBOLS = [
 ]
 
 STAT_WORDS = 8
+STREAM_PACKED, STREAM_NO_STATS = 1, 2
 
 
 def _preload_torch_hip_runtime():

@@ -27,16 +27,33 @@ void set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
+// Device buffer that only grows.  Growing never calls hipFree on the launch path: hipFree synchronises the whole device (and the old
+// allocation may still be read by a launch in flight on another stream), so the outgrown allocation is retired and released with the
+// buffer.  Growth is geometric (at least 1.5x), which bounds the retired bytes by twice the final size.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    std::vector<void *> retired;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+        for (void *q : retired) (void)hipFree(q);
+    }
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        SWD_HIP(hipMalloc(&p, bytes));
-        cap = bytes;
+        const size_t want = std::max(bytes, cap + cap / 2);
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        size_t got = want;
+        if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); e = hipMalloc(&q, bytes); got = bytes; }
+        if (e != hipSuccess) {
+            swd::set_error("hipMalloc(%zu bytes) failed: %s (%s:%d)", bytes, hipGetErrorString(e), __FILE__, __LINE__);
+            return -1;
+        }
+        if (p) retired.push_back(p);
+        p = q; cap = got;
         return 0;
     }
     template <class T> T *as() { return (T *)p; }

@@ -4,6 +4,8 @@
 //   swd_pipeline_*  the whole (W,F) sliding-window loop of /root/reference/osd.py:130-179 for B
 //                   shots in one launch
 // Both run swd::pipeline_kernel (swd_osdw_kernel.h); a single window is a pipeline of length 1.
+#include <thread>
+
 #include "swd_plan.h"
 #include "swd_variants.h"
 
@@ -516,31 +518,279 @@ extern "C" int swd_pipeline_debug_counters(swd_pipeline *h, uint32_t *out16) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// streaming form (include/swd.h: swd_pipeline_stream_*) and the host-buffer entry points built on it
+// ------------------------------------------------------------------------------------------
+namespace swd {
+
+// total_e_hat bytes -> bits: thread = one output byte (columns 8 j .. 8 j + 7 of one shot), bit k = column 8 j + k
+__global__ void __launch_bounds__(256) pack_bits_kernel(const uint8_t *total, int64_t stride, int num_col, int B, uint8_t *bits, int row_bytes) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * row_bytes) return;
+    const int b = (int)(t / row_bytes), j = (int)(t - (long long)b * row_bytes);
+    const uint8_t *src = total + (int64_t)b * stride + 8 * j;
+    uint32_t x = 0;
+    if (8 * j + 8 <= num_col && (((uintptr_t)src) & 7) == 0) {
+        const uint64_t w = *(const uint64_t *)src; // bytes 0/1 -> bits: gather the low bit of every byte
+        x = (uint32_t)((((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) & 0xFFu);
+    } else {
+        for (int k = 0; k < 8 && 8 * j + k < num_col; ++k) x |= (src[k] ? 1u : 0u) << k;
+    }
+    bits[t] = (uint8_t)x;
+}
+
+// bits -> bytes on the host: one 8-byte store per packed byte; rows dealt to a few threads when the output is large
+static void unpack_rows(const uint8_t *bits, size_t row_bytes, int num_col, uint8_t *out, size_t r0, size_t r1) {
+    static uint64_t lut[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int v = 0; v < 256; ++v) {
+            uint64_t w = 0;
+            for (int k = 0; k < 8; ++k) w |= (uint64_t)((v >> k) & 1) << (8 * k);
+            lut[v] = w;
+        }
+    });
+    const int full = num_col / 8;
+    for (size_t r = r0; r < r1; ++r) {
+        const uint8_t *src = bits + r * row_bytes;
+        uint8_t *dst = out + r * (size_t)num_col;
+        for (int j = 0; j < full; ++j) memcpy(dst + 8 * j, &lut[src[j]], 8);
+        for (int c = full * 8; c < num_col; ++c) dst[c] = (src[c >> 3] >> (c & 7)) & 1;
+    }
+}
+static void unpack_bits_host(const uint8_t *bits, size_t B, int num_col, uint8_t *out) {
+    const size_t row_bytes = ((size_t)num_col + 7) / 8;
+    unsigned nthr = 1;
+    if (B * (size_t)num_col >= (8u << 20)) nthr = std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nthr <= 1) { unpack_rows(bits, row_bytes, num_col, out, 0, B); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nthr; ++i) th.emplace_back(unpack_rows, bits, row_bytes, num_col, out, B * i / nthr, B * (i + 1) / nthr);
+    unpack_rows(bits, row_bytes, num_col, out, 0, B / nthr);
+    for (auto &t : th) t.join();
+}
+
+static int stream_alloc_lane(HostStream *hs, StreamLane &l) {
+    Plan *d = hs->plan;
+    const size_t B = (size_t)hs->max_shots, W = d->wins.size();
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t row_bytes = ((size_t)d->num_col + 7) / 8;
+    const bool stats = !(hs->flags & SWD_STREAM_NO_STATS);
+    // device: det | total bytes | then the block that travels back in one copy: bits | stats | min_pm | shot_result | status
+    l.o_total = al(B * d->num_det);
+    l.o_bits = l.o_total + al(B * (size_t)d->num_col);
+    l.h_stats = al(B * row_bytes);
+    l.h_pm = l.h_stats + (stats ? al(B * W * SWD_STAT_WORDS * 4) : 0);
+    l.h_shot = l.h_pm + (stats ? al(B * W * 8) : 0);
+    l.h_status = l.h_shot + al(B * 8);
+    l.out_bytes = l.h_status + 256;
+    l.o_stats = l.o_bits + l.h_stats; l.o_pm = l.o_bits + l.h_pm; l.o_shot = l.o_bits + l.h_shot; l.o_status = l.o_bits + l.h_status;
+    l.dev_bytes = l.o_bits + l.out_bytes;
+    if (l.dev.reserve(l.dev_bytes) || l.hin.reserve(B * d->num_det) || l.hout.reserve(l.out_bytes)) return -1;
+    return 0;
+}
+
+static int stream_lane_init(StreamLane &l) {
+    if (!l.st) SWD_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    if (!l.done) SWD_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+    if (!l.ready) SWD_HIP(hipEventCreateWithFlags(&l.ready, hipEventDisableTiming));
+    return 0;
+}
+
+static HostStream *stream_new(Plan *d, int max_shots, int flags) {
+    if (d->wins.empty() || d->num_col <= 0) { set_error("streaming needs a sliding-window pipeline"); return nullptr; }
+    if (max_shots <= 0) { set_error("max_shots must be positive"); return nullptr; }
+    if (hipSetDevice(d->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", d->device); return nullptr; }
+    HostStream *hs = new HostStream();
+    hs->plan = d; hs->max_shots = max_shots; hs->flags = flags;
+    for (auto &l : hs->lane)
+        if (stream_lane_init(l)) { delete hs; return nullptr; }
+    return hs;
+}
+
+static int stream_push(HostStream *hs, int B, const uint8_t *det) {
+    Plan *d = hs->plan;
+    if (B <= 0 || B > hs->max_shots) { set_error("stream push: %d shots, the stream was created for 1..%d", B, hs->max_shots); return -1; }
+    if (!det) { set_error("null input pointer"); return -1; }
+    std::lock_guard<std::mutex> lk(hs->mu);
+    StreamLane &l = hs->lane[hs->npush & 1];
+    if (l.busy) { set_error("stream push: two batches are in flight, pop the oldest first"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    if (!l.dev.p && stream_alloc_lane(hs, l)) return -1;
+    const size_t W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
+    const bool stats = !(hs->flags & SWD_STREAM_NO_STATS);
+    char *dv = (char *)l.dev.p;
+    memcpy(l.hin.p, det, (size_t)B * d->num_det);
+    SWD_HIP(hipMemcpyAsync(dv, l.hin.p, (size_t)B * d->num_det, hipMemcpyHostToDevice, l.st));
+    int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, (const uint8_t *)dv, 0, (uint8_t *)(dv + l.o_total), 0,
+                                     stats ? (int32_t *)(dv + l.o_stats) : nullptr, stats ? (double *)(dv + l.o_pm) : nullptr,
+                                     (int32_t *)(dv + l.o_shot), l.st);
+    if (rc) return rc;
+    const long long nb = (long long)B * (long long)row_bytes;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, l.st, (const uint8_t *)(dv + l.o_total),
+                       (int64_t)d->num_col, d->num_col, B, (uint8_t *)(dv + l.o_bits), (int)row_bytes);
+    SWD_HIP(hipGetLastError());
+    // the decoder's fault word as this batch left it (read-and-clear happens at pop, on the host copy)
+    SWD_HIP(hipMemcpyAsync(dv + l.o_status, d->status.p, 4, hipMemcpyDeviceToDevice, l.st));
+    // what travels back: only the used prefix of every array (four copies into the page-locked block)
+    char *ho = (char *)l.hout.p;
+    SWD_HIP(hipMemcpyAsync(ho, dv + l.o_bits, (size_t)nb, hipMemcpyDeviceToHost, l.st));
+    if (stats) {
+        SWD_HIP(hipMemcpyAsync(ho + l.h_stats, dv + l.o_stats, (size_t)B * W * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost, l.st));
+        SWD_HIP(hipMemcpyAsync(ho + l.h_pm, dv + l.o_pm, (size_t)B * W * 8, hipMemcpyDeviceToHost, l.st));
+    }
+    SWD_HIP(hipMemcpyAsync(ho + l.h_shot, dv + l.o_shot, (size_t)B * 8, hipMemcpyDeviceToHost, l.st));
+    SWD_HIP(hipMemcpyAsync(ho + l.h_status, dv + l.o_status, 4, hipMemcpyDeviceToHost, l.st));
+    SWD_HIP(hipEventRecord(l.done, l.st));
+    l.B = B; l.busy = true;
+    hs->npush++;
+    return 0;
+}
+
+// packed_out: the caller's `total` takes the packed rows whatever the stream's flag says (swd_pipeline_decode_packed)
+static int stream_pop(HostStream *hs, uint8_t *total, int32_t *stats, double *min_pm, int32_t *shot_result, int packed_out) {
+    Plan *d = hs->plan;
+    std::lock_guard<std::mutex> lk(hs->mu);
+    StreamLane &l = hs->lane[hs->npop & 1];
+    if (!l.busy) { set_error("stream pop: no batch in flight"); return -1; }
+    SWD_HIP(hipSetDevice(d->device));
+    SWD_HIP(hipEventSynchronize(l.done));
+    l.busy = false;
+    hs->npop++;
+    const size_t B = (size_t)l.B, W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
+    const char *ho = (const char *)l.hout.p;
+    const uint32_t err = *(const uint32_t *)(ho + l.h_status);
+    if (err) {
+        (void)hipMemsetAsync(d->status.p, 0, 4, l.st);
+        set_error("internal: a window waited more than 10 s for its predecessor (scheduling fault, flags 0x%x)", err);
+        return -1;
+    }
+    if ((stats || min_pm) && (hs->flags & SWD_STREAM_NO_STATS)) { set_error("stream pop: the stream was created with SWD_STREAM_NO_STATS"); return -1; }
+    if (total) {
+        if (packed_out || (hs->flags & SWD_STREAM_PACKED)) memcpy(total, ho, B * row_bytes);
+        else unpack_bits_host((const uint8_t *)ho, B, d->num_col, total);
+    }
+    if (stats) memcpy(stats, ho + l.h_stats, B * W * SWD_STAT_WORDS * 4);
+    if (min_pm) memcpy(min_pm, ho + l.h_pm, B * W * 8);
+    if (shot_result) memcpy(shot_result, ho + l.h_shot, B * 8);
+    return (int)B;
+}
+
+// One host-buffer call on the plan's own stream object.  A large batch is cut in two halves on the two lanes: the copy-out and
+// the unpacking of the first half overlap the second half's launch, whose grid also fills the first one's tail.
+static int pipeline_decode_host(Plan *d, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats, double *min_pm,
+                                int32_t *shot_result, int packed) {
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
+    SWD_HIP(hipSetDevice(d->device));
+    static const int split_min = getenv("SWD_HOST_SPLIT_MIN") ? atoi(getenv("SWD_HOST_SPLIT_MIN")) : 2048; // shots from which a call is cut in two
+    const int parts = (B >= split_min && B >= 2) ? 2 : 1;
+    const int per = (B + parts - 1) / parts;
+    if (!d->hstream || d->hstream->max_shots < per) {
+        d->hstream.reset(stream_new(d, std::max(per, 256), 0));
+        if (!d->hstream) return -1;
+        d->hstream->owned_by_plan = true;
+    }
+    HostStream *hs = d->hstream.get();
+    while (hs->npop < hs->npush) (void)stream_pop(hs, nullptr, nullptr, nullptr, nullptr, 0); // (a failed earlier call left batches behind)
+    const size_t W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
+    for (int k = 0; k < parts; ++k) {
+        const int lo = k * per, n = std::min(per, B - lo);
+        if (n > 0 && stream_push(hs, n, det + (size_t)lo * d->num_det)) return -1;
+    }
+    int rc = 0;
+    for (int k = 0; k < parts; ++k) {
+        const size_t lo = (size_t)k * per;
+        const int n = std::min(per, B - (int)lo);
+        if (n <= 0) continue;
+        if (stream_pop(hs, total + lo * (packed ? row_bytes : (size_t)d->num_col), stats ? stats + lo * W * SWD_STAT_WORDS : nullptr,
+                       min_pm ? min_pm + lo * W : nullptr, shot_result ? shot_result + lo * 2 : nullptr, packed) < 0)
+            rc = -1;
+    }
+    return rc;
+}
+
+} // namespace swd
+
 extern "C" int swd_pipeline_decode(swd_pipeline *h, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats,
                                    double *min_pm, int32_t *shot_result) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null pipeline"); return -1; }
     if (B <= 0) return 0;
     if (!det || !total) { set_error("null output/input pointer"); return -1; }
-    std::lock_guard<std::recursive_mutex> lk(d->mu);
+    return pipeline_decode_host(d, B, det, total, stats, min_pm, shot_result, 0);
+}
+
+extern "C" int swd_pipeline_decode_packed(swd_pipeline *h, int32_t B, const uint8_t *det, uint8_t *total_bits, int32_t *stats,
+                                          double *min_pm, int32_t *shot_result) {
+    Plan *d = (Plan *)h;
+    if (!d) { set_error("null pipeline"); return -1; }
+    if (B <= 0) return 0;
+    if (!det || !total_bits) { set_error("null output/input pointer"); return -1; }
+    return pipeline_decode_host(d, B, det, total_bits, stats, min_pm, shot_result, 1);
+}
+
+extern "C" swd_stream *swd_pipeline_stream_create(swd_pipeline *h, int32_t max_shots, int32_t flags) {
+    Plan *d = (Plan *)h;
+    if (!d) { set_error("null pipeline"); return nullptr; }
+    return (swd_stream *)stream_new(d, max_shots, flags);
+}
+
+extern "C" void swd_pipeline_stream_destroy(swd_stream *s) {
+    HostStream *hs = (HostStream *)s;
+    if (!hs) return;
+    (void)hipSetDevice(hs->plan->device);
+    delete hs;
+}
+
+extern "C" int swd_pipeline_stream_push(swd_stream *s, int32_t B, const uint8_t *det) {
+    HostStream *hs = (HostStream *)s;
+    if (!hs) { set_error("null stream"); return -1; }
+    return stream_push(hs, B, det);
+}
+
+extern "C" int swd_pipeline_stream_pop(swd_stream *s, uint8_t *total, int32_t *stats, double *min_pm, int32_t *shot_result) {
+    HostStream *hs = (HostStream *)s;
+    if (!hs) { set_error("null stream"); return -1; }
+    return stream_pop(hs, total, stats, min_pm, shot_result, 0);
+}
+
+extern "C" int swd_pipeline_stream_pending(swd_stream *s) {
+    HostStream *hs = (HostStream *)s;
+    if (!hs) { set_error("null stream"); return -1; }
+    std::lock_guard<std::mutex> lk(hs->mu);
+    return (int)(hs->npush - hs->npop);
+}
+
+extern "C" int swd_pipeline_stream_push_dev(swd_stream *s, int32_t B, const uint8_t *det, int64_t det_stride, uint8_t *total,
+                                            int64_t total_stride, int32_t *stats, double *min_pm, int32_t *shot_result, void *after) {
+    HostStream *hs = (HostStream *)s;
+    if (!hs) { set_error("null stream"); return -1; }
+    std::lock_guard<std::mutex> lk(hs->mu);
+    if (hs->npush != hs->npop) { set_error("stream push_dev: host batches are in flight on this stream object"); return -1; }
+    Plan *d = hs->plan;
     SWD_HIP(hipSetDevice(d->device));
-    const size_t W = d->wins.size();
-    if (d->synd.reserve((size_t)B * d->num_det) || d->total.reserve((size_t)B * d->num_col) ||
-        d->stats.reserve(B * W * SWD_STAT_WORDS * 4) || d->pm.reserve(B * W * 8) || d->shot.reserve((size_t)B * 8))
-        return -1;
-    SWD_HIP(hipMemcpy(d->synd.p, det, (size_t)B * d->num_det, hipMemcpyHostToDevice));
-    int rc = swd_pipeline_decode_dev(h, B, d->synd.as<uint8_t>(), 0, d->total.as<uint8_t>(), 0, d->stats.as<int32_t>(),
-                                     d->pm.as<double>(), d->shot.as<int32_t>(), nullptr);
-    if (rc) return rc;
-    {
-        uint32_t err = 0;
-        if (swd_pipeline_status(h, &err)) return -1; // synchronises
-        if (err) { set_error("internal: a window waited more than 10 s for its predecessor (scheduling fault, flags 0x%x)", err); return -1; }
+    StreamLane &l = hs->lane[hs->npush & 1];
+    if (after) { // the producer of the inputs (and whoever still reads the output buffers) comes first
+        SWD_HIP(hipEventRecord(l.ready, (hipStream_t)after));
+        SWD_HIP(hipStreamWaitEvent(l.st, l.ready, 0));
     }
-    SWD_HIP(hipMemcpy(total, d->total.p, (size_t)B * d->num_col, hipMemcpyDeviceToHost));
-    if (shot_result) SWD_HIP(hipMemcpy(shot_result, d->shot.p, (size_t)B * 8, hipMemcpyDeviceToHost));
-    if (stats) SWD_HIP(hipMemcpy(stats, d->stats.p, B * W * SWD_STAT_WORDS * 4, hipMemcpyDeviceToHost));
-    if (min_pm) SWD_HIP(hipMemcpy(min_pm, d->pm.p, B * W * 8, hipMemcpyDeviceToHost));
+    int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, det, det_stride, total, total_stride, stats, min_pm, shot_result, l.st);
+    if (rc) return rc;
+    SWD_HIP(hipEventRecord(l.done, l.st));
+    hs->npush++; hs->npop++; // (nothing to pop: the results are the caller's device buffers)
+    return 0;
+}
+
+extern "C" int swd_pipeline_stream_wait(swd_stream *s, void *stream) {
+    HostStream *hs = (HostStream *)s;
+    if (!hs) { set_error("null stream"); return -1; }
+    std::lock_guard<std::mutex> lk(hs->mu);
+    SWD_HIP(hipSetDevice(hs->plan->device));
+    for (auto &l : hs->lane) {
+        if (stream) {
+            SWD_HIP(hipEventRecord(l.ready, l.st));
+            SWD_HIP(hipStreamWaitEvent((hipStream_t)stream, l.ready, 0));
+        } else SWD_HIP(hipStreamSynchronize(l.st));
+    }
     return 0;
 }
 

@@ -28,6 +28,34 @@ struct WindowHost {
 };
 
 struct Plan;
+// Streaming form of the window loop (include/swd.h: swd_pipeline_stream_*): two lanes, each with its own HIP stream, device
+// buffers and page-locked staging, so that the copies and the host-side unpacking of batch k overlap the launch of batch k + 1 and
+// the persistent grid of k + 1 fills the workgroup slots the tail of k leaves empty.
+struct StreamLane {
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr, ready = nullptr;
+    int B = 0;
+    bool busy = false;       // a host batch is in flight on this lane (pushed, not popped)
+    DevBuf dev;              // [ det | total bytes | bits | stats | min_pm | shot_result | status copy ]
+    PinnedBuf hin, hout;     // det in; [ bits | stats | min_pm | shot_result | status ] out
+    size_t o_total = 0, o_bits = 0, o_stats = 0, o_pm = 0, o_shot = 0, o_status = 0, dev_bytes = 0; // offsets inside dev
+    size_t h_stats = 0, h_pm = 0, h_shot = 0, h_status = 0, out_bytes = 0;                            // offsets inside hout
+};
+struct HostStream {
+    Plan *plan = nullptr;
+    int max_shots = 0, flags = 0;
+    StreamLane lane[2];
+    long long npush = 0, npop = 0;
+    bool owned_by_plan = false;
+    std::mutex mu;
+    ~HostStream() {
+        for (auto &l : lane) {
+            if (l.st) { (void)hipStreamSynchronize(l.st); (void)hipStreamDestroy(l.st); }
+            if (l.done) (void)hipEventDestroy(l.done);
+            if (l.ready) (void)hipEventDestroy(l.ready);
+        }
+    }
+};
 // Kernel variants: threads per shot, VNs per thread, column-degree bound, groups of four row positions.
 // A plan uses the first variant with NT >= m, NT*VF >= n, DM >= D, 4*KG >= K over all its windows.
 struct Variant {
@@ -90,8 +118,10 @@ struct Plan {
     double t_total_ms = 0;
     int64_t t_launches = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unique_ptr<HostStream> hstream; // the host-buffer entry point swd_pipeline_decode runs on its own two-lane stream object
 
     ~Plan() {
+        hstream.reset();
         if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
         for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
     }

@@ -525,25 +525,55 @@ class SlidingWindowDecoder:
                 pass
             self._h = None
 
-    def decode(self, det_data):
-        """det_data [B, num_det] (host) -> total_e_hat uint8 [B, num_col]; per-window records in
-        ``last_stats`` [B, W, 8] and ``last_min_pm`` [B, W]."""
+    def _check_det(self, det_data):
         d = np.asarray(det_data)
         if d.ndim != 2 or d.shape[1] != self.num_det:
             raise ValueError(f"det_data must have shape [B, {self.num_det}]")
-        d = np.ascontiguousarray((d.astype(np.int64) & 0xFF).astype(np.uint8))
+        if d.dtype != np.uint8 or not d.flags.c_contiguous:
+            d = np.ascontiguousarray((d.astype(np.int64) & 0xFF).astype(np.uint8))
+        return d
+
+    def decode(self, det_data, packed=False):
+        """det_data [B, num_det] (host) -> total_e_hat uint8 [B, num_col]; per-window records in
+        ``last_stats`` [B, W, 8] and ``last_min_pm`` [B, W].  ``packed=True`` returns total_e_hat bit-packed instead,
+        uint8 [B, ceil(num_col / 8)] (``np.unpackbits(bits, axis=1, count=num_col, bitorder="little")`` gives the bytes): the
+        faults always travel device -> host in that form (1098 B per shot instead of 8784 for the [[144,12,12]] experiment)."""
+        d = self._check_det(det_data)
         B = d.shape[0]
-        total = np.zeros((B, self.num_col), np.uint8)
-        st = np.zeros((B, self.W, _lib.STAT_WORDS), np.int32)
-        pm = np.zeros((B, self.W), np.float64)
-        shot = np.zeros((B, 2), np.int32)
-        rc = _lib.lib().swd_pipeline_decode(self._h, B, d.ctypes.data, total.ctypes.data, st.ctypes.data,
-                                            pm.ctypes.data, shot.ctypes.data)
+        total = np.empty((B, (self.num_col + 7) // 8 if packed else self.num_col), np.uint8)
+        st = np.empty((B, self.W, _lib.STAT_WORDS), np.int32)
+        pm = np.empty((B, self.W), np.float64)
+        shot = np.empty((B, 2), np.int32)
+        fn = _lib.lib().swd_pipeline_decode_packed if packed else _lib.lib().swd_pipeline_decode
+        rc = fn(self._h, B, d.ctypes.data, total.ctypes.data, st.ctypes.data, pm.ctypes.data, shot.ctypes.data)
         if rc:
             raise RuntimeError(f"swd_pipeline_decode failed: {_lib.last_error()}")
         self.last_stats, self.last_min_pm = st, pm
         self.last_obs_flips, self.last_flagged = shot[:, 0].astype(np.uint32), shot[:, 1].astype(bool)
         return total
+
+    def stream(self, max_shots, packed=False, want_stats=True):
+        """Streaming form for consecutive batches (``SlidingWindowStream``): two batches in flight on two lanes of this
+        pipeline, copies and unpacking of batch k overlapped with the launch of batch k + 1."""
+        return SlidingWindowStream(self, max_shots, packed=packed, want_stats=want_stats)
+
+    def decode_stream(self, batches, packed=False, want_stats=True):
+        """Generator over an iterable of host batches [B_k, num_det]: yields (total_e_hat, stats, min_pm, obs_flips, flagged) per
+        batch, in order, keeping two batches in flight (the deployment form of the shots loop of /root/reference/osd.py:130-191)."""
+        st, it = None, iter(batches)
+        try:
+            for d in it:
+                d = self._check_det(d)
+                if st is None:
+                    st = self.stream(d.shape[0], packed=packed, want_stats=want_stats)
+                if st.pending == 2:
+                    yield st.pop()
+                st.push(d)
+            while st is not None and st.pending:
+                yield st.pop()
+        finally:
+            if st is not None:
+                st.close()
 
     def decode_device(self, det, total=None, stats=None, min_pm=None, shot_result=None, stream=None,
                       want_stats=True):
@@ -599,6 +629,76 @@ class SlidingWindowDecoder:
         ms, k = C.c_double(), C.c_int64()
         _lib.lib().swd_pipeline_get_timing(self._h, C.byref(ms), C.byref(k))
         return ms.value, k.value
+
+
+class SlidingWindowStream:
+    """Two-lane stream of a ``SlidingWindowDecoder`` (C ABI: swd_pipeline_stream_*).  Host form: ``push(det)`` returns at once,
+    ``pop()`` waits for the oldest batch in flight -> (total_e_hat, stats, min_pm, obs_flips, flagged).  Device form:
+    ``push_device`` launches on the next lane with the caller's CUDA tensors (keep one set of outputs per lane), ``wait()`` joins."""
+
+    def __init__(self, dec, max_shots, packed=False, want_stats=True):
+        self.dec, self.packed, self.want_stats = dec, bool(packed), bool(want_stats)
+        self.max_shots = int(max_shots)
+        flags = (_lib.STREAM_PACKED if packed else 0) | (0 if want_stats else _lib.STREAM_NO_STATS)
+        self._h = _lib.lib().swd_pipeline_stream_create(dec._h, self.max_shots, flags)
+        if not self._h:
+            raise RuntimeError(f"swd_pipeline_stream_create failed: {_lib.last_error()}")
+        self._sizes = []
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().swd_pipeline_stream_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def pending(self):
+        return len(self._sizes)
+
+    def push(self, det_data):
+        d = self.dec._check_det(det_data)
+        if _lib.lib().swd_pipeline_stream_push(self._h, d.shape[0], d.ctypes.data):
+            raise RuntimeError(f"swd_pipeline_stream_push failed: {_lib.last_error()}")
+        self._sizes.append(d.shape[0])  # (the library has copied the detector bytes into its page-locked block)
+
+    def pop(self):
+        if not self._sizes:
+            raise RuntimeError("stream pop: no batch in flight")
+        B, dec = self._sizes.pop(0), self.dec
+        total = np.empty((B, (dec.num_col + 7) // 8 if self.packed else dec.num_col), np.uint8)
+        st = np.empty((B, dec.W, _lib.STAT_WORDS), np.int32) if self.want_stats else None
+        pm = np.empty((B, dec.W), np.float64) if self.want_stats else None
+        shot = np.empty((B, 2), np.int32)
+        rc = _lib.lib().swd_pipeline_stream_pop(self._h, total.ctypes.data, st.ctypes.data if st is not None else None,
+                                                pm.ctypes.data if pm is not None else None, shot.ctypes.data)
+        if rc != B:
+            raise RuntimeError(f"swd_pipeline_stream_pop failed: {_lib.last_error()}")
+        return total, st, pm, shot[:, 0].astype(np.uint32), shot[:, 1].astype(bool)
+
+    def push_device(self, det, total, stats=None, min_pm=None, shot_result=None, after=None):
+        """CUDA tensors as in ``SlidingWindowDecoder.decode_device``; ``after``: a torch stream whose work so far must precede
+        the launch (default: the current stream)."""
+        import torch
+        dec = self.dec
+        if det.dtype != torch.uint8 or det.dim() != 2 or det.shape[1] != dec.num_det or det.stride(1) != 1 or not det.is_cuda:
+            raise ValueError(f"det must be a uint8 CUDA tensor [B, {dec.num_det}] with unit column stride")
+        aft = torch.cuda.current_stream(det.device) if after is None else after
+        rc = _lib.lib().swd_pipeline_stream_push_dev(self._h, det.shape[0], det.data_ptr(), det.stride(0), total.data_ptr(), total.stride(0),
+                                                     stats.data_ptr() if stats is not None else None,
+                                                     min_pm.data_ptr() if min_pm is not None else None,
+                                                     shot_result.data_ptr() if shot_result is not None else None, aft.cuda_stream)
+        if rc:
+            raise RuntimeError(f"swd_pipeline_stream_push_dev failed: {_lib.last_error()}")
+
+    def wait(self, stream=None):
+        """stream=None: the host waits for both lanes; a torch stream: that stream waits (device-side)."""
+        if _lib.lib().swd_pipeline_stream_wait(self._h, stream.cuda_stream if stream is not None else None):
+            raise RuntimeError(f"swd_pipeline_stream_wait failed: {_lib.last_error()}")
 
 
 class DemSampler:

@@ -33,6 +33,8 @@ def gather_decisions(local, num_shots: int):
     if not (dist.is_available() and dist.is_initialized()):
         return local  # (a one-rank process group still runs the collective: the same code path at every N)
     world = dist.get_world_size()
+    if world == 1 and local.is_cuda and dist.get_backend() != "nccl":
+        return local  # a one-rank group on a backend that cannot all_gather device tensors (gloo): nothing to exchange
     sizes = [shard_bounds(num_shots, r, world) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

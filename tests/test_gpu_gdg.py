@@ -286,6 +286,22 @@ def test_threaded_ensemble_bb144_window_vs_oracle():
         print(f"bb144 window {wi}: {post} ensembles, {ties} with a tied different vector")
 
 
+def test_threaded_ensemble_bb144_64_hypotheses_vs_oracle():
+    """BASELINE configs[2] as written: "64 decimation hypotheses per shot" = max_tree_depth 5, max_side_depth 6 (main + 31 tree
+    threads with two leaves each + one side thread) on the [[144,12,12]] (3,1) windows 0 / 5 / 10 of the recorded run.  Vector,
+    converge flag, min_pm, winner and tie count of every shot against the oracle, whose restatement of this shape is pinned to
+    the reference's real threads in tests/test_oracle_vs_ref.py::test_gdg_multi_64_hypotheses_bb144_window."""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    kw.update(max_tree_depth=5, max_side_depth=6)
+    for wi in (0, 5, 10):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        tr = fx.Trace(f, f"gdg_win{wi}_", *mat.shape)
+        post, ties = _ensemble_vs_oracle(mat, priors, kw, tr.synd[:96], 15)
+        print(f"bb144 window {wi}, D = 5 / S = 6: {post} ensembles, {ties} with a tied different vector")
+
+
 def test_threaded_ensemble_weight2_known_answer():
     """`Syndrome code.ipynb` cell 6 (:233-234): only (0,72) and (1,73) converge, both with 14 flipped variable nodes -- the stored
     output of the reference's multi_thread=True run (recorded again in the fixture)"""

@@ -236,6 +236,24 @@ def test_fuzz_large_m_column_form_elimination_vs_oracle():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("seed", [7000, 7001])
+def test_v7816_osd_exits_vs_oracle(seed):
+    """The matrices of the fuzz campaign that exposed the round-3 miscompile (seeds 7000 / 7001, 121..300 checks: the
+    <256, 7, 8, 16> kernel returned a wrong vector on every OSD exit when built with -structurizecfg-skip-uniform-regions and the
+    explicitly scalar loop values) -- the same trials, deterministic, in the suite.  Fails if a compiler or
+    flag change brings the wrong OSD ordering back."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_vs_oracle.py"), "30", str(seed), "121", "300", "osdw"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "256" in last.split("threads per shot")[1].split("]")[0], last  # the 256-thread variants served these trials
+    assert int(last.split("osd_window comparisons")[1].split("shots through OSD")[0].split(",")[-1]) > 500, last  # and OSD exits were compared
+
+
 @pytest.mark.parametrize("mode", ["gd", "gdg", "bp"])
 def test_fuzz_guessing_decoders_vs_oracle(mode):
     """Randomised matrices and parameters for bpgd_decoder / bpgdg_decoder / bp_history_decoder, including

@@ -176,3 +176,64 @@ def test_x_basis_sliding_window_experiment():
     print(f"x-basis (5,2) p=0.004: {nerr}/{shots} logical errors (notebook 140/10000), flagged {int(flagged.sum())}")
     assert not flagged.any()
     assert ref // 3 < nerr < 2 * ref, (nerr, ref)
+
+
+def test_packed_output_and_streaming_equal_the_one_shot_decode():
+    """The host path of the notebooks: total_e_hat travels bit-packed (decode(packed=True) returns it as it travels), a call of
+    2048 shots or more is cut in two halves on the two lanes, and the streaming form (two batches in flight, ragged batch sizes)
+    returns batch by batch what separate decode() calls return -- all against the reference's recorded run."""
+    import torch
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "osd10_params")
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    want = fx.unpack(f["osd10_total"], plan.chk.shape[1])
+    dec = SlidingWindowDecoder(plan, **kw)
+    ncol = plan.chk.shape[1]
+    bits = dec.decode(det, packed=True)
+    assert bits.shape == (len(det), (ncol + 7) // 8)
+    assert np.array_equal(np.unpackbits(bits, axis=1, count=ncol, bitorder="little"), want)
+    st0, pm0, fl0 = dec.last_stats.copy(), dec.last_min_pm.copy(), dec.last_obs_flips.copy()
+    # a call large enough to be cut in two (the 192 recorded shots tiled): both halves, in order
+    reps = 11
+    big = np.tile(det, (reps, 1))
+    total = dec.decode(big)
+    assert np.array_equal(total, np.tile(want, (reps, 1)))
+    assert np.array_equal(dec.last_stats, np.tile(st0, (reps, 1, 1))) and np.array_equal(dec.last_min_pm, np.tile(pm0, (reps, 1)))
+    assert np.array_equal(dec.last_obs_flips, np.tile(fl0, reps)) and not dec.last_flagged.any()
+    # streaming: ragged batches, two in flight
+    cuts = [0, 64, 65, 130, 192]
+    batches = [det[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    got = list(dec.decode_stream(batches))
+    assert len(got) == len(batches)
+    for (a, b), (tot, st, pm, flips, flagged) in zip(zip(cuts[:-1], cuts[1:]), got):
+        assert np.array_equal(tot, want[a:b]) and np.array_equal(st, st0[a:b]) and np.array_equal(pm, pm0[a:b])
+        assert np.array_equal(flips, fl0[a:b]) and not flagged.any()
+    # packed stream without statistics; a third push without a pop is refused
+    s = dec.stream(192, packed=True, want_stats=False)
+    s.push(det); s.push(det[:100])
+    with pytest.raises(RuntimeError):
+        s.push(det)
+    t1, st, pm, _, _ = s.pop()
+    assert st is None and pm is None and np.array_equal(np.unpackbits(t1, axis=1, count=ncol, bitorder="little"), want)
+    t2 = s.pop()[0]
+    assert np.array_equal(np.unpackbits(t2, axis=1, count=ncol, bitorder="little"), want[:100])
+    with pytest.raises(RuntimeError):
+        s.pop()
+    s.close()
+    # device form: launches alternate between the two lanes, one set of output tensors per lane
+    dev = torch.device("cuda", 0)
+    d_t = torch.from_numpy(det).to(dev)
+    outs = [dict(total=torch.empty((len(det), ncol), dtype=torch.uint8, device=dev), stats=torch.empty((len(det), 11, 8), dtype=torch.int32, device=dev),
+                 shot_result=torch.empty((len(det), 2), dtype=torch.int32, device=dev)) for _ in range(2)]
+    s = dec.stream(len(det))
+    for i in range(6):
+        s.push_device(d_t, **outs[i % 2])
+    s.wait()
+    for o in outs:
+        assert np.array_equal(o["total"].cpu().numpy(), want) and np.array_equal(o["stats"].cpu().numpy(), st0)
+        assert np.array_equal(o["shot_result"].cpu().numpy()[:, 0].astype(np.uint32), fl0)
+    s.wait(torch.cuda.current_stream(dev))
+    dec.check_status()
+    s.close()

@@ -13,11 +13,28 @@ from oracle import oracle as O
 from tests import fixtures as fx
 
 REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libswd_ref.so")
-pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built (needs /root/reference)")
+HAVE_REFERENCE = os.path.isdir("/root/reference/src/include")
+# Where the reference's sources exist (the build container) a missing library is a FAILURE -- the strongest pin of the oracle must
+# not disappear silently there; on a box without /root/reference (the GPU box) the library travels prebuilt, and if it is absent
+# too the skip says so loudly.
+if not os.path.exists(REF) and not HAVE_REFERENCE:
+    import warnings
+    warnings.warn("oracle/_ref/libswd_ref.so is absent and /root/reference does not exist here: the oracle-vs-reference pin "
+                  "(tests/test_oracle_vs_ref.py) is NOT checked in this run; the recorded fixtures still are")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF) and not HAVE_REFERENCE,
+                                reason="ORACLE PIN NOT CHECKED: oracle/_ref/libswd_ref.so absent and no /root/reference to build it from")
+
+
+def test_ref_library_is_built():
+    """/root/reference present => `make -C oracle ref` (run by __graft_entry__.build()) must have produced the library"""
+    assert os.path.exists(REF), ("oracle/_ref/libswd_ref.so is missing although /root/reference exists: run "
+                                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C oracle ref`")
+
 
 
 @pytest.fixture(scope="module")
 def R():
+    assert os.path.exists(REF), "oracle/_ref/libswd_ref.so is missing although /root/reference exists (make -C oracle ref)"
     L = C.CDLL(REF)
     vp, i32 = C.c_void_p, C.c_int32
     L.ref_pcm_new.restype = vp
@@ -202,6 +219,23 @@ def test_threaded_ensemble_bb144_window(R):
     kw.pop("multi_thread")
     ran, conv, ties = _ensemble_case(R, mat, priors, kw, list(tr.synd[:192]))
     assert ran >= 40 and conv >= 30, (ran, conv, ties)
+
+
+def test_gdg_multi_64_hypotheses_bb144_window(R):
+    """BASELINE configs[2] as written -- 64 decimation hypotheses per shot: max_tree_depth 5, max_side_depth 6 (main + 31 tree threads
+    with two leaves each + one side thread) -- on [[144,12,12]] circuit-level windows: every thread's path metric of the oracle's
+    restatement against the reference's REAL threads (ref_gdg_multi), the shared minimum, and the vector wherever it is unique."""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    kw.update(max_tree_depth=5, max_side_depth=6)
+    tot = [0, 0, 0]
+    for wi in (0, 5, 10):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        tr = fx.Trace(f, f"gdg_win{wi}_", *mat.shape)
+        r = _ensemble_case(R, mat, priors, kw, list(tr.synd[:64]))
+        tot = [a + b for a, b in zip(tot, r)]
+    assert tot[0] >= 30 and tot[1] >= 25, tot
 
 
 def test_threaded_ensemble_weight2_known_answer():
