@@ -12,17 +12,29 @@ by torch.distributed.run (the driver's way) it is one rank of the job.
 
 One "step" = one pass of the whole hot path over one batch of synthetic shots: a single launch of the
 sliding-window pipeline kernel that decodes shots x 11 windows with commit and residual-syndrome update.
+Consecutive steps go through the product's streaming entry (include/swd.h: swd_pipeline_stream_push_dev -- two lanes, each with
+its own HIP stream, launch slot and output buffers): step k + 1 is launched while step k still runs and its persistent grid takes
+the workgroup slots that the tail of step k leaves empty.  Every one of the K timed steps starts and finishes inside the timed
+region.  `--no-stream` times one launch at a time instead (also reported as config.single_stream_windows_per_s); the kernel
+duration behind `roofline` is always measured one launch at a time, with HIP events on the launch stream, after the timed region.
 Detector data is sampled from the DEM on the device BEFORE the timed region and is resident in HBM when timing
 starts.  Shots are sharded over ranks with no data-path collective (weak: 4096 shots per GPU; strong: a fixed
 total split contiguously); one RCCL all_gather of the per-shot decisions (observable flips + flagged bit,
 slidingwindowdecoder_amd.distributed.gather_decisions) closes the job inside the timed region.
 
 Rank 0 prints ONE JSON line.  `roofline`: the kernel keeps its messages in LDS, so HBM is not what bounds it;
-`frac` is the largest of the CAPACITY-BOUNDED utilisations -- LDS array busy (SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x t)),
-VALU busy at four cycles per wave instruction (SQ_INSTS_VALU x 4 / (1024 SIMDs x 2.4 GHz x t)) and HBM
-((2 x FETCH_SIZE + WRITE_SIZE) / 8 TB/s) -- none of which can exceed 1; the counters come from the committed rocprofv3
-profile of this same command (profiles/<tag>_<workload>_*), the time from HIP events measured live, and the line says
-`profile_stale` when the live kernel time has moved away from the profiled one.  `lds_pipe` (wave time inside LDS
+`frac` is the largest of the CAPACITY-BOUNDED utilisations, none of which can exceed 1:
+  lds   the CU's LDS pipeline: SQ_LDS_IDX_ACTIVE (array cycles incl. bank conflicts) + 2 cycles per store instruction (the
+        address / data transfer of a ds_write takes 2 cycles more than its array cycles: MI355X_MICROARCH.md, LDS table)
+        / (256 CUs x 2.4 GHz x t)
+  valu  VALU instructions priced by width: 4 cycles per wave64 instruction for the fp64-rate kinds (SQ_INSTS_VALU_ADD/MUL/FMA/
+        TRANS_F64 counted by the hardware + min / max / compare on doubles, which no counter separates: their static ratio to the
+        double adds in the kernel's ISA, profiles/<tag>_<workload>_isa_mix.json), 2 cycles for the rest / (1024 SIMDs x 2.4 GHz x t)
+  hbm   (2 x FETCH_SIZE + WRITE_SIZE) / 8 TB/s
+The counters come from the committed rocprofv3 profile of this same command (profiles/<tag>_<workload>_*), the time from HIP
+events measured live, and the line says `profile_stale` when the live kernel time has moved away from the profiled one.
+`lds_algorithmic_frac` = the LDS bytes the BP iterations must move (32 per live edge and iteration) over the ~79 TB/s a
+half-read / half-write 8-byte mix can move: the useful share of the busy time.  `lds_pipe` (wave time inside LDS
 instructions) is a diagnostic, not a capacity.  SURVEY 8(d)'s algorithmic-bytes figure is reported next to it as
 `achieved_algorithmic` (it exceeds the HBM peak: that is the traffic the LDS-resident design avoids, not a utilisation),
 and `lds_bytes_algorithmic` (32 E per executed BP iteration) against `lds_bytes_moved` (SQ_INSTS_LDS x 512) shows the
@@ -51,12 +63,16 @@ GDG_KW = dict(decoder="bpgdg_decoder", max_iter=8, max_iter_per_step=6, max_step
               max_tree_branch_step=10, max_side_branch_step=10)  # `Sliding Window GDG.ipynb` cell 3
 # --workload: the headline (BASELINE configs[1], what the driver measures) or one of the other circuit-level configurations
 # under the same launcher / sharding / gather (north star: "reported at 1, 2, 4 and 8 GPUs")
+GDG64_KW = dict(GDG_KW, multi_thread=True, max_tree_depth=5, max_side_depth=6)  # BASELINE configs[2] as written: 64 hypotheses per shot
 WORKLOADS = {
     "headline": dict(problem=dict(), metric="sliding windows decoded/s, [[144,12,12]] BB p=0.003",
                      desc="configs[1]: [[144,12,12]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(3,1) -> 11 windows/shot, "
                           "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d)"),
     "gdg": dict(problem=dict(), metric="sliding windows decoded/s, [[144,12,12]] BB p=0.003, bpgdg_decoder",
                 desc="configs[2]: [[144,12,12]] BB, circuit-level p=0.003, (3,1) windows, bpgdg_decoder(max_iter=8, T=6, R=25, D=3, S=10)"),
+    "gdg64": dict(problem=dict(), metric="sliding windows decoded/s, [[144,12,12]] BB p=0.003, bpgdg_decoder(multi_thread=True), 64 hypotheses",
+                  desc="configs[2] as written: [[144,12,12]] BB, circuit-level p=0.003, (3,1) windows, the reference's threaded ensemble "
+                       "bpgdg_decoder(multi_thread=True, max_iter=8, T=6, R=25, D=5, S=6) = main + 31 tree threads x 2 leaves + 1 side thread"),
     "bb288": dict(problem=dict(N=288, W=4, F=1), metric="sliding windows decoded/s, [[288,12,18]] BB p=0.003",
                   desc="configs[3]: [[288,12,18]] BB, circuit-level p=0.003, 12 rounds, (W,F)=(4,1), "
                        "osd_window(pre=8, post=200, alpha=1.0, osd_cs order %d)"),
@@ -69,12 +85,12 @@ WORKLOADS = {
     # the quaternary decoder of configs[4], device-resident (the reference runs BP4 on code-capacity noise only: Misc.ipynb cell 2)
     "bp4": dict(problem=None, metric="bp4_osd decodes/s, [[144,12,12]] BB depolarizing p=0.02", unit="decodes/s",
                 desc="bp4_osd(max_iter=100, alpha=0.625, osd_cs order 10) on [[144,12,12]] hx/hz, depolarizing code-capacity noise p=0.02 "
-                     "(Misc.ipynb cell 2 setting), syndromes resident in HBM"),
+                     "(Misc.ipynb cell 2 setting), syndromes resident in HBM, persistent grid"),
 }
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9   # same guide: max clock
 NUM_CU, SIMD_PER_CU = 256, 4
-PROFILE_TAGS = ("r03",)  # newest first; find_profile falls back to the round-2 headline files
+PROFILE_TAGS = ("r04", "r03")  # newest first; find_profile falls back to the round-2 headline files
 STUB = os.environ.get("SWD_BENCH_STUB") == "1"  # launcher test on CPU: gloo + a stand-in decoder, never a measurement
 
 
@@ -170,7 +186,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--shots", type=int, default=4096, help="shots per GPU per step (weak scaling)")
+    ap.add_argument("--shots", type=int, default=None, help="shots per GPU per step (weak scaling); default 4096, bp4: 65536 decodes (a launch that fills the 256 CUs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline",
                     help="headline = BASELINE configs[1] (default; the only one with roofline / cpu_baseline); gdg, bb288 = configs[2], [3]")
@@ -180,7 +196,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-order0", "--no-order10", dest="no_side_order", action="store_true",
                     help="skip the extra measurement at the other OSD order (N = 1): order 0 next to the default 10, or 10 next to 0")
     ap.add_argument("--distinct-batches", type=int, default=4, help="pre-sampled batches cycled over the steps")
-    return ap.parse_args(argv)
+    ap.add_argument("--no-stream", action="store_true", help="time one launch at a time instead of the two-lane streaming entry")
+    args = ap.parse_args(argv)
+    if args.shots is None:
+        args.shots = 65536 if args.workload == "bp4" else 4096
+    return args
 
 
 def self_launch(args):
@@ -200,7 +220,7 @@ def self_launch(args):
     raise SystemExit(r.returncode)
 
 
-class StubEngine:
+class StubEngine:  # (launcher test only)
     """Stand-in for the device pipeline in the launcher test (SWD_BENCH_STUB=1): decisions are a pure function of
     the global shot number, so the gathered result can be checked; nothing it reports is a measurement."""
 
@@ -221,15 +241,19 @@ class StubEngine:
     def sync(self):
         pass
 
+    def finish(self):
+        pass
+
 
 class GpuEngine:
-    def __init__(self, args, rank, local_rank, lo, hi, plan, order, workload="headline"):
+    def __init__(self, args, rank, local_rank, lo, hi, plan, order, workload="headline", streaming=True):
         import torch
         from slidingwindowdecoder_amd import DemSampler, SlidingWindowDecoder
         self.torch = torch
         self.dev = torch.device("cuda", local_rank)
         self.plan, self.W = plan, len(plan.windows)
-        kw = dict(GDG_KW) if workload == "gdg" else dict(DECODER_KW, osd_order=order, **WORKLOADS[workload].get("decoder_kw", {}))
+        kw = dict(GDG_KW) if workload == "gdg" else (dict(GDG64_KW) if workload == "gdg64" else
+                                                     dict(DECODER_KW, osd_order=order, **WORKLOADS[workload].get("decoder_kw", {})))
         self.dec = SlidingWindowDecoder(plan, device=local_rank, **kw)
         shots = hi - lo
         self.nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
@@ -241,23 +265,59 @@ class GpuEngine:
             det, flips = sampler.sample_device(shots, seed=20240318, first_shot=i * (1 << 24) + lo)
             self.dets.append(det)
             self.obs_true.append(flips.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
-        self.total = torch.empty((shots, plan.chk.shape[1]), dtype=torch.uint8, device=self.dev)
-        self.stats = torch.empty((shots, self.W, 8), dtype=torch.int32, device=self.dev)
-        self.shot = torch.empty((shots, 2), dtype=torch.int32, device=self.dev)
+        # one set of output buffers per lane of the stream object (a launch writes the set of its lane)
+        self.streaming = streaming
+        self.out = [dict(total=torch.empty((shots, plan.chk.shape[1]), dtype=torch.uint8, device=self.dev),
+                         stats=torch.empty((shots, self.W, 8), dtype=torch.int32, device=self.dev),
+                         shot_result=torch.empty((shots, 2), dtype=torch.int32, device=self.dev)) for _ in range(2 if streaming else 1)]
+        self.stream = self.dec.stream(shots) if streaming else None
+        self.nstep = 0
+        self.last = 0
+
+    @property
+    def shot(self):  # decisions of the most recent step
+        return self.out[self.last]["shot_result"]
+
+    @property
+    def stats(self):
+        return self.out[self.last]["stats"]
 
     def step(self, i):
-        self.dec.decode_device(self.dets[i % self.nb], total=self.total, stats=self.stats, min_pm=None, shot_result=self.shot)
+        if self.streaming:
+            self.last = self.nstep & 1
+            self.stream.push_device(self.dets[i % self.nb], min_pm=None, **self.out[self.last])
+            self.nstep += 1
+        else:
+            self.dec.decode_device(self.dets[i % self.nb], min_pm=None, **self.out[0])
 
-    def set_timing(self, on):
-        self.dec.set_timing(on)  # HIP events around every kernel launch, on the launch stream
+    def finish(self):
+        """the current torch stream waits for both lanes (what follows on it -- the gather of the decisions -- sees the results)"""
+        if self.streaming:
+            self.stream.wait(self.torch.cuda.current_stream(self.dev))
 
-    def get_timing(self):
-        return self.dec.get_timing()
+    def kernel_timing(self, i0, k):
+        """k launches one at a time with HIP events around each on the launch stream (swd_pipeline_set_timing): the single-launch
+        kernel duration the roofline and the committed rocprof profile describe -> (total ms, launches, wall seconds)"""
+        o = self.out[0]
+        self.sync()
+        self.dec.decode_device(self.dets[i0 % self.nb], min_pm=None, **o)
+        self.sync()
+        self.dec.set_timing(True)
+        t0 = time.perf_counter()
+        for i in range(k):
+            self.dec.decode_device(self.dets[(i0 + i) % self.nb], min_pm=None, **o)
+        self.sync()
+        wall = time.perf_counter() - t0
+        ms, n = self.dec.get_timing()
+        self.dec.set_timing(False)
+        return ms, n, wall
 
     def check_status(self):
         self.dec.check_status()  # raises if any window of any launch gave up waiting for its predecessor
 
     def sync(self):
+        if self.streaming:
+            self.stream.wait()
         self.torch.cuda.synchronize()
 
 
@@ -311,6 +371,21 @@ class Bp4Engine:
     def check_status(self):
         pass
 
+    def finish(self):
+        pass
+
+    def kernel_timing(self, i0, k):
+        self.sync()
+        self.set_timing(True)
+        t0 = time.perf_counter()
+        for i in range(k):
+            self.step(i0 + i)
+        self.sync()
+        wall = time.perf_counter() - t0
+        ms, n = self.get_timing()
+        self.set_timing(False)
+        return ms, n, wall
+
     def sync(self):
         self.torch.cuda.synchronize()
 
@@ -348,13 +423,19 @@ def lds_algorithmic_bytes(plan, stats):
     return total
 
 
+LDS_MIX_PEAK_GBS = 79000.0  # what a half-read / half-write ds_*_b64 mix can move with every CU streaming (MI355X_MICROARCH.md, LDS: ~150 TB/s reads, 38-51 TB/s writes)
+
+
 def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducible):
     """Utilisation of the resources the kernel could be bound by.  Counters: the committed per-launch means of separate
     rocprofv3 --pmc passes of this same command (profiles/); time: the kernel time measured live with HIP events.
     `frac` is the largest of the capacity-bounded ones (each <= 1 by construction):
-      lds   SQ_LDS_IDX_ACTIVE (cycles the LDS array of a CU is busy, summed over the CUs) / (256 CUs x 2.4 GHz x t)
-      valu  SQ_INSTS_VALU x 4 (a wave64 instruction occupies its SIMD's vector ALU for at least four cycles) /
-            (1024 SIMDs x 2.4 GHz x t)
+      lds   (SQ_LDS_IDX_ACTIVE + 2 x SQ_INSTS_LDS_STORE) / (256 CUs x 2.4 GHz x t): cycles the CU's LDS pipeline is occupied --
+            array cycles incl. bank conflicts, plus the two cycles by which the address / data transfer of a store exceeds its
+            array cycles (guide, LDS table: ds_write_b32 4 vs 2, ds_write_b64 6 vs 4)
+      valu  (4 x fp64-rate instructions + 2 x the other VALU instructions) / (1024 SIMDs x 2.4 GHz x t); fp64-rate = the hardware's
+            SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 + the min / max / compare instructions on doubles, estimated as ADD_F64 x their
+            static ratio in the kernel's ISA (profiles/<tag>_<workload>_isa_mix.json) -- no counter separates them
       hbm   (2 x FETCH_SIZE + WRITE_SIZE) / (8 TB/s x t)"""
     sq, sm, sq_src, sm_src = find_profile(workload)
     out = {"kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "bound": "lds", "frac": None, "achieved": None,
@@ -368,14 +449,40 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
         # the counters belong to the binary that was profiled: flag the line when the live kernel time has moved away from it
         out["profile_stale"] = bool(prof_ms and abs(avg_kernel_s * 1e3 - prof_ms) > 0.05 * prof_ms)
         if "SQ_LDS_IDX_ACTIVE" in c:
-            busy = c["SQ_LDS_IDX_ACTIVE"] / NUM_CU / PEAK_CLOCK_HZ
+            stores = c.get("SQ_INSTS_LDS_STORE")
+            cyc = c["SQ_LDS_IDX_ACTIVE"] + (2.0 * stores if stores is not None else 0.0)
+            busy = cyc / NUM_CU / PEAK_CLOCK_HZ
             fr["lds"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
+                         "array_only_frac": c["SQ_LDS_IDX_ACTIVE"] / NUM_CU / PEAK_CLOCK_HZ / avg_kernel_s,
                          "bank_conflict_share": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"],
-                         "counter": "SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz)"}
+                         "counter": "(SQ_LDS_IDX_ACTIVE + 2 x SQ_INSTS_LDS_STORE) / (256 CUs x 2.4 GHz)" if stores is not None
+                                    else "SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz) (no per-kind LDS pass in this profile)"}
+            if stores is not None:
+                fr["lds"]["instructions_load_store_atomic"] = [c.get("SQ_INSTS_LDS_LOAD"), stores, c.get("SQ_INSTS_LDS_ATOMIC")]
+                for k in ("SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_CMD_FIFO_FULL"):
+                    if k in c:
+                        fr["lds"][k.lower() + "_share_of_cu_cycles"] = c[k] / NUM_CU / PEAK_CLOCK_HZ / avg_kernel_s
         if "SQ_INSTS_VALU" in c:
-            busy = c["SQ_INSTS_VALU"] * 4.0 / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
-            fr["valu"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
-                          "counter": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz)"}
+            mix = load_profile(sq_src.split("/")[-1].replace("_sq_counters.json", "_isa_mix.json")) if sq_src else None
+            if "SQ_INSTS_VALU_ADD_F64" in c:
+                hw64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+                ratio = (mix or {}).get("f64_minmaxcmp_per_f64_add")
+                est = c["SQ_INSTS_VALU_ADD_F64"] * ratio if ratio is not None else None
+                f64 = min(hw64 + (est or 0.0), c["SQ_INSTS_VALU"])
+                cyc = 4.0 * f64 + 2.0 * (c["SQ_INSTS_VALU"] - f64)
+                busy = cyc / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
+                fr["valu"] = {"frac": busy / avg_kernel_s, "busy_ms_at_peak_clock": busy * 1e3,
+                              "fp64_rate_instructions": f64, "fp64_rate_counted_by_hardware": hw64, "fp64_minmaxcmp_estimated": est,
+                              "all_valu_instructions": c["SQ_INSTS_VALU"],
+                              "bounds": {"every_instruction_at_2_cycles": 2.0 * c["SQ_INSTS_VALU"] / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ / avg_kernel_s,
+                                         "every_instruction_at_4_cycles": 4.0 * c["SQ_INSTS_VALU"] / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ / avg_kernel_s},
+                              "counter": "(4 x fp64-rate + 2 x other VALU instructions) / (1024 SIMDs x 2.4 GHz)"
+                                         + ("" if ratio is not None else " -- fp64 min / max / compare NOT included (no ISA mix file): lower bound")}
+            else:  # an older profile without the per-type pass: the bracket only
+                lo = 2.0 * c["SQ_INSTS_VALU"] / (NUM_CU * SIMD_PER_CU) / PEAK_CLOCK_HZ
+                fr["valu"] = {"frac": 2.0 * lo / avg_kernel_s, "busy_ms_at_peak_clock": 2.0 * lo * 1e3,
+                              "bounds": {"every_instruction_at_2_cycles": lo / avg_kernel_s, "every_instruction_at_4_cycles": 2.0 * lo / avg_kernel_s},
+                              "counter": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz): UPPER bound, no per-type pass in this profile"}
         traffic = sm.get("hbm_bytes_per_launch")
         if traffic:
             out["traffic"] = traffic
@@ -392,8 +499,11 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
         if "SQ_INSTS_LDS" in c:
             out["lds_bytes_moved"] = c["SQ_INSTS_LDS"] * 512.0
             out["lds_bytes_moved_note"] = "SQ_INSTS_LDS x 512 B (one 8-byte access per lane of a wave instruction)"
+        if sm.get("dispatch"):
+            out["scratch_bytes_per_lane"] = int(sm["dispatch"].get("Scratch_Size", 0) or 0)
     if lds_alg_bytes is not None:
         out["lds_bytes_algorithmic"] = lds_alg_bytes
+        out["lds_algorithmic_frac"] = lds_alg_bytes / avg_kernel_s / 1e9 / LDS_MIX_PEAK_GBS
         if out.get("lds_bytes_moved"):
             out["lds_padding_factor"] = out["lds_bytes_moved"] / lds_alg_bytes
     if irreducible is not None:
@@ -406,8 +516,9 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
     out["fractions"] = fr
     out["diagnostics"] = diag
     out["note"] = ("messages never leave LDS, so SURVEY 8(d)'s algorithmic bytes (40E+17n+2m per executed BP iteration + sort + OSD "
-                   "row adds + I/O) exceed what HBM could carry; frac = the highest capacity-bounded utilisation among the LDS array, "
-                   "the vector ALUs and HBM (counters from profiles/, time measured here with HIP events)")
+                   "row adds + I/O) exceed what HBM could carry; frac = the highest capacity-bounded utilisation among the CU's LDS "
+                   "pipeline, the vector ALUs priced by instruction width, and HBM (counters from profiles/, time measured here with "
+                   "HIP events on single launches)")
     if fr:
         bound = max(fr, key=lambda k: fr[k]["frac"])
         out.update({"bound": bound, "frac": fr[bound]["frac"]})
@@ -427,14 +538,13 @@ def time_steps(engine, args, dist, world, total_shots):
     for i in range(args.warmup):
         engine.step(i)
     engine.sync()
-    if hasattr(engine, "set_timing"):
-        engine.set_timing(True)  # kernel timing covers the timed steps only, not the warm-up launches
     if dist.is_initialized():
         dist.barrier()
     engine.sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         engine.step(args.warmup + i)
+    engine.finish()  # (streaming: the current stream waits for both lanes before the decisions are gathered)
     gathered = gather_decisions(engine.shot, total_shots)  # per-shot decisions of the last step, over RCCL
     engine.sync()
     if dist.is_initialized():
@@ -463,6 +573,7 @@ def main():
     wl = WORKLOADS[args.workload]
     headline = args.workload == "headline"
     osdw = args.workload in ("headline", "bb288", "global144")
+    streaming = not args.no_stream and args.workload != "bp4" and not STUB
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)
@@ -496,7 +607,7 @@ def main():
     elif args.workload == "bp4":
         engine = Bp4Engine(args, rank, local_rank, lo, hi)
     else:
-        engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload)
+        engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload, streaming=not args.no_stream)
     W = engine.W
     elapsed, gathered = time_steps(engine, args, dist, world, total_shots)
     assert gathered.shape[0] == total_shots, (gathered.shape, total_shots)
@@ -530,12 +641,17 @@ def main():
             raise SystemExit("gathered decisions differ from the expected ones")
         return
 
-    kern_ms, launches = engine.get_timing()  # the timed steps only (timing is switched on after the warm-up)
-    engine.set_timing(False)
+    engine.check_status()
+    # accounting data of the LAST timed step (copied before the timing loop below re-uses the first lane's buffers)
+    st = engine.stats.cpu().numpy()
+    sr = engine.shot.cpu().numpy()
+    # the single-launch kernel duration behind the roofline: HIP events around each launch on the launch stream, one launch at a
+    # time, after the timed region (streamed launches overlap, so their individual durations would not describe the kernel)
+    kt = max(3, min(args.steps, 20))
+    kern_ms, launches, single_wall = engine.kernel_timing(args.warmup + args.steps, kt)
     engine.check_status()
 
     # accounting (outside the timed region), on this rank's shard of the last step
-    st = engine.stats.cpu().numpy()
     avg_kernel_s = kern_ms / max(launches, 1) / 1e3
     cfg = {
         "workload": (wl["desc"] % args.osd_order if "%d" in wl["desc"] else wl["desc"]) + ", "
@@ -546,6 +662,9 @@ def main():
         # what closed the timed region: the RCCL (backend nccl) all_gather over this many ranks, or nothing (plain one-process run)
         "collective_backend": backend, "collective_ranks": dist_ranks,
         "kernel_launches_timed": int(launches),
+        "step_mode": ("two-lane stream (swd_pipeline_stream_push_dev): consecutive steps overlap" if streaming else "one launch at a time"),
+        "single_stream_windows_per_s": (hi - lo) * W * launches / single_wall if launches else None,
+        "single_stream_note": "this rank's shots, one launch at a time with HIP events and a host synchronisation per launch (the loop that times the kernel)",
     }
     alg_bytes = lds_alg = irr = None
     if args.workload == "bp4":
@@ -555,7 +674,6 @@ def main():
         kernel = "swd::bp4_kernel"
     else:
         last = (args.warmup + args.steps - 1) % engine.nb
-        sr = engine.shot.cpu().numpy()
         logical = (sr[:, 0].astype(np.int64) != engine.obs_true[last]) | (sr[:, 1] != 0)
         cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
         cfg.update({"exit_classes_pre_post_osd_rank0": [int(cls[0]), int(cls[1]), int(cls[2])], "sched_faults": int(cls[6]),
@@ -572,37 +690,15 @@ def main():
     if rank == 0 and world == 1 and headline and not args.no_side_order:
         # the same batches at the other OSD order (a second, untimed-by-the-driver loop): order 0 next to the notebooks' default 10
         side = 0 if args.osd_order != 0 else 10
-        e2 = GpuEngine(args, rank, local_rank, lo, hi, plan, side)
-        k2 = max(1, min(args.steps, 5))
+        e2 = GpuEngine(args, rank, local_rank, lo, hi, plan, side, streaming=streaming)
+        k2 = max(2, min(args.steps, 6))
         e2.step(0); e2.sync()
         t0 = time.perf_counter()
         for i in range(k2):
             e2.step(i)
         e2.sync()
-        cfg[f"osd_cs_order{side}_windows_per_s"] = total_shots * W * k2 / (time.perf_counter() - t0)
+        cfg[f"osd_cs_order{side}_windows_per_s"] = total_shots * W * k2 / (time.perf_counter() - t0)  # (same step mode)
         e2.check_status()
-
-    if rank == 0 and world == 1 and headline and not args.no_side_order:
-        # deployment-mode side figure: consecutive batches on two streams with their own output buffers -- the persistent grid of the
-        # next launch fills the workgroup slots that the tail of the previous one leaves empty (the headline `value` keeps one launch
-        # at a time, which is what the kernel-level roofline and the committed rocprof profile describe)
-        import torch as _t
-        e3 = [GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order) for _ in range(2)]
-        for e in e3[1:]:
-            e.dec = e3[0].dec  # ONE decoder handle: its launch slots keep concurrent launches apart
-        streams = [_t.cuda.Stream() for _ in range(2)]
-        k3 = max(4, min(args.steps, 40))
-        for i in range(4):
-            with _t.cuda.stream(streams[i % 2]):
-                e3[i % 2].step(i)
-        _t.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(k3):
-            with _t.cuda.stream(streams[i % 2]):
-                e3[i % 2].step(i)
-        _t.cuda.synchronize()
-        cfg["two_stream_windows_per_s"] = total_shots * W * k3 / (time.perf_counter() - t0)
-        e3[0].check_status()
 
     if rank == 0:
         line["config"] = cfg

@@ -132,7 +132,12 @@ typedef struct swd_gdg_params {
                                     metric is not shared by a second, different vector (statistics word 7 counts those; the
                                     reference's own answer depends on thread timing there).  stats for this mode: [4]
                                     hypotheses run, [5] BP blocks, [6] winner (0 main, 1.. tree ids, then side threads; -1 none),
-                                    [7] tied hypotheses with a different vector.  2: NOT a reference mode -- every leaf of gdg()'s
+                                    [7] tied hypotheses with a different vector.  Every decode has the state of a NEWLY BUILT
+                                    reference object: min_pm_error starts as zeros (when BPGD::reset fails the zero vector comes back; a
+                                    reference object that is re-used returns its PREVIOUS decode's vector there, bpgd.cpp:583, 619-625)
+                                    and each thread's 4-slot posterior history starts as zeros (a re-used reference thread keeps its
+                                    own stale slots when max_iter_per_step < 4).  The oracle and oracle/ref_shim.cpp build a fresh
+                                    object per decode too.  2: NOT a reference mode -- every leaf of gdg()'s
                                     decimation tree counts (no min_converge_depth pruning, no snapshot cap), smallest path metric
                                     wins, ties to the earliest in stack order. */
 } swd_gdg_params;

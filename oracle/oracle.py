@@ -267,6 +267,14 @@ class bpgdg_decoder(_GdgBase):
         k = lib().swo_gdg_ensemble_info(self._h, pm.ctypes.data, 256, C.byref(w), C.byref(t))
         return pm[:k].copy(), w.value, t.value
 
+    def ensemble_blocks(self):
+        """(BP blocks of the last ensemble decode, those at depth < max_tree_depth of the main / tree threads, the latter counted
+        once per distinct direction prefix)"""
+        t, p, u = C.c_int32(), C.c_int32(), C.c_double()
+        lib().swo_gdg_ensemble_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        lib().swo_gdg_ensemble_blocks(self._h, C.byref(t), C.byref(p), C.byref(u))
+        return t.value, p.value, u.value
+
     @property
     def cols(self):
         return np.ctypeslib.as_array(lib().swo_gdg_cols(self._h), (self.n,)).astype(np.int32)

@@ -616,6 +616,7 @@ struct swo_gdg {
      * [0] main thread, [1 .. T] tree threads by id, [T+1 .. T+S] side threads by index */
     double *ens_pm;
     int ens_count, ens_winner, ens_ties;
+    int ens_blocks, ens_blocks_prefix; double ens_blocks_unique; /* statistics: BP blocks of the last ensemble, those at depth < D of the main / tree threads, and the latter counted once per distinct prefix */
 };
 
 static void bpgd_alloc(bpgd_t *b, int m, int n, int num_iter, int low_error_mode, double factor) {
@@ -995,6 +996,7 @@ static void gdg_multi_run(swo_gdg *d) {
     for (int v = 0; v < n; v++) { const double *h = d->hist + (size_t)v * 4; d->llr_sum[v] = h[0] + h[1] + h[2] + h[3]; }
     index_sort(d->llr_sum, d->cols, n);
     d->ens_count = 1 + T + NS; d->ens_winner = -1; d->ens_ties = 0;
+    d->ens_blocks = d->ens_blocks_prefix = 0; d->ens_blocks_unique = 0.0;
     free(d->ens_pm); d->ens_pm = xcalloc(d->ens_count, sizeof(double));
     for (int i = 0; i < d->ens_count; i++) d->ens_pm[i] = 10000.0;
     double best = 10000.0;
@@ -1011,6 +1013,7 @@ static void gdg_multi_run(swo_gdg *d) {
     if (bpgd_reset(b, &d->t, d->cols, d->g->llr, d->synd) != -1) {
         for (int depth = 0; depth < d->p.max_step; depth++) {
             int conv = bpgd_min_sum_log(b);
+            d->ens_blocks++; if (depth < Dp) { d->ens_blocks_prefix++; d->ens_blocks_unique += 1.0 / (double)(1 << (Dp - depth)); }
             int guess_vn = -1;
             int favor = bpgd_select_vn(b, -3, depth == 0 ? -16 : -12, depth, &guess_vn); /* BEFORE the convergence test (:630-633) */
             if (conv || favor == -1 || guess_vn == -1) {
@@ -1043,6 +1046,7 @@ static void gdg_multi_run(swo_gdg *d) {
             double own_pm = 10000.0;
             for (int depth = 0; depth < d->p.max_tree_branch_step + Dp + 1; depth++) {
                 if (depth > 0 && !on_side) A_sum = -12;
+                d->ens_blocks++; if (depth < Dp) { d->ens_blocks_prefix++; d->ens_blocks_unique += 1.0 / (double)(1 << (Dp - depth)); }
                 if (bpgd_min_sum_log(b)) { own_pm = bpgd_get_pm(b); ens_offer(d, id, b, own_pm, &best, best_err); done = 1; break; }
                 int guess_vn = -1;
                 int favor = bpgd_select_vn(b, A, A_sum, depth, &guess_vn);
@@ -1063,6 +1067,7 @@ static void gdg_multi_run(swo_gdg *d) {
             if (bpgd_peel(b) == -1) continue;
             int depth = Dp + 1;
             for (int i = 0; i < d->p.max_tree_branch_step; i++) {
+                d->ens_blocks++;
                 if (bpgd_min_sum_log(b)) {
                     double pm = bpgd_get_pm(b);
                     if (pm > own_pm) break;
@@ -1090,6 +1095,7 @@ static void gdg_multi_run(swo_gdg *d) {
             if (bpgd_peel(b) == -1) continue;
             int depth = side_depth[j];
             for (int i = 0; i < d->p.max_side_branch_step; i++) {
+                d->ens_blocks++;
                 if (bpgd_min_sum_log(b)) { ens_offer(d, 1 + T + j, b, bpgd_get_pm(b), &best, best_err); break; }
                 int guess_vn = -1;
                 int favor = bpgd_select_vn(b, 0, -10, depth, &guess_vn);
@@ -1116,6 +1122,11 @@ int swo_gdg_ensemble_info(const swo_gdg *d, double *pm, int cap, int32_t *winner
     if (winner) *winner = d->ens_winner;
     if (ties) *ties = d->ens_ties;
     return d->ens_count;
+}
+/* BP blocks (min_sum_log calls) of the last ensemble decode: all, those of the main / tree threads at depth < max_tree_depth, and the
+ * latter with a block shared by every thread of one direction prefix counted once (what a walk of the prefix tree would run) */
+void swo_gdg_ensemble_blocks(const swo_gdg *d, int32_t *total, int32_t *prefix, double *prefix_unique) {
+    *total = d->ens_blocks; *prefix = d->ens_blocks_prefix; *prefix_unique = d->ens_blocks_unique;
 }
 const int *swo_gdg_cols(const swo_gdg *d) { return d->cols; }
 

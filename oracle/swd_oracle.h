@@ -103,6 +103,7 @@ int swo_gdg_decode(swo_gdg *d, int mode, const uint8_t *synd, uint8_t *out, swo_
  * none) and how many converged hypotheses share the winning metric with a different vector (> 0: the reference's own answer
  * depends on thread timing) */
 int swo_gdg_ensemble_info(const swo_gdg *d, double *pm, int cap, int32_t *winner, int32_t *ties);
+void swo_gdg_ensemble_blocks(const swo_gdg *d, int32_t *total, int32_t *prefix, double *prefix_unique);
 const int *swo_gdg_cols(const swo_gdg *d); /* column order of the last post-processing (index_sort of the history sums) */
 const double *swo_gdg_history(const swo_gdg *d);
 

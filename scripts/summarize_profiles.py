@@ -78,7 +78,7 @@ for log in glob.glob(os.path.join(src, "stats.log")):
 json.dump(out, open(stem + "_summary.json", "w"), indent=1)
 
 vals = {}
-for d in ("sq1", "sq2"):
+for d in ("sq1", "sq2", "sq3", "sq4"):
     for f in newest(os.path.join(src, d, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if KERNEL in row["Kernel_Name"]:

@@ -292,7 +292,15 @@ def bb_dem(code, A_list, B_list, p: float, num_repeat: int, z_basis: bool = True
     ``dem_to_check_matrices(build_circuit(..., z_basis=z_basis).detector_error_model())``
     (/root/reference/osd.py:35-37).  ``column_order``: "circuit" (first appearance in circuit order; default for z-basis, where
     the reference's results do not depend on it) or "stim" (the reference's own order; default for x-basis, whose windows
-    are cut inside a column region -- dem_from_ops)."""
+    are cut inside a column region -- dem_from_ops).
+    The two modes also MERGE a mechanism's probabilities differently: "stim" merges the faults of one unit of the circuit (what
+    precedes the REPEAT block, each iteration, what follows) by p(1-q) + q(1-p) and ADDS the merged probabilities of the same symptom
+    across units, which is what ``dem_to_check_matrices`` does (/root/reference/src/build_circuit.py:262-270); "circuit" merges every
+    fault of the whole circuit by p(1-q) + q(1-p).  A symptom emitted by two units therefore gets p + q in "stim" and
+    p + q - 2pq in "circuit": the z-basis priors of the two modes differ by O(p^2) (at most 4.1e-5 absolute for p = 0.003,
+    tests/test_circuit.py::test_z_basis_prior_merge_modes).  The recorded fixtures, the headline bench and the notebook known
+    answers reproduced in tests/test_circuit.py all use the z-basis default "circuit"; every parity claim is on the decoder given
+    the SAME priors as the reference (make_golden.py feeds these priors to the reference), not on the DEM construction."""
     if column_order is None:
         column_order = "circuit" if z_basis else "stim"
     if column_order == "circuit":

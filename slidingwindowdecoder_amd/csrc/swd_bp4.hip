@@ -27,7 +27,18 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
         SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<NT, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
         lds_limit[d->device & 63] = d->L.total;
     }
-    hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(a.camel ? 4 * a.B : a.B), dim3(NT), d->L.total, st, a);
+    // persistent grid: as many workgroups as the device holds at once, each walks its share of the units
+    static int slots[64] = {0}, slots_lds[64] = {0};
+    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total) {
+        int per_cu = 0, cus = 0;
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<NT, DM>, NT, (size_t)d->L.total));
+        SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
+        while (per_cu > 1 && (long long)per_cu * ((d->L.total + 1279) / 1280 * 1280) > 160 * 1024) --per_cu; // LDS is granted in granules of 1280 B (swd_plan.h)
+        slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
+        slots_lds[d->device & 63] = d->L.total;
+    }
+    const int units = a.camel ? 4 * a.B : a.B;
+    hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(std::min(units, slots[d->device & 63])), dim3(NT), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
     return 0;
 }

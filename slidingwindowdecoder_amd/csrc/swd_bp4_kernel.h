@@ -92,8 +92,9 @@ template <int NT, int DM>
 __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SwdGraphDev &gx = a.gx, &gz = a.gz;
-    const int tid = threadIdx.x, unit = blockIdx.x, b = a.camel ? unit >> 2 : unit, n = gx.n, mx = gx.m, mz = gz.m;
+    const int tid = threadIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
     const int fixed = a.camel ? n - 1 : -1; // the decided qubit of a camel run
+    const int nunits = a.camel ? 4 * a.B : a.B;
     double *msgx = (double *)smem, *msgz = (double *)(smem + a.L.off_msgz);
     uint16_t *jpx = (uint16_t *)(smem + a.L.off_jptrx), *jpz = (uint16_t *)(smem + a.L.off_jptrz);
     int8_t *cnx = (int8_t *)(smem + a.L.off_cnx), *cnz = (int8_t *)(smem + a.L.off_cnz);
@@ -103,25 +104,56 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
     Lds s;
     s.scratch = smem; s.msg = msgx; s.hard = (uint8_t *)(smem + a.L.off_hard);
     s.flags = (int *)(smem + a.L.off_misc); s.scal = s.flags + 32; s.dbl = (double *)(s.scal + 32); s.iaux = (int *)(s.dbl + 24);
-    s.fpar = 0; s.ctid = s.vtid = threadIdx.x;
+    s.ctid = s.vtid = threadIdx.x;
+    // what does not depend on the syndrome is set up once per workgroup: the grid is persistent (as many workgroups as the device
+    // holds, each taking units blockIdx.x, blockIdx.x + gridDim.x, ...), and when every variable node has a thread of its own
+    // (n <= NT: the BB and SHYPS codes of the notebooks) its edges, degrees and channel LLRs stay in registers -- no global load
+    // and no posterior store inside the iterations (the posteriors of the last update are stored once, after the loop)
+    for (int j = tid; j <= gx.K; j += NT) jpx[j] = gx.jptr[j];
+    for (int j = tid; j <= gz.K; j += NT) jpz[j] = gz.jptr[j];
+    const bool one = n <= NT;
+    const bool mine = one && tid < n;
+    int c_dx = 0, c_dz = 0;
+    uint32_t c_ex[DM], c_ez[DM];
+    double c_lx = 0.0, c_ly = 0.0, c_lz = 0.0;
+#pragma unroll
+    for (int k = 0; k < DM; ++k) { c_ex[k] = 0u; c_ez[k] = 0u; }
+    if (mine) {
+        c_dx = gx.col_deg[tid]; c_dz = gz.col_deg[tid];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            c_ex[k] = (k < c_dx) ? gx.vn_edge[k * n + tid] : 0u;
+            c_ez[k] = (k < c_dz) ? gz.vn_edge[k * n + tid] : 0u;
+        }
+        c_lx = a.llr_x[tid]; c_ly = a.llr_y[tid]; c_lz = a.llr_z[tid];
+    }
+    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int b = a.camel ? unit >> 2 : unit;
+    s.fpar = 0;
     const uint8_t *sx_b = a.sx + (int64_t)b * mx, *sz_b = a.sz + (int64_t)b * mz;
     double *lpr_b = a.lpr + (int64_t)unit * 3 * n;
+    double p_x = 0.0, p_y = 0.0, p_z = 0.0; // (one node per thread) the posteriors of the last update
+    bool p_set = false;
+    __syncthreads(); // the previous unit is done with LDS
 
     // reset + bp_init (bp4_osd.pyx:371-386, 425-442)
     for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
     for (int l = tid; l < mz; l += NT) cnz[l] = (int8_t)(sz_b[gz.perm[l]] ? 1 : 0);
     for (int r = tid; r < mx; r += NT) sxo[r] = sx_b[r] ? 1 : 0;
     for (int r = tid; r < mz; r += NT) szo[r] = sz_b[r] ? 1 : 0;
-    for (int j = tid; j <= gx.K; j += NT) jpx[j] = gx.jptr[j];
-    for (int j = tid; j <= gz.K; j += NT) jpz[j] = gz.jptr[j];
     for (int v = tid; v < n; v += NT) {
         decx[v] = 0; decz[v] = 0;
-        const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
+        const double llrx = one ? c_lx : a.llr_x[v], llry = one ? c_ly : a.llr_y[v], llrz = one ? c_lz : a.llr_z[v];
         const double m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
         const double m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz); // sic (bp4_osd.pyx:438)
-        const int dx = gx.col_deg[v], dz = gz.col_deg[v];
-        for (int k = 0; k < dx; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
-        for (int k = 0; k < dz; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
+        const int dx = one ? c_dx : (int)gx.col_deg[v], dz = one ? c_dz : (int)gz.col_deg[v];
+        if (one) {
+#pragma unroll
+            for (int k = 0; k < DM; ++k) { if (k < dx) msgx[swd_edge_slot(c_ex[k])] = m_x; if (k < dz) msgz[swd_edge_slot(c_ez[k])] = m_z; }
+        } else {
+            for (int k = 0; k < dx; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
+            for (int k = 0; k < dz; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
+        }
     }
     __syncthreads();
     if (a.camel) { // vn_set_value(n - 1, value) after bp_init (bp4_osd.pyx:234-236, 388-423): the qubit keeps its prior messages
@@ -150,14 +182,15 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
                 for (int k = 0; k < gz.col_deg[v]; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
                 continue;
             }
-            const int dx = gx.col_deg[v], dz = gz.col_deg[v];
+            const int dx = one ? c_dx : (int)gx.col_deg[v], dz = one ? c_dz : (int)gz.col_deg[v];
             uint32_t ex[DM], ez[DM];
             double cx[DM], cz[DM];
 #pragma unroll
             for (int k = 0; k < DM; ++k) {
-                ex[k] = (k < dx) ? gx.vn_edge[k * n + v] : 0u;
-                ez[k] = (k < dz) ? gz.vn_edge[k * n + v] : 0u;
+                ex[k] = one ? c_ex[k] : ((k < dx) ? gx.vn_edge[k * n + v] : 0u);
+                ez[k] = one ? c_ez[k] : ((k < dz) ? gz.vn_edge[k * n + v] : 0u);
             }
+            const double v_lx = one ? c_lx : a.llr_x[v], v_ly = one ? c_ly : a.llr_y[v], v_lz = one ? c_lz : a.llr_z[v];
 #pragma unroll
             for (int k = 0; k < DM; ++k) { cx[k] = msgx[swd_edge_slot(ex[k])]; cz[k] = msgz[swd_edge_slot(ez[k])]; }
             double llrx_hx = 0.0, llrz_hz = 0.0;
@@ -165,10 +198,11 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
             for (int k = 0; k < DM; ++k) if (k < dz) llrx_hx += cz[k];
 #pragma unroll
             for (int k = 0; k < DM; ++k) if (k < dx) llrz_hz += cx[k];
-            const double llry_all = llrx_hx + llrz_hz + a.llr_y[v];
-            llrx_hx = llrx_hx + a.llr_x[v];
-            llrz_hz = llrz_hz + a.llr_z[v];
-            lpr_b[v] = llrx_hx; lpr_b[n + v] = llry_all; lpr_b[2 * n + v] = llrz_hz;
+            const double llry_all = llrx_hx + llrz_hz + v_ly;
+            llrx_hx = llrx_hx + v_lx;
+            llrz_hz = llrz_hz + v_lz;
+            if (one) { p_x = llrx_hx; p_y = llry_all; p_z = llrz_hz; p_set = true; }
+            else { lpr_b[v] = llrx_hx; lpr_b[n + v] = llry_all; lpr_b[2 * n + v] = llrz_hz; }
             int idx;
             if (0 < llrx_hx && 0 < llry_all && 0 < llrz_hz) idx = 0;
             else if (llrx_hx < llry_all && llrx_hx < llrz_hz) idx = 1;
@@ -195,6 +229,7 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         }
         __syncthreads();
     }
+    if (p_set) { lpr_b[tid] = p_x; lpr_b[n + tid] = p_y; lpr_b[2 * n + tid] = p_z; } // (read back below by this thread only)
     if (!conv) {
         bool unsat = false;
         if (a.max_iter > 0) {
@@ -219,7 +254,7 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
             a.camel_pm[unit] = pm;
             a.camel_st[2 * unit] = conv; a.camel_st[2 * unit + 1] = iters;
         }
-        return;
+        continue;
     }
     uint8_t *out_b = a.out + (int64_t)b * 2 * n;
     if (a.bp_dec)
@@ -267,6 +302,7 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         st[0] = exit_class | (conv ? SWD_STATUS_CONVERGE : 0);
         st[1] = iters; st[2] = iters; st[3] = 0; st[4] = n; st[5] = mx + mz; st[6] = gx.E + gz.E; st[7] = rowadds;
     }
+    } // next unit
 }
 
 // camel_decode's choice among the four runs of a shot: the converged run of smallest path metric, strict < keeps

@@ -1147,6 +1147,293 @@ __device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const Swd
     R.live_vn = ran; R.live_cn = blocks; R.live_e = winner; R.osd_rowadds = ties;
 }
 
+// The same ensemble with the work its threads share done once: the walk of the PREFIX TREE.
+// A tree thread's first D steps are fixed by the direction bits of its id, and two threads whose ids share the first d bits do
+// exactly the same work through depth d - 1 -- same masks, same messages (an unfavoured guess does not re-initialise them), same
+// thresholds (they depend on the depth and on whether a 1-bit has been passed), hence the same BP block, the same select_vn
+// scan and the same guess at depth d.  The main thread walks the all-favoured path with the thresholds of a tree thread that has
+// not left it.  So the 2^D hypotheses (main = leaf 0, tree thread p = leaf p) are the leaves of a binary tree of depth D whose
+// inner node (d, prefix) is one BP block + one scan, shared by the 2^(D-d) threads below it: 2^D - 1 shared steps instead of
+// D 2^D.  (Oracle statistics on the [[144,12,12]] (3,1) windows: 153.6 -> 59.2 BP blocks per ensemble at D = 5 / S = 6,
+// 39.4 -> 24.1 at D = 3 / S = 10.)  Leaves are visited in increasing order (favoured child first): that is the order main, tree
+// threads by id in which the thread-by-thread form -- and the oracle -- make their strict-< offers, so winner and tie count come
+// out the same; an inner node that converges makes the offer for every thread below it (same metric, same vector: the first id
+// wins, the others neither win nor count as ties), after the main thread's own on the all-favoured path (main scans BEFORE its
+// convergence test, so its vector may carry more decimations than the tree threads': the post-block vector is stashed).  At a
+// fork the state AFTER the scan -- masks and all messages -- is saved; the unfavoured child is walked from it when its first leaf
+// comes up.  BP blocks and iterations are counted once per thread that would have run them.  From depth D on every thread is on
+// its own and the code is that of the thread-by-thread form; so are the side threads.
+// Snapshot area (per workgroup): slot 0 unused, 1 = the solo tree thread's saved masks, 2 + j = side thread j's, then D fork
+// records (masks + message cells), the stash vector and the main thread's exit vector.
+// A fork record's message part: with the static tree-walk cache (every position has its thread, with every edge of its column:
+// new_n <= 2 NT) each thread keeps the cells of its own positions -- VF x DM cells per thread, coalesced, every access in flight
+// at once; decided positions and padded edges copy the wave's zero slot, which is re-armed before anybody reads it.  Without the
+// static cache: all message cells of the window, eight per thread in flight.  (A first version copied every cell with one
+// dependent agent-scope access per loop turn: 25 us per fork, more than two BP blocks.)
+__device__ __forceinline__ int gdg_ens_fork_cells(int nmsg, int nt, int vf, int dm) { return max(nmsg, vf * dm * nt); }
+__device__ __forceinline__ int64_t gdg_ens_fork_bytes(int m, int new_n, int cells) { return ((gdg_snap_bytes(m, new_n) + 15) & ~(int64_t)15) + (((int64_t)cells * 8 + 15) & ~(int64_t)15); }
+template <int NT, int VF, int DM, class ST>
+__device__ __forceinline__ void gdg_msg_save(const Lds &s, const ST &st, int nmsg, uint8_t *dst) {
+    unsigned long long *d = (unsigned long long *)dst;
+    if constexpr (!std::is_same_v<ST, GdgNoStatic>) {
+#pragma unroll
+        for (int i = 0; i < VF; ++i) {
+            uint32_t ad[DM];
+            st.get_ed(i, ad);
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                __hip_atomic_store(&d[(i * DM + k) * NT + (int)threadIdx.x], *(const unsigned long long *)((const char *)s.msg + ad[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        const unsigned long long *src = (const unsigned long long *)s.msg;
+        for (int i0 = threadIdx.x; i0 < nmsg; i0 += 8 * NT) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u * NT, nmsg - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < nmsg) __hip_atomic_store(&d[i0 + u * NT], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+template <int NT, int VF, int DM, class ST>
+__device__ __forceinline__ void gdg_msg_load(Lds &s, const ST &st, int nmsg, const uint8_t *srcb) {
+    const unsigned long long *src = (const unsigned long long *)srcb;
+    if constexpr (!std::is_same_v<ST, GdgNoStatic>) {
+        unsigned long long v[VF][DM];
+#pragma unroll
+        for (int i = 0; i < VF; ++i)
+#pragma unroll
+            for (int k = 0; k < DM; ++k) v[i][k] = __hip_atomic_load(&src[(i * DM + k) * NT + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < VF; ++i) {
+            uint32_t ad[DM];
+            st.get_ed(i, ad);
+#pragma unroll
+            for (int k = 0; k < DM; ++k) *(unsigned long long *)((char *)s.msg + ad[k]) = v[i][k];
+        }
+    } else {
+        unsigned long long *d = (unsigned long long *)s.msg;
+        for (int i0 = threadIdx.x; i0 < nmsg; i0 += 8 * NT) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(&src[min(i0 + u * NT, nmsg - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < nmsg) d[i0 + u * NT] = v[u];
+        }
+    }
+    __syncthreads();
+}
+
+// Written as ONE loop whose body runs a single step -- [restore a saved state] [decide a node + peel] BP block [scan] [offers, saves]
+// -- with the scalar bookkeeping around it deciding what the next step is: the BP block, the scan, the decimation and the
+// snapshot routines are each inlined exactly once (as straight-line copies of the thread bodies the kernel took 25 minutes to
+// compile and its code no longer fit the instruction cache).
+template <int NT, int VF, int DM, int KG, class ST>
+__device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
+                                                  double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
+                                                  GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const ST &st, const GdgCnMap &cmap) {
+    const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
+    const int Dp = P.max_tree_depth, S = P.max_side_depth;
+    const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
+    const int64_t rec = gdg_snap_bytes(m, new_n), rec16 = (rec + 15) & ~(int64_t)15;
+    const int nmsg = g.E + 1 + 2 * (NT / 64); // message cells incl. the sink and the waves' far / zero slots
+    const int64_t forkb = gdg_ens_fork_bytes(m, new_n, gdg_ens_fork_cells(nmsg, NT, VF, DM)), vecb = ((int64_t)new_n + 15) & ~(int64_t)15;
+    uint8_t *fork0 = snap_b + (((int64_t)(2 + NS) * rec + 15) & ~(int64_t)15);
+    uint32_t *stash = (uint32_t *)(fork0 + (int64_t)Dp * forkb); // post-block vector of a converged node on the all-favoured path
+    uint32_t *main_fb = (uint32_t *)((uint8_t *)stash + vecb);   // the main thread's error vector when it ends unconverged
+    const int NONE = 0x7fffffff;
+    enum { M_DESC, M_MAIN, M_TREE1, M_TREE2, M_SIDE };                                  // what the next step belongs to
+    enum { C_NONE, C_LEAF, C_DESC, C_MAIN, C_TREE1, C_BK, C_TREE2, C_SIDE0, C_SIDE };   // whose decimation precedes it
+    enum { ADV_NONE, ADV_LEAF, ADV_REPLAY, ADV_SIDE };                                  // where to go when a walk ends
+    enum { R_NONE, R_FORK, R_BK, R_SIDE };
+    double best = 10000.0;
+    int winner = -1, ties = 0, blocks = 0, sides_run = 0, it = 0;
+    bool main_alive = true, main_conv = false, have_main_fb = false;
+    int *nd_gpos = s.iaux + 16, *nd_fav = s.iaux + 24; // the guess of the fork at depth d (d < 6)
+    double h4[VF][4] = {};
+    auto vec_byte = [&](const uint32_t *v, int j) { return (uint8_t)((ag_ld(&v[j >> 2]) >> (8 * (j & 3))) & 0xFFu); };
+    // walk state
+    int mode = Dp > 0 ? M_DESC : M_MAIN, p = 0, d = 0, iter = 0, jside = -1, dead_depth = NONE;
+    bool first = true;                   // the next block starts from the priors
+    int adv = ADV_NONE, restore = R_NONE, rslot = 0, set_ctx = C_NONE, set_pos = NONE, set_val = 0;
+    bool prev_with_main = false;         // the pending decimation is also the main thread's
+    bool want_main_end = false;          // the main thread has left its loop: keep its vector (before any state is restored)
+    bool saved = false;                  // tree thread on its own: masks saved at depth D
+    double own_pm = 10000.0;
+    int bk_pos = NONE, bk_val = 0;
+    for (;;) {
+        if (want_main_end) { // the vector returned if nothing converges (bpgd.cpp:677-682)
+            if (!main_conv) { gdg_store_err<NT>(s, G, new_n, main_fb); ag_publish_barrier(); have_main_fb = true; }
+            main_alive = false; want_main_end = false;
+        }
+        if (adv == ADV_LEAF) { // the next leaf whose fork is alive: its path leaves that fork through the unfavoured child
+            int dstar = 0;
+            for (++p; p <= T; ++p) { dstar = Dp - __ffs(p); if (dead_depth > dstar) break; }
+            if (p > T) adv = ADV_SIDE;
+            else {
+                dead_depth = NONE;
+                restore = R_FORK; rslot = dstar;
+                set_ctx = C_LEAF; set_pos = nd_gpos[dstar]; set_val = 1 - nd_fav[dstar];
+                d = dstar + 1; first = false;
+                mode = d < Dp ? M_DESC : M_TREE1;
+                saved = false; own_pm = 10000.0;
+                adv = ADV_NONE;
+            }
+        }
+        if (adv == ADV_REPLAY) { // tree thread p: back to the masks saved at depth D, fresh messages, the unfavoured value (bpgd.cpp:501-523)
+            restore = R_BK; set_ctx = C_BK; set_pos = bk_pos; set_val = bk_val;
+            mode = M_TREE2; d = Dp + 1; iter = 0; first = true; adv = ADV_NONE;
+        }
+        if (adv == ADV_SIDE) { // the next side thread that was handed a snapshot (bpgd.cpp:527-570)
+            for (++jside; jside < NS; ++jside) if (G.alt_depth[jside] == Dp + jside + 1) break;
+            if (jside >= NS) break;
+            ++sides_run;
+            restore = R_SIDE; rslot = jside; set_ctx = C_SIDE0; set_pos = (int)G.dec_vn[jside]; set_val = (int)G.dec_val[jside];
+            mode = M_SIDE; d = G.alt_depth[jside]; iter = 0; first = true; adv = ADV_NONE;
+        }
+        if (restore != R_NONE) {
+            const uint8_t *src = restore == R_FORK ? fork0 + (int64_t)rslot * forkb : (restore == R_BK ? snap_b + rec : snap_b + (int64_t)(2 + rslot) * rec);
+            gdg_snap_load<NT>(g, s, G, src);
+            if (restore == R_FORK) gdg_msg_load<NT, VF, DM>(s, st, nmsg, src + rec16); // (an unfavoured guess does not re-initialise the messages)
+            restore = R_NONE;
+        }
+        if (set_ctx != C_NONE) { // vn_set_value + peel
+            __syncthreads();
+            if (tid < 64) {
+                bool bad = (set_pos == NONE) ? true : gdg_set_value_wave(g, s, G.pos_lv[set_pos], set_val);
+                if (!bad) bad = peel_wave<false, NT>(g, s);
+                if (tid == 0) s.scal[1] = bad ? 1 : 0;
+            }
+            __syncthreads();
+            const int ctx = set_ctx;
+            set_ctx = C_NONE;
+            if (s.scal[1] != 0) { // the threads that made this decimation end here
+                if (ctx == C_LEAF) { dead_depth = d; adv = ADV_LEAF; }
+                else if (ctx == C_DESC) { if (prev_with_main) want_main_end = true; dead_depth = d; adv = ADV_LEAF; }
+                else if (ctx == C_MAIN) { want_main_end = true; adv = ADV_LEAF; }
+                else if (ctx == C_TREE1) adv = saved ? ADV_REPLAY : ADV_LEAF;
+                else if (ctx == C_BK || ctx == C_TREE2) adv = ADV_LEAF;
+                else adv = ADV_SIDE;
+                continue;
+            }
+        }
+        // loop bounds of the thread bodies
+        if (mode == M_DESC) {
+            if (p == 0 && main_alive && d >= P.max_step) { // (max_step <= D: the main thread's loop is over, the tree threads go on)
+                if (!main_conv) { gdg_store_err<NT>(s, G, new_n, main_fb); ag_publish_barrier(); have_main_fb = true; }
+                main_alive = false;
+            }
+        } else if (mode == M_MAIN) {
+            if (d >= P.max_step) { want_main_end = true; adv = ADV_LEAF; continue; }
+        } else if (mode == M_TREE1) {
+            if (d >= P.max_tree_branch_step + Dp + 1) { adv = saved ? ADV_REPLAY : ADV_LEAF; continue; }
+        } else if (mode == M_TREE2) {
+            if (iter >= P.max_tree_branch_step) { adv = ADV_LEAF; continue; }
+        } else if (iter >= P.max_side_branch_step) { adv = ADV_SIDE; continue; }
+        // ---- one step: the BP block ...
+        const bool desc = mode == M_DESC;
+        const bool with_main = mode == M_MAIN || (desc && p == 0 && main_alive);
+        const int ntree = desc ? (1 << (Dp - d)) - (p == 0 ? 1 : 0) : 0; // tree threads that share this node
+        const int share = desc ? ntree + (with_main ? 1 : 0) : 1;
+        int cv;
+        {
+            const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn, cmap);
+            if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
+            first = false;
+            cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
+            blocks += share; R.post_it += it * share; // counted once per thread of the ensemble that runs this block
+        }
+        // ... the scan (the main thread scans BEFORE its convergence test, bpgd.cpp:630-633; the others only go on when the block failed)
+        double pm_t = 0.0;
+        if (cv && desc && with_main) { // the tree threads below this node offer the vector as it is now
+            pm_t = gdg_get_pm<NT>(g, s, G);
+            gdg_store_err<NT>(s, G, new_n, stash);
+            ag_publish_barrier();
+        }
+        int gpos = NONE, favor = 0, rc = 0;
+        if (!cv || with_main) {
+            const bool sidethr = !(mode == M_MAIN || (desc && p == 0)); // thresholds (0, -10) once an unfavoured branch has been taken
+            rc = gdg_select_core<NT>(g, P, s, G, hist_b, sidethr ? 0.0 : -3.0, sidethr ? -10.0 : (d == 0 ? -16.0 : -12.0), d, gpos, favor, st, h4);
+        }
+        if (cv) { // ---- a converged block: the strict-< offers, in the order main, tree threads by id, side threads
+            const double pm = gdg_get_pm<NT>(g, s, G);
+            int who = 0, count = 1;
+            bool offer = true;
+            if (desc) { who = with_main ? 0 : (p == 0 ? 1 : p); count = with_main ? 1 : ntree; }
+            else if (mode == M_TREE1) { who = p; own_pm = pm; }
+            else if (mode == M_TREE2) { who = p; offer = !(pm > own_pm); }
+            else if (mode == M_SIDE) who = 1 + T + jside;
+            if (with_main) main_conv = true;
+            if (offer) {
+                if (pm < best) {
+                    best = pm; winner = who; ties = 0;
+                    for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
+                    __syncthreads();
+                } else if (pm == best) { // same metric: a different vector makes the reference's answer timing dependent
+                    bool diff = false;
+                    for (int j = tid; j < new_n; j += NT) diff |= (G.best_err[j] != s.hard[G.pos_lv[j]]);
+                    if (block_any<NT>(diff, s)) ties += count;
+                }
+            }
+            if (desc && with_main && ntree > 0) { // ... then the tree threads of the all-favoured path, with the stashed vector
+                if (pm_t < best) {
+                    best = pm_t; winner = 1; ties = 0;
+                    for (int j = tid; j < new_n; j += NT) G.best_err[j] = vec_byte(stash, j);
+                    __syncthreads();
+                } else if (pm_t == best) {
+                    bool diff = false;
+                    for (int j = tid; j < new_n; j += NT) diff |= (G.best_err[j] != vec_byte(stash, j));
+                    if (block_any<NT>(diff, s)) ties += ntree;
+                }
+            }
+            if (with_main) main_alive = false; // (converged: nothing to keep for the fallback)
+            if (desc) dead_depth = d;
+            adv = mode == M_SIDE ? ADV_SIDE : ADV_LEAF;
+            continue;
+        }
+        if (rc == -1 || gpos == NONE) { // the scan failed: the threads of this step end
+            if (with_main) want_main_end = true;
+            if (desc) dead_depth = d;
+            adv = mode == M_SIDE ? ADV_SIDE : (mode == M_TREE1 && saved ? ADV_REPLAY : ADV_LEAF);
+            continue;
+        }
+        // ---- the guess: save what later walks start from, then decide the favoured value (at the top of the next turn)
+        {
+            uint8_t *dst = nullptr;
+            if (desc) dst = fork0 + (int64_t)d * forkb;                                        // fork: the unfavoured child starts here
+            else if (mode == M_MAIN && d >= Dp && d < S) dst = snap_b + (int64_t)(2 + d - Dp) * rec; // handed to side thread d - D
+            else if (mode == M_TREE1 && d == Dp) dst = snap_b + rec;                             // the tree thread's own way back
+            if (dst) {
+                gdg_snap_save<NT>(g, s, G, dst);
+                if (desc) gdg_msg_save<NT, VF, DM>(s, st, nmsg, dst + rec16);
+                if (tid == 0) {
+                    if (desc) { nd_gpos[d] = gpos; nd_fav[d] = favor; }
+                    else if (mode == M_MAIN) { const int j = d - Dp; G.dec_vn[j] = (int16_t)gpos; G.dec_val[j] = (int8_t)(1 - favor); G.alt_depth[j] = (int16_t)(d + 1); }
+                }
+                if (mode == M_TREE1) { bk_pos = gpos; bk_val = 1 - favor; saved = true; }
+                ag_publish_barrier();
+            }
+        }
+        set_pos = gpos; set_val = favor; prev_with_main = with_main;
+        set_ctx = desc ? C_DESC : (mode == M_MAIN ? C_MAIN : (mode == M_TREE1 ? C_TREE1 : (mode == M_TREE2 ? C_TREE2 : C_SIDE)));
+        if (mode == M_TREE2 || mode == M_SIDE) ++iter;
+        ++d;
+        if (desc && d == Dp) { // the shared part of this path ends: the leaf's thread goes on alone
+            if (p == 0) {
+                if (main_alive) mode = M_MAIN;
+                else { set_ctx = C_NONE; adv = ADV_LEAF; } // (no tree thread 0: nobody walks the all-favoured leaf)
+            } else { mode = M_TREE1; saved = false; own_pm = 10000.0; }
+        }
+    }
+    __syncthreads();
+    if (!(best < 9999.0) && have_main_fb) { // nothing converged: the main thread's vector as it left its loop (:677-682)
+        for (int j = tid; j < new_n; j += NT) G.best_err[j] = vec_byte(main_fb, j);
+        __syncthreads();
+    }
+    R.conv = best < 9999.0; R.pm = best;
+    R.live_vn = 1 + T + sides_run; R.live_cn = blocks; R.live_e = winner; R.osd_rowadds = ties;
+}
+
 // bpgdg_decoder.decode / bpgd_decoder.decode / bp_history_decoder for one syndrome.  On return
 // s.hard[0..n) is the returned vector.
 // par != nullptr (parallel form): a tree with side branches is parked in a context and its side branches are queued;
@@ -1318,7 +1605,11 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const
     if constexpr (ENS) {
         for (int j = tid; j < SWD_GDG_MAXGUESS; j += NT) G.alt_depth[j] = -1;
         __syncthreads();
-        gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst, cmap);
+#ifdef SWD_ENS_FLAT_BUILD // development builds: round 3's form (the thread bodies one after the other) beside the prefix-tree walk, chosen by SWD_ENS_FLAT=1
+        if (P.ens_flat) gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst, cmap);
+        else
+#endif
+        gdg_ensemble_tree<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst, cmap);
         for (int v = tid; v < n; v += NT) s.hard[v] = 0;
         __syncthreads();
         for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];

@@ -53,7 +53,7 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     // The tuned osd_window kernels (up to 256 threads, swd_osdw_kernel.h: SWD_P16 / DIET) keep a smaller state: 32 + 16 bits of
     // live mask per check (row weight <= 48), one parity byte per check, no copy of the original check degrees, one
     // "decided" bit per variable node.  Every other kernel: the classic arrays.
-    const bool diet = kind == 0 && nt <= 256;
+    const bool diet = kind == 0 && nt <= SWD_TUNED_NT;
     L.off_livemask = o; o += (diet && g.K <= 48) ? align_up(m * 6, 4) : m * 8;
     L.off_par = o; o += diet ? align_up(m + 1, 4) : (m + 1) * 4; // parities; index m: sink for the dead positions' flips
     L.off_lv = o; o = align_up(o + new_n * 2, 4);
@@ -168,7 +168,7 @@ const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int
     for (const Variant &v : kVariants) {
         if (!(kind == 0 ? v.launch != nullptr : v.launch_gdg != nullptr)) continue;
         if (!(v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm)) continue;
-        if (kind == 0 && v.nt <= 256) { // these kernels keep LDS byte offsets in 16 bits (swd_osdw_kernel.h, P16)
+        if (kind == 0 && v.nt <= SWD_TUNED_NT) { // these kernels keep LDS byte offsets in 16 bits (swd_osdw_kernel.h, P16)
             bool fits = true;
             for (auto &w : wins) {
                 SwdLdsLayout L{};
@@ -265,6 +265,7 @@ static void fill_params(const Plan *d, SwdDecodeParams &P, bool hist_is_state, b
         P.max_tree_depth = d->gp.max_tree_depth; P.max_side_depth = d->gp.max_side_depth;
         P.max_side_branch_step = d->gp.max_side_branch_step; P.low_error_mode = d->gp.low_error_mode;
         P.max_guess = d->max_guess; P.gdg_factor = d->gp.gdg_factor; P.max_tree_branch_step = d->gp.max_tree_branch_step;
+        P.ens_flat = getenv("SWD_ENS_FLAT") ? 1 : 0;
         P.zero_hist = (!hist_is_state && (hist_is_output || d->gp.max_iter < 4)) ? 1 : 0;
     }
 }
@@ -675,14 +676,17 @@ static int stream_pop(HostStream *hs, uint8_t *total, int32_t *stats, double *mi
     return (int)B;
 }
 
-// One host-buffer call on the plan's own stream object.  A large batch is cut in two halves on the two lanes: the copy-out and
-// the unpacking of the first half overlap the second half's launch, whose grid also fills the first one's tail.
+// One host-buffer call on the plan's own stream object.  A large batch is cut into parts that go through the two lanes one after
+// the other, two in flight: the copy-out and the unpacking of part k overlap the launch of part k + 1 (whose grid also fills the
+// tail of part k), so only the last part's unpacking is left after the device has finished.
 static int pipeline_decode_host(Plan *d, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats, double *min_pm,
                                 int32_t *shot_result, int packed) {
     std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
-    static const int split_min = getenv("SWD_HOST_SPLIT_MIN") ? atoi(getenv("SWD_HOST_SPLIT_MIN")) : 2048; // shots from which a call is cut in two
-    const int parts = (B >= split_min && B >= 2) ? 2 : 1;
+    static const int split_min = getenv("SWD_HOST_SPLIT_MIN") ? atoi(getenv("SWD_HOST_SPLIT_MIN")) : 2048; // shots from which a call is cut
+    static const int want_parts = getenv("SWD_HOST_PARTS") ? std::max(1, atoi(getenv("SWD_HOST_PARTS"))) : 4;
+    int parts = (B >= split_min) ? want_parts : 1;
+    while (parts > 1 && B / parts < 512) --parts; // (a part keeps the device busy)
     const int per = (B + parts - 1) / parts;
     if (!d->hstream || d->hstream->max_shots < per) {
         d->hstream.reset(stream_new(d, std::max(per, 256), 0));
@@ -692,18 +696,18 @@ static int pipeline_decode_host(Plan *d, int32_t B, const uint8_t *det, uint8_t 
     HostStream *hs = d->hstream.get();
     while (hs->npop < hs->npush) (void)stream_pop(hs, nullptr, nullptr, nullptr, nullptr, 0); // (a failed earlier call left batches behind)
     const size_t W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
-    for (int k = 0; k < parts; ++k) {
-        const int lo = k * per, n = std::min(per, B - lo);
-        if (n > 0 && stream_push(hs, n, det + (size_t)lo * d->num_det)) return -1;
-    }
-    int rc = 0;
-    for (int k = 0; k < parts; ++k) {
+    auto push = [&](int k) { const int lo = k * per, n = std::min(per, B - lo); return n > 0 ? stream_push(hs, n, det + (size_t)lo * d->num_det) : 0; };
+    auto pop = [&](int k) {
         const size_t lo = (size_t)k * per;
-        const int n = std::min(per, B - (int)lo);
-        if (n <= 0) continue;
-        if (stream_pop(hs, total + lo * (packed ? row_bytes : (size_t)d->num_col), stats ? stats + lo * W * SWD_STAT_WORDS : nullptr,
-                       min_pm ? min_pm + lo * W : nullptr, shot_result ? shot_result + lo * 2 : nullptr, packed) < 0)
-            rc = -1;
+        if ((int)lo >= B) return 0;
+        return stream_pop(hs, total + lo * (packed ? row_bytes : (size_t)d->num_col), stats ? stats + lo * W * SWD_STAT_WORDS : nullptr,
+                          min_pm ? min_pm + lo * W : nullptr, shot_result ? shot_result + lo * 2 : nullptr, packed) < 0 ? -1 : 0;
+    };
+    int rc = 0;
+    for (int k = 0; k < parts && k < 2; ++k) if (push(k)) return -1;
+    for (int k = 0; k < parts; ++k) {
+        if (pop(k)) rc = -1;
+        if (k + 2 < parts && push(k + 2)) return -1;
     }
     return rc;
 }

@@ -25,7 +25,10 @@
 #ifndef SWD_OSDW_TUNED
 #define SWD_OSDW_TUNED 0
 #endif
-#define SWD_P16(NT) (SWD_OSDW_TUNED && (NT) <= 256)
+#ifndef SWD_TUNED_NT // largest workgroup of the tuned osd_window kernels (16-bit LDS offsets, LDS diet); the host uses the same bound
+#define SWD_TUNED_NT 256
+#endif
+#define SWD_P16(NT) (SWD_OSDW_TUNED && (NT) <= SWD_TUNED_NT)
 // experiment builds only (scripts/devbuild.sh -DSWD_POST_RENUM=1 + SWD_POST_RENUM=1 in the environment): the shortened graph's message
 // cells renumbered one column per live variable node in the tuned kernels too (the large-graph kernels always do it)
 #ifndef SWD_POST_RENUM
@@ -77,7 +80,7 @@ struct SwdDecodeParams {
     int32_t max_guess;
     double gdg_factor;
     int32_t max_tree_branch_step; // threaded ensemble (kernel kind 7): steps of a tree thread after its last split
-    int32_t pad_;
+    int32_t ens_flat;             // diagnostics (SWD_ENS_FLAT=1): the ensemble's thread bodies one after the other instead of the prefix-tree walk
 };
 
 // one window of the sliding-window plan: its graph + where it sits in the global DEM
@@ -1921,7 +1924,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 
     // kernels of up to 256 threads: the cache's loads are in flight during the reset loops (headline 9.95 -> 9.84 ms per launch at
     // order 0; the 1024-thread kernels lose by it -- [[288]] 63.2 -> 64.0 ms -- and load where they always did)
-    constexpr bool kSplitLoad = NT <= 256;
+    constexpr bool kSplitLoad = NT <= SWD_TUNED_NT;
     [[maybe_unused]] VnRaw<NT, kSplitLoad ? VF : 1, DM> vraw;
     if constexpr (kSplitLoad) vn_cache_issue<NT, VF, DM>(g, s, vraw);
     // reset (osd_window.pyx:288-303)
@@ -2399,7 +2402,7 @@ __global__ void __launch_bounds__(NT) shot_order_kernel(const uint32_t *wt, int 
 }
 
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false, int VFP = VF>
-__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2))) pipeline_kernel(const SwdPipeArgs a) {
+__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 512 && SWD_TUNED_NT >= 512 && (KIND == 0 || KIND == 3)) ? 6 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2)))) pipeline_kernel(const SwdPipeArgs a) {
     static_assert(!BIG || KIND == 0 || KIND == 3, "the HBM-resident scratch region exists for the osd_window kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;

@@ -181,6 +181,7 @@ struct Plan {
                 snap_stride = std::max(snap_stride, rec * (gdg_parallel ? SWD_GDG_SLOTS : std::max(std::max(max_guess, 1), ens_slots)));
                 new_n_max = std::max(new_n_max, w.new_n);
             }
+            snap_stride = (snap_stride + 15) & ~(int64_t)15;
         }
         nmax = 0;
         int lmax = 0, mmax = 0;
@@ -216,7 +217,7 @@ struct Plan {
             if (mmax > num_det) { set_error("window rows exceed the global check matrix (%d > %d)", mmax, num_det); return -1; }
             off_det = align_up(lmax, 16) + 16; // 16 bytes below the syndrome bytes: per-shot accumulators
             int dmax = num_det; // tuned osd_window kernels (up to 256 threads): LDS keeps the residual syndrome of one window's rows (whole words), swd_osdw_kernel.h
-            if (kind == 0 && nt <= 256) {
+            if (kind == 0 && nt <= SWD_TUNED_NT) {
                 dmax = 0;
                 for (auto &w : wins) dmax = std::max(dmax, std::min((w.row0 + w.g->m + 3) & ~3, (num_det + 3) & ~3) - (w.row0 & ~3));
             }
@@ -231,6 +232,20 @@ struct Plan {
         if (!variant) return -1;
         post_depth2 = kind != 0 && !getenv("SWD_GDG_NO_DEPTH2");
         for (auto &w : wins) post_depth2 = post_depth2 && w.new_n <= 2 * nt;
+        if (kind == 1 && gp.multi_thread == 1) {
+            // prefix-tree walk of the ensemble (swd_gdg_kernel.h, gdg_ensemble_tree): behind the 2 + (S - D) mask records come D fork
+            // records (masks + message cells: every cell of the window, or -- static tree-walk cache -- VF x DM cells per thread),
+            // the stash vector and the main thread's exit vector
+            const int ens_slots = 2 + std::max(gp.max_side_depth - gp.max_tree_depth, 0);
+            const int vfp = (post_depth2 && vf > 2) ? 2 : vf;
+            for (auto &w : wins) {
+                const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
+                const int64_t cells = std::max<int64_t>(w.g->E + 1 + 2 * (nt / 64), (int64_t)vfp * variant->dm * nt);
+                const int64_t forkb = ((rec + 15) & ~(int64_t)15) + ((cells * 8 + 15) & ~(int64_t)15);
+                snap_stride = std::max(snap_stride, ((rec * ens_slots + 15) & ~(int64_t)15) + gp.max_tree_depth * forkb + 2 * (((int64_t)w.new_n + 15) & ~(int64_t)15) + 16);
+            }
+            snap_stride = (snap_stride + 15) & ~(int64_t)15;
+        }
         if (status.reserve(64)) return -1; // word 0: fault flags; words 1..15: counters of diagnostic builds
         SWD_HIP(hipMemset(status.p, 0, 64));
         std::vector<SwdWindowDev> hw(wins.size());

@@ -5,7 +5,9 @@
 // A plan uses the first variant with NT >= m, NT * VF >= n, DM >= D, 4 * KG >= K over all its windows.
 // X(nt, vf, dm, kg, sf, has_k1, has_k2, has_k3)
 #pragma once
-#ifdef SWD_HEADLINE_ONLY // development builds: only the [[144,12,12]] kernels
+#if defined(SWD_HEADLINE_ONLY) && defined(SWD_EXP512) // experiment: the [[144,12,12]] windows on 512 threads, heavy checks shared by two lanes in both phases
+#define SWD_VARIANTS(X) X(512, 4, 6, 6, 1, 0, 0, 1) X(256, 7, 6, 9, 0, 1, 1, 1)
+#elif defined(SWD_HEADLINE_ONLY) // development builds: only the [[144,12,12]] kernels
 #define SWD_VARIANTS(X) X(256, 7, 6, 9, 0, 1, 1, 1)
 #elif defined(SWD_V7816_ONLY) // development builds: the <256, 7, 8, 16> kernels
 #define SWD_VARIANTS(X) X(256, 7, 8, 16, 0, 1, 1, 0)

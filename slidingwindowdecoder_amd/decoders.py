@@ -245,7 +245,11 @@ class bp_history_decoder:
     deterministic single-thread ``gdg()`` bit for bit; ``multi_thread=True`` runs the reference's threaded ensemble
     (bpgd.cpp:419-688: main thread, 2^D - 1 tree threads, S - D side threads) with the thread bodies in a fixed order, equal to
     the reference on every syndrome whose winning path metric is unique (``last_stats[:, 7]`` counts the tied, different
-    vectors); ``hypotheses=64`` is this package's own ensemble over every leaf of gdg()'s tree (no reference counterpart)."""
+    vectors) -- the hypotheses are the leaves of a prefix tree whose shared BP blocks and scans run once (gdg_ensemble_tree).
+    Every decode of the ensemble has the state of a NEWLY BUILT reference object: when ``BPGD::reset`` fails the zero vector is
+    returned (a re-used reference object returns its previous decode's ``min_pm_error``, bpgd.cpp:583, 619-625), and each thread's
+    posterior history starts from zeros (a re-used reference thread keeps its own stale slots when ``max_iter_per_step < 4``);
+    ``hypotheses=64`` is this package's own ensemble over every leaf of gdg()'s tree (no reference counterpart)."""
     _mode = 2
 
     def __init__(self, parity_check_matrix, **kwargs):
@@ -564,6 +568,11 @@ class SlidingWindowDecoder:
         try:
             for d in it:
                 d = self._check_det(d)
+                if st is not None and d.shape[0] > st.max_shots:  # a larger batch than the lanes were sized for: drain, then re-create
+                    while st.pending:
+                        yield st.pop()
+                    st.close()
+                    st = None
                 if st is None:
                     st = self.stream(d.shape[0], packed=packed, want_stats=want_stats)
                 if st.pending == 2:

@@ -101,7 +101,8 @@ def test_other_workloads_share_the_launcher():
     """`--workload gdg|bb288|bp4` run configs[2] / configs[3] / the quaternary decoder under the same launcher, sharding and gather (stub: CPU)."""
     sys.path.insert(0, ROOT)
     import bench
-    assert set(bench.WORKLOADS) == {"headline", "gdg", "bb288", "bp4", "global144"}
+    assert set(bench.WORKLOADS) == {"headline", "gdg", "gdg64", "bb288", "bp4", "global144"}
+    assert bench.parse_args(["--workload", "bp4"]).shots == 65536 and bench.parse_args([]).shots == 4096
     assert bench.parse_args(["--workload", "bb288"]).workload == "bb288" and bench.parse_args([]).workload == "headline"
     assert bench.parse_args([]).osd_order == 10  # the notebooks' default is the headline
     r, lines = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--shots", "37", "--workload", "gdg")

@@ -158,3 +158,25 @@ def test_reference_column_order_reproduces_the_z_basis_known_answers_too():
         key = lambda m: sorted(tuple(m.indices[m.indptr[j]:m.indptr[j + 1]]) for j in range(m.shape[1]))
         assert key(sp.csc_matrix(d.chk)) == key(sp.csc_matrix(c.chk))  # the same mechanisms, another order
         assert 0.0 <= np.sort(d.priors)[-1] - np.sort(c.priors)[-1] < 1e-4
+
+
+def test_z_basis_prior_merge_modes():
+    """The z-basis default ("circuit") XOR-merges a mechanism's probabilities over the whole circuit, the reference's
+    dem_to_check_matrices ADDS them across the units of the circuit ("stim" mode, build_circuit.py:262-270).  Mechanism by
+    mechanism (matched by symptom): the summed prior is never smaller, the gap is O(p^2) -- measured here so that the deviation of
+    the default's priors from the reference's is a number, not a remark."""
+    code, A, B = bb_code(144)
+    p = 0.003
+    d, c = bb_dem(code, A, B, p, 12, column_order="stim"), bb_dem(code, A, B, p, 12)
+
+    def by_symptom(dem):
+        chk, obs = sp.csc_matrix(dem.chk), sp.csc_matrix(dem.obs)
+        return {(tuple(chk.indices[chk.indptr[j]:chk.indptr[j + 1]]), tuple(obs.indices[obs.indptr[j]:obs.indptr[j + 1]])): dem.priors[j]
+                for j in range(chk.shape[1])}
+    ps, pc = by_symptom(d), by_symptom(c)
+    assert ps.keys() == pc.keys() and len(ps) == 8784
+    gap = np.array([ps[k] - pc[k] for k in ps])
+    assert (gap >= -1e-18).all()
+    assert 0.0 < gap.max() < 4.2e-5, gap.max()          # 2 p q for the largest pair of unit probabilities
+    assert (gap > 1e-12).sum() < 0.45 * len(gap)        # mechanisms emitted by one unit only have identical priors
+    assert gap.max() / min(pc.values()) < 0.11          # ... and the relative deviation stays below 11 % of the smallest prior

@@ -252,6 +252,9 @@ def _ensemble_vs_oracle(mat, priors, kw, synd, min_post=20):
         ties += int(nt > 0)
         assert dev.last_min_pm[k] == ora.min_pm, f"shot {k}: min_pm {dev.last_min_pm[k]} vs {ora.min_pm}"
         assert dev.last_stats[k, 6] == winner and dev.last_stats[k, 7] == nt, f"shot {k}: winner / ties {dev.last_stats[k, 6:8]} vs {(winner, nt)}"
+        # BP blocks: the device walks the prefix tree (a shared block runs once) but counts a block once per thread that would
+        # have run it -- the number the oracle's thread-by-thread restatement counts
+        assert dev.last_stats[k, 5] == ora.ensemble_blocks()[0], f"shot {k}: BP blocks {dev.last_stats[k, 5]} vs {ora.ensemble_blocks()[0]}"
     assert post >= min_post, post
     return post, ties
 
@@ -300,6 +303,26 @@ def test_threaded_ensemble_bb144_64_hypotheses_vs_oracle():
         tr = fx.Trace(f, f"gdg_win{wi}_", *mat.shape)
         post, ties = _ensemble_vs_oracle(mat, priors, kw, tr.synd[:96], 15)
         print(f"bb144 window {wi}, D = 5 / S = 6: {post} ensembles, {ties} with a tied different vector")
+
+
+def test_ensemble_prefix_tree_shapes_vs_oracle():
+    """The device walks the ensemble's prefix tree (shared BP blocks and scans run once, gdg_ensemble_tree); the oracle runs the
+    thread bodies one after the other.  Shapes that stress the walk's bookkeeping: a tree deeper than max_step (the main thread's
+    loop ends inside the shared part), D = 0 (no tree threads), D = 1, fewer iterations per block than history slots, tree threads
+    without steps of their own (max_tree_branch_step = 0), low-error mode -- every record incl. the BP block count per shot."""
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    base = fx.params(f, "gdg_params")
+    base.pop("multi_thread")
+    mat, priors = fx.graph(f, "win5_")
+    tr = fx.Trace(f, "gdg_win5_", *mat.shape)
+    shapes = [dict(max_tree_depth=4, max_side_depth=4, max_step=3, max_tree_branch_step=2),
+              dict(max_tree_depth=0, max_side_depth=3),
+              dict(max_tree_depth=1, max_side_depth=1, max_tree_branch_step=0),
+              dict(max_tree_depth=2, max_side_depth=7, max_iter_per_step=3, low_error_mode=True),
+              dict(max_tree_depth=6, max_side_depth=8, max_tree_branch_step=1, max_side_branch_step=2, max_step=8)]
+    for sh in shapes:
+        post, ties = _ensemble_vs_oracle(mat, priors, dict(base, **sh), tr.synd[:64], 8)
+        print(f"{sh}: {post} ensembles, {ties} with a tied different vector")
 
 
 def test_threaded_ensemble_weight2_known_answer():

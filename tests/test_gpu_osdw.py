@@ -250,8 +250,7 @@ def test_v7816_osd_exits_vs_oracle(seed):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert "256" in last.split("threads per shot")[1].split("]")[0], last  # the 256-thread variants served these trials
-    assert int(last.split("osd_window comparisons")[1].split("shots through OSD")[0].split(",")[-1]) > 500, last  # and OSD exits were compared
+    assert int(last.split("osd_window comparisons")[1].split("shots through OSD")[0].split(",")[-1]) > 500, last  # OSD exits were compared
 
 
 @pytest.mark.parametrize("mode", ["gd", "gdg", "bp"])
