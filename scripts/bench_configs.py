@@ -21,7 +21,7 @@ which = sys.argv[1:] or ["3", "3small", "3ens", "3mt", "4", "5", "5w12", "bp4", 
 
 def run_pipeline(name, plan, shots, reps, **kw):
     dec = SlidingWindowDecoder(plan, **kw)
-    det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=7)
+    det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=int(os.environ.get("SWD_CFG_SEED", "7")))
     d = torch.from_numpy(np.ascontiguousarray(det)).cuda()
     stats = torch.empty((shots, dec.W, 8), dtype=torch.int32, device="cuda")
     dec.decode_device(d, stats=stats); torch.cuda.synchronize()

@@ -1025,127 +1025,7 @@ __device__ __forceinline__ bool gdg_finalize(const SwdGraphDev &g, const SwdDeco
 //   side   thresholds (0, -10): the handed-over masks, messages = priors, the unfavoured value, max_side_branch_step steps
 // Snapshot slots in snap_b: 0 = state after BPGD::reset, 1 = the tree thread's saved masks, 2 + j = side thread j's.
 // Entered with the state after reset (peeled, caches built, messages initialised).  Leaves the winner in G.best_err.
-template <int NT, int VF, int DM, int KG, class ST>
-__device__ __forceinline__ void gdg_ensemble_ref(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
-                                                 double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
-                                                 GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const ST &st, const GdgCnMap &cmap) { // (VF here = the caller's post-phase depth)
-    const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
-    const int Dp = P.max_tree_depth, S = P.max_side_depth;
-    const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
-    const int64_t rec = gdg_snap_bytes(m, new_n);
-    const int NONE = 0x7fffffff;
-    double best = 10000.0;
-    int winner = -1, ties = 0, blocks = 0, ran = 1, it = 0;
-    double h4[VF][4] = {}; // (static cache: the history of a block stays with the threads of the positions)
-    auto block = [&](bool first) { // one min_sum_log call (bpgd.cpp:97-197); first: the messages start from the priors
-        const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn, cmap);
-        if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
-        const int cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
-        ++blocks; R.post_it += it;
-        return cv;
-    };
-    auto set_value = [&](int pos, int val) { // vn_set_value + peel; true on failure
-        __syncthreads();
-        if (tid < 64) {
-            bool bad = (pos == NONE) ? true : gdg_set_value_wave(g, s, G.pos_lv[pos], val);
-            if (!bad) bad = peel_wave<false, NT>(g, s);
-            if (tid == 0) s.scal[1] = bad ? 1 : 0;
-        }
-        __syncthreads();
-        return s.scal[1] != 0;
-    };
-    auto offer = [&](int who) { // the strict-< update of the shared best under store_mtx
-        const double pm = gdg_get_pm<NT>(g, s, G);
-        if (pm < best) {
-            best = pm; winner = who; ties = 0;
-            for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
-            __syncthreads();
-        } else if (pm == best) { // same metric: a different vector makes the reference's answer timing dependent
-            bool diff = false;
-            for (int j = tid; j < new_n; j += NT) diff |= (G.best_err[j] != s.hard[G.pos_lv[j]]);
-            if (block_any<NT>(diff, s)) ++ties;
-        }
-        return pm;
-    };
-    gdg_snap_save<NT>(g, s, G, snap_b); // slot 0: what every thread's reset() arrives at
-    // ---- main thread
-    bool main_conv = false;
-    for (int depth = 0; depth < P.max_step; ++depth) {
-        const int cv = block(false);
-        int gpos = NONE, favor = 0;
-        const int rc = gdg_select_core<NT>(g, P, s, G, hist_b, -3.0, depth == 0 ? -16.0 : -12.0, depth, gpos, favor, st, h4);
-        if (cv || rc == -1 || gpos == NONE) {
-            if (cv) { main_conv = true; offer(0); }
-            break;
-        }
-        if (depth >= Dp && depth < S) {
-            const int j = depth - Dp;
-            gdg_snap_save<NT>(g, s, G, snap_b + (int64_t)(2 + j) * rec);
-            if (tid == 0) { G.dec_vn[j] = (int16_t)gpos; G.dec_val[j] = (int8_t)(1 - favor); G.alt_depth[j] = (int16_t)(depth + 1); }
-        }
-        if (set_value(gpos, favor)) break;
-    }
-    if (!main_conv) { // returned when no hypothesis converges (:677-682)
-        for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
-    }
-    __syncthreads();
-    // which side threads were handed a snapshot: depth d saved iff the main loop reached its save, i.e. alt_depth[j] == Dp + j + 1
-    // (the array is cleared by the caller)
-    // ---- tree threads
-    for (int id = 1; id <= T; ++id) {
-        ++ran;
-        gdg_snap_load<NT>(g, s, G, snap_b);
-        bool on_side = false, saved = false, done = false;
-        double A = -3.0, A_sum = -16.0, own_pm = 10000.0;
-        int bk_pos = NONE, bk_val = 0;
-        for (int depth = 0; depth < P.max_tree_branch_step + Dp + 1; ++depth) {
-            if (depth > 0 && !on_side) A_sum = -12.0;
-            if (block(depth == 0)) { own_pm = offer(id); done = true; break; }
-            int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st, h4) == -1 || gpos == NONE) break;
-            if (depth < Dp) {
-                if ((id >> (Dp - 1 - depth)) & 1) { on_side = true; A = 0.0; A_sum = -10.0; favor = 1 - favor; }
-            } else if (depth == Dp) {
-                gdg_snap_save<NT>(g, s, G, snap_b + rec);
-                bk_pos = gpos; bk_val = 1 - favor; saved = true;
-            }
-            if (set_value(gpos, favor)) break;
-        }
-        if (done || !saved) continue;
-        gdg_snap_load<NT>(g, s, G, snap_b + rec);
-        if (set_value(bk_pos, bk_val)) continue;
-        int depth = Dp + 1;
-        for (int i = 0; i < P.max_tree_branch_step; ++i) {
-            if (block(i == 0)) {
-                const double pm = gdg_get_pm<NT>(g, s, G);
-                if (!(pm > own_pm)) offer(id);
-                break;
-            }
-            int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, A, A_sum, depth, gpos, favor, st, h4) == -1 || gpos == NONE) break;
-            if (set_value(gpos, favor)) break;
-            ++depth;
-        }
-    }
-    // ---- side threads
-    for (int j = 0; j < NS; ++j) {
-        if (G.alt_depth[j] != Dp + j + 1) continue; // never handed a snapshot (status -1 / 0)
-        ++ran;
-        gdg_snap_load<NT>(g, s, G, snap_b + (int64_t)(2 + j) * rec);
-        if (set_value((int)G.dec_vn[j], (int)G.dec_val[j])) continue;
-        int depth = G.alt_depth[j];
-        for (int i = 0; i < P.max_side_branch_step; ++i) {
-            if (block(i == 0)) { offer(1 + T + j); break; }
-            int gpos = NONE, favor = 0;
-            if (gdg_select_core<NT>(g, P, s, G, hist_b, 0.0, -10.0, depth, gpos, favor, st, h4) == -1 || gpos == NONE) break;
-            if (set_value(gpos, favor)) break;
-            ++depth;
-        }
-    }
-    __syncthreads();
-    R.conv = best < 9999.0; R.pm = best;
-    R.live_vn = ran; R.live_cn = blocks; R.live_e = winner; R.osd_rowadds = ties;
-}
+// (Round 3 ran these bodies one after the other on the unit's workgroup -- gdg_ensemble_ref, removed; the oracle's gdg_multi_run is that form.)
 
 // The same ensemble with the work its threads share done once: the walk of the PREFIX TREE.
 // A tree thread's first D steps are fixed by the direction bits of its id, and two threads whose ids share the first d bits do
@@ -1182,7 +1062,7 @@ __device__ __forceinline__ void gdg_msg_save(const Lds &s, const ST &st, int nms
             st.get_ed(i, ad);
 #pragma unroll
             for (int k = 0; k < DM; ++k)
-                __hip_atomic_store(&d[(i * DM + k) * NT + (int)threadIdx.x], *(const unsigned long long *)((const char *)s.msg + ad[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&d[(i * DM + k) * NT + s.vtid], *(const unsigned long long *)((const char *)s.msg + ad[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (by position: another workgroup may deal its waves differently)
         }
     } else {
         const unsigned long long *src = (const unsigned long long *)s.msg;
@@ -1203,7 +1083,7 @@ __device__ __forceinline__ void gdg_msg_load(Lds &s, const ST &st, int nmsg, con
 #pragma unroll
         for (int i = 0; i < VF; ++i)
 #pragma unroll
-            for (int k = 0; k < DM; ++k) v[i][k] = __hip_atomic_load(&src[(i * DM + k) * NT + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < DM; ++k) v[i][k] = __hip_atomic_load(&src[(i * DM + k) * NT + s.vtid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int i = 0; i < VF; ++i) {
             uint32_t ad[DM];
@@ -1224,14 +1104,54 @@ __device__ __forceinline__ void gdg_msg_load(Lds &s, const ST &st, int nmsg, con
     __syncthreads();
 }
 
+// ---- the ensemble's leaves as work items (kernel kind 7 on the work-item ring) ------------------------------------------------
+// A hard window's ensemble takes up to 16 ms on one workgroup (64 hypotheses, most of them walking all their steps), a shot's windows
+// are sequential, and a launch ended with a 60 ms tail in which one to three workgroups walked the last monster shots.  The 2^D
+// leaves are independent once the shared prefix has been walked, so the OWNER of a unit (ROLE 1) walks the prefix tree, the main
+// thread's own steps and the side threads, and hands every tree thread to the queue: at a fork of depth D - 1 it stores the fork
+// record in the unit's CONTEXT (HBM: header, position list, fork table, offer table, one vector per hypothesis, 2^(D-1) fork
+// records) and queues one TASK per leaf below it (ROLE 2: restore, decide the leaf's value, walk the thread's own steps).  Nobody
+// applies an offer: every role writes (metric, vector) into the offer table at the hypothesis' id, and whoever takes the last
+// token of the context queues FINAL, whose handler replays the table in the oracle's order -- main, tree threads by id, side
+// threads -- with the strict "<" and the tie count.  ROLE 0 is the whole ensemble on one workgroup (no context free, W = 1 calls).
+struct EnsCtx {
+    uint32_t *hdr, *pos, *node, *etab; // header words: 0 tokens  4 window  5 shot  6 dead_unsat  8 BP blocks  9 iterations  10 side threads run
+    uint8_t *vec, *fork;               //               11 main's exit vector present  12 pre-processing iterations
+    int vecb, nh, id;
+};
+__device__ __forceinline__ EnsCtx gdg_ens_ctx(const SwdGdgPar &gp, int id) {
+    uint8_t *b = gp.ctx + (int64_t)id * gp.ctx_stride;
+    EnsCtx c;
+    c.hdr = (uint32_t *)b; c.pos = (uint32_t *)(b + gp.off_pos); c.node = (uint32_t *)(b + gp.off_node); c.etab = (uint32_t *)(b + gp.off_rec);
+    c.vec = b + gp.off_err; c.vecb = gp.err_stride; c.nh = gp.ens_hyps; c.id = id;
+    c.fork = gp.csnap + (int64_t)id * gp.csnap_stride;
+    return c;
+}
+
 // Written as ONE loop whose body runs a single step -- [restore a saved state] [decide a node + peel] BP block [scan] [offers, saves]
 // -- with the scalar bookkeeping around it deciding what the next step is: the BP block, the scan, the decimation and the
 // snapshot routines are each inlined exactly once (as straight-line copies of the thread bodies the kernel took 25 minutes to
 // compile and its code no longer fit the instruction cache).
-template <int NT, int VF, int DM, int KG, class ST>
-__device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const GdgLds &G,
-                                                  double *hist_b, uint8_t *snap_b, WinResult &R, bool dead_unsat,
-                                                  GdgVC<VF, DM> &vc, GdgCC<KG> &cn, const ST &st, const GdgCnMap &cmap) {
+// role 0: the whole ensemble here.  1: owner (tree threads become tasks).  2: task = tree thread `task_p` from its fork on.
+// The role is a run-time value and the kernel inlines this walk at ONE place (pipeline_kernel, where a unit that needs its ensemble
+// and a task of a parked ensemble meet).  Measured on the way: three inlined copies (one per role) or two -- every launch 1.3 to
+// 1.5 times slower, the copies evict each other from the instruction cache that the workgroups of a CU share; a real, non-inlined
+// function -- twice as slow, the BP caches and the walk's state live on the stack.  Everything a walk keeps in registers (static
+// cache, check map, BP caches) is built in here.
+template <int NT, int VF, int DM, int KG>
+__device__ __forceinline__ void gdg_ensemble_tree(int ROLE, const SwdGraphDev *gptr, const SwdDecodeParams *Pptr, Lds s, GdgLds G,
+                                                            double *hist_b, uint8_t *snap_b, WinResult *Rptr, int dead_unsat_i,
+                                                            const SwdGdgPar *gp, const EnsCtx *ec, int task_p) {
+    const SwdGraphDev &g = *gptr;
+    const SwdDecodeParams &P = *Pptr;
+    WinResult &R = *Rptr;
+    const bool dead_unsat = dead_unsat_i != 0;
+    using ST = GdgStatic<VF, DM>;
+    ST st;
+    gdg_static_init<NT, VF, DM>(g, s, G, st);
+    const GdgCnMap cmap = gdg_cn_map<NT, KG>(g, s, G); // (the degrees of the state this walk starts from bound every later state of it)
+    GdgVC<VF, DM> vc;
+    GdgCC<KG> cn;
     const int tid = threadIdx.x, m = g.m, new_n = g.new_n;
     const int Dp = P.max_tree_depth, S = P.max_side_depth;
     const int T = (1 << Dp) - 1, NS = max(S - Dp, 0);
@@ -1245,7 +1165,7 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
     enum { M_DESC, M_MAIN, M_TREE1, M_TREE2, M_SIDE };                                  // what the next step belongs to
     enum { C_NONE, C_LEAF, C_DESC, C_MAIN, C_TREE1, C_BK, C_TREE2, C_SIDE0, C_SIDE };   // whose decimation precedes it
     enum { ADV_NONE, ADV_LEAF, ADV_REPLAY, ADV_SIDE };                                  // where to go when a walk ends
-    enum { R_NONE, R_FORK, R_BK, R_SIDE };
+    enum { R_NONE, R_FORK, R_BK, R_SIDE, R_CTX };
     double best = 10000.0;
     int winner = -1, ties = 0, blocks = 0, sides_run = 0, it = 0;
     bool main_alive = true, main_conv = false, have_main_fb = false;
@@ -1261,14 +1181,46 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
     bool saved = false;                  // tree thread on its own: masks saved at depth D
     double own_pm = 10000.0;
     int bk_pos = NONE, bk_val = 0;
+#ifdef SWD_GDGPROF
+    long long gp_t_ = wall_clock64();
+#define EPT(k) do { const long long gp_n_ = wall_clock64(); R.gp[k] += gp_n_ - gp_t_; gp_t_ = gp_n_; } while (0)
+#else
+#define EPT(k) do { } while (0)
+#endif
+    R.post_it = (ROLE == 0) ? R.post_it : 0;
+    const int nforks = Dp >= 1 ? (1 << (Dp - 1)) : 0;
+    if (ROLE == 2 && task_p <= T) { // tree thread task_p: from the fork at depth D - 1 above it, through the child its last direction bit names
+        const int q = task_p >> 1, gp_ = (int)ag_ld(&ec->node[2 * q]), fv_ = (int)ag_ld(&ec->node[2 * q + 1]);
+        p = task_p; d = Dp; mode = M_TREE1; first = false; main_alive = false;
+        restore = R_CTX; rslot = q; set_ctx = C_LEAF; set_pos = gp_; set_val = (task_p & 1) ? 1 - fv_ : fv_;
+    } else if (ROLE == 2) { // side thread task_p - T - 1: the masks the main thread handed over, messages = priors, the unfavoured value
+        const uint32_t *sd = ec->node + 2 * nforks + 3 * (task_p - T - 1);
+        jside = task_p - T - 1; mode = M_SIDE; d = (int)ag_ld(&sd[2]); iter = 0; first = true; main_alive = false; sides_run = 1;
+        restore = R_CTX; rslot = -1 - jside; set_ctx = C_SIDE0; set_pos = (int)ag_ld(&sd[0]); set_val = (int)ag_ld(&sd[1]);
+    }
+    // an offer: applied at once when the whole ensemble runs here, else written into the context's table at the hypothesis' id
+    auto emit = [&](int who, int count, double pm) {
+        gdg_store_err<NT>(s, G, new_n, (uint32_t *)(ec->vec + (int64_t)who * ec->vecb));
+        if (tid == 0) {
+            uint32_t *e = ec->etab + 4 * who;
+            const unsigned long long pb = (unsigned long long)__double_as_longlong(pm);
+            ag_st(&e[2], (uint32_t)pb); ag_st(&e[3], (uint32_t)(pb >> 32)); ag_st(&e[0], 1u | ((uint32_t)count << 8));
+        }
+    };
     for (;;) {
+        EPT(4);
+        if (ROLE == 2 && (adv == ADV_LEAF || adv == ADV_SIDE)) break; // the thread's walk is over
         if (want_main_end) { // the vector returned if nothing converges (bpgd.cpp:677-682)
-            if (!main_conv) { gdg_store_err<NT>(s, G, new_n, main_fb); ag_publish_barrier(); have_main_fb = true; }
+            if (!main_conv) { gdg_store_err<NT>(s, G, new_n, ROLE == 1 ? (uint32_t *)(ec->vec + (int64_t)ec->nh * ec->vecb) : main_fb); ag_publish_barrier(); have_main_fb = true; }
             main_alive = false; want_main_end = false;
         }
         if (adv == ADV_LEAF) { // the next leaf whose fork is alive: its path leaves that fork through the unfavoured child
             int dstar = 0;
-            for (++p; p <= T; ++p) { dstar = Dp - __ffs(p); if (dead_depth > dstar) break; }
+            for (++p; p <= T; ++p) {
+                dstar = Dp - __ffs(p);
+                if (ROLE == 1 && dstar == Dp - 1) continue; // (owner: the leaves below a fork of depth D - 1 are tasks)
+                if (dead_depth > dstar) break;
+            }
             if (p > T) adv = ADV_SIDE;
             else {
                 dead_depth = NONE;
@@ -1285,6 +1237,7 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
             mode = M_TREE2; d = Dp + 1; iter = 0; first = true; adv = ADV_NONE;
         }
         if (adv == ADV_SIDE) { // the next side thread that was handed a snapshot (bpgd.cpp:527-570)
+            if (ROLE == 1) break; // (owner: the side threads are tasks, queued when the main thread handed them their snapshots)
             for (++jside; jside < NS; ++jside) if (G.alt_depth[jside] == Dp + jside + 1) break;
             if (jside >= NS) break;
             ++sides_run;
@@ -1293,8 +1246,9 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
         }
         if (restore != R_NONE) {
             const uint8_t *src = restore == R_FORK ? fork0 + (int64_t)rslot * forkb : (restore == R_BK ? snap_b + rec : snap_b + (int64_t)(2 + rslot) * rec);
+            if (ROLE == 2 && restore == R_CTX) src = rslot >= 0 ? ec->fork + (int64_t)rslot * forkb : ec->fork + (int64_t)nforks * forkb + (int64_t)(-1 - rslot) * rec16;
             gdg_snap_load<NT>(g, s, G, src);
-            if (restore == R_FORK) gdg_msg_load<NT, VF, DM>(s, st, nmsg, src + rec16); // (an unfavoured guess does not re-initialise the messages)
+            if (restore == R_FORK || (restore == R_CTX && rslot >= 0)) gdg_msg_load<NT, VF, DM>(s, st, nmsg, src + rec16); // (an unfavoured guess does not re-initialise the messages)
             restore = R_NONE;
         }
         if (set_ctx != C_NONE) { // vn_set_value + peel
@@ -1317,10 +1271,11 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
                 continue;
             }
         }
+        EPT(3);
         // loop bounds of the thread bodies
         if (mode == M_DESC) {
             if (p == 0 && main_alive && d >= P.max_step) { // (max_step <= D: the main thread's loop is over, the tree threads go on)
-                if (!main_conv) { gdg_store_err<NT>(s, G, new_n, main_fb); ag_publish_barrier(); have_main_fb = true; }
+                if (!main_conv) { gdg_store_err<NT>(s, G, new_n, ROLE == 1 ? (uint32_t *)(ec->vec + (int64_t)ec->nh * ec->vecb) : main_fb); ag_publish_barrier(); have_main_fb = true; }
                 main_alive = false;
             }
         } else if (mode == M_MAIN) {
@@ -1340,21 +1295,24 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
             const int nlive = gdg_caches<NT, VF, DM, KG>(g, s, G, st, vc, cn, cmap);
             if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
             first = false;
+            EPT(0);
             cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
             blocks += share; R.post_it += it * share; // counted once per thread of the ensemble that runs this block
+            EPT(1);
         }
         // ... the scan (the main thread scans BEFORE its convergence test, bpgd.cpp:630-633; the others only go on when the block failed)
         double pm_t = 0.0;
         if (cv && desc && with_main) { // the tree threads below this node offer the vector as it is now
             pm_t = gdg_get_pm<NT>(g, s, G);
-            gdg_store_err<NT>(s, G, new_n, stash);
-            ag_publish_barrier();
+            if (ROLE == 0) { gdg_store_err<NT>(s, G, new_n, stash); ag_publish_barrier(); }
+            else if (ntree > 0) emit(1, ntree, pm_t);
         }
         int gpos = NONE, favor = 0, rc = 0;
         if (!cv || with_main) {
             const bool sidethr = !(mode == M_MAIN || (desc && p == 0)); // thresholds (0, -10) once an unfavoured branch has been taken
             rc = gdg_select_core<NT>(g, P, s, G, hist_b, sidethr ? 0.0 : -3.0, sidethr ? -10.0 : (d == 0 ? -16.0 : -12.0), d, gpos, favor, st, h4);
         }
+        EPT(2);
         if (cv) { // ---- a converged block: the strict-< offers, in the order main, tree threads by id, side threads
             const double pm = gdg_get_pm<NT>(g, s, G);
             int who = 0, count = 1;
@@ -1364,7 +1322,8 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
             else if (mode == M_TREE2) { who = p; offer = !(pm > own_pm); }
             else if (mode == M_SIDE) who = 1 + T + jside;
             if (with_main) main_conv = true;
-            if (offer) {
+            if (ROLE != 0) { if (offer) emit(who, count, pm); }
+            else if (offer) {
                 if (pm < best) {
                     best = pm; winner = who; ties = 0;
                     for (int j = tid; j < new_n; j += NT) G.best_err[j] = s.hard[G.pos_lv[j]];
@@ -1375,7 +1334,7 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
                     if (block_any<NT>(diff, s)) ties += count;
                 }
             }
-            if (desc && with_main && ntree > 0) { // ... then the tree threads of the all-favoured path, with the stashed vector
+            if (ROLE == 0 && desc && with_main && ntree > 0) { // ... then the tree threads of the all-favoured path, with the stashed vector
                 if (pm_t < best) {
                     best = pm_t; winner = 1; ties = 0;
                     for (int j = tid; j < new_n; j += NT) G.best_err[j] = vec_byte(stash, j);
@@ -1400,18 +1359,34 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
         // ---- the guess: save what later walks start from, then decide the favoured value (at the top of the next turn)
         {
             uint8_t *dst = nullptr;
-            if (desc) dst = fork0 + (int64_t)d * forkb;                                        // fork: the unfavoured child starts here
-            else if (mode == M_MAIN && d >= Dp && d < S) dst = snap_b + (int64_t)(2 + d - Dp) * rec; // handed to side thread d - D
+            const bool to_ctx = ROLE == 1 && desc && d == Dp - 1;                               // (owner: the leaves below this fork are tasks)
+            if (to_ctx) dst = ec->fork + (int64_t)(p >> 1) * forkb;
+            else if (desc) dst = fork0 + (int64_t)d * forkb;                                   // fork: the unfavoured child starts here
+            else if (mode == M_MAIN && d >= Dp && d < S)                                        // handed to side thread d - D
+                dst = ROLE == 1 ? ec->fork + (int64_t)nforks * forkb + (int64_t)(d - Dp) * rec16 : snap_b + (int64_t)(2 + d - Dp) * rec;
             else if (mode == M_TREE1 && d == Dp) dst = snap_b + rec;                             // the tree thread's own way back
             if (dst) {
                 gdg_snap_save<NT>(g, s, G, dst);
                 if (desc) gdg_msg_save<NT, VF, DM>(s, st, nmsg, dst + rec16);
                 if (tid == 0) {
-                    if (desc) { nd_gpos[d] = gpos; nd_fav[d] = favor; }
+                    if (to_ctx) { ag_st(&ec->node[2 * (p >> 1)], (uint32_t)gpos); ag_st(&ec->node[2 * (p >> 1) + 1], (uint32_t)favor); }
+                    else if (desc) { nd_gpos[d] = gpos; nd_fav[d] = favor; }
+                    else if (mode == M_MAIN && ROLE == 1) { uint32_t *sd = ec->node + 2 * nforks + 3 * (d - Dp); ag_st(&sd[0], (uint32_t)gpos); ag_st(&sd[1], (uint32_t)(1 - favor)); ag_st(&sd[2], (uint32_t)(d + 1)); }
                     else if (mode == M_MAIN) { const int j = d - Dp; G.dec_vn[j] = (int16_t)gpos; G.dec_val[j] = (int8_t)(1 - favor); G.alt_depth[j] = (int16_t)(d + 1); }
                 }
                 if (mode == M_TREE1) { bk_pos = gpos; bk_val = 1 - favor; saved = true; }
                 ag_publish_barrier();
+                {
+                    if (ROLE == 1 && to_ctx && tid == 0) { // one token and one work item per tree thread below the fork (leaf 0 is the main thread: the owner goes on)
+                        const int lo = p == 0 ? 1 : p, cnt = p == 0 ? 1 : 2;
+                        __hip_atomic_fetch_add(&ec->hdr[0], (uint32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < cnt; ++k) ring_push(gp->q, gp->qmask, item_side(ec->id, lo + k));
+                    }
+                    if (ROLE == 1 && mode == M_MAIN && tid == 0) { // ... and one per side thread that is handed its snapshot
+                        __hip_atomic_fetch_add(&ec->hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ring_push(gp->q, gp->qmask, item_side(ec->id, 1 + T + d - Dp));
+                    }
+                }
             }
         }
         set_pos = gpos; set_val = favor; prev_with_main = with_main;
@@ -1422,16 +1397,67 @@ __device__ __forceinline__ void gdg_ensemble_tree(const SwdGraphDev &g, const Sw
             if (p == 0) {
                 if (main_alive) mode = M_MAIN;
                 else { set_ctx = C_NONE; adv = ADV_LEAF; } // (no tree thread 0: nobody walks the all-favoured leaf)
-            } else { mode = M_TREE1; saved = false; own_pm = 10000.0; }
+            } else if (ROLE == 1) { set_ctx = C_NONE; adv = ADV_LEAF; } // (owner: both leaves below this fork are tasks)
+            else { mode = M_TREE1; saved = false; own_pm = 10000.0; }
         }
     }
     __syncthreads();
+    if (ROLE != 0) { // hand in: statistics, then this role's token; the last token queues FINAL
+        ag_publish_barrier();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&ec->hdr[8], (uint32_t)blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&ec->hdr[9], (uint32_t)R.post_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sides_run) __hip_atomic_fetch_add(&ec->hdr[10], (uint32_t)sides_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ROLE == 1) ag_st(&ec->hdr[11], have_main_fb ? 1u : 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t before = __hip_atomic_fetch_sub(&ec->hdr[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == 1u) ring_push(gp->q, gp->qmask, item_final(ec->id));
+        }
+        __syncthreads();
+        return;
+    }
     if (!(best < 9999.0) && have_main_fb) { // nothing converged: the main thread's vector as it left its loop (:677-682)
         for (int j = tid; j < new_n; j += NT) G.best_err[j] = vec_byte(main_fb, j);
         __syncthreads();
     }
     R.conv = best < 9999.0; R.pm = best;
     R.live_vn = 1 + T + sides_run; R.live_cn = blocks; R.live_e = winner; R.osd_rowadds = ties;
+}
+
+// FINAL item of a parked ensemble: the offers of every hypothesis in the oracle's order (main, tree threads by id, side threads),
+// strict "<", ties of the winning metric with a different vector counted; fills R and s.hard like the ensemble on one workgroup.
+template <int NT>
+__device__ __forceinline__ void gdg_ens_finalize(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, const EnsCtx &c, WinResult &R) {
+    const int tid = threadIdx.x, n = g.n, new_n = g.new_n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    R = WinResult{};
+    R.exit_class = SWD_EXIT_POST;
+    double best = 10000.0;
+    int winner = -1, ties = 0;
+    auto byte_of = [&](int who, int j) { const uint32_t *v = (const uint32_t *)(c.vec + (int64_t)who * c.vecb); return (uint8_t)((ag_ld(&v[j >> 2]) >> (8 * (j & 3))) & 0xFFu); };
+    for (int who = 0; who < c.nh; ++who) {
+        const uint32_t w0 = ag_ld(&c.etab[4 * who]);
+        if (!(w0 & 1u)) continue;
+        const int count = (int)(w0 >> 8);
+        const double pm = __longlong_as_double((long long)((unsigned long long)ag_ld(&c.etab[4 * who + 2]) | ((unsigned long long)ag_ld(&c.etab[4 * who + 3]) << 32)));
+        if (pm < best) { best = pm; winner = who; ties = 0; }
+        else if (pm == best) {
+            bool diff = false;
+            for (int j = tid; j < new_n; j += NT) diff |= (byte_of(who, j) != byte_of(winner, j));
+            if (block_any<NT>(diff, s)) ties += count;
+        }
+    }
+    const int src = winner >= 0 ? winner : (ag_ld(&c.hdr[11]) ? c.nh : -1); // nothing converged: the main thread's vector as it left its loop
+    for (int v = tid; v < n; v += NT) s.hard[v] = 0;
+    __syncthreads();
+    if (src >= 0)
+        for (int j = tid; j < new_n; j += NT)
+            if (byte_of(src, j)) { const uint32_t pw = ag_ld(&c.pos[j >> 1]); s.hard[(j & 1) ? (pw >> 16) : (pw & 0xFFFFu)] = 1; }
+    __syncthreads();
+    const int T = (1 << P.max_tree_depth) - 1;
+    R.conv = best < 9999.0; R.pm = best;
+    R.pre_it = (int)ag_ld(&c.hdr[12]); R.post_it = (int)ag_ld(&c.hdr[9]); R.total_it = R.pre_it + R.post_it;
+    R.live_vn = 1 + T + (int)ag_ld(&c.hdr[10]); R.live_cn = (int)ag_ld(&c.hdr[8]); R.live_e = winner; R.osd_rowadds = ties;
 }
 
 // bpgdg_decoder.decode / bpgd_decoder.decode / bp_history_decoder for one syndrome.  On return
@@ -1460,8 +1486,14 @@ __device__ __forceinline__ void gdg_stage_graph(SwdGraphDev &gl, const SwdGraphD
     }
 }
 
+// the descriptor gdg_stage_graph set up, again (the copies are in LDS already)
+__device__ __forceinline__ void gdg_staged_graph(SwdGraphDev &gl, const SwdGraphDev &g, const Lds &s) {
+    const int Ee = (g.E + 1) & ~1;
+    if ((Ee + g.m) * 2 <= g.K * g.m * 2) { gl.row_col = s.lslot; gl.perm = s.lslot + Ee; }
+}
+
 // ENS (kernel kind 7): bpgdg_decoder(multi_thread=True) -- the post-processing is the reference's threaded ensemble
-// (gdg_ensemble_ref) instead of gdg()'s tree walk.
+// (gdg_ensemble_tree, run by the caller) instead of gdg()'s tree walk.
 template <int NT, int VF, int DM, int KG, bool ENS = false, int VFP = VF>
 __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                                   const uint8_t *synd, double *hist_b, uint8_t *snap_b, WinResult &R,
@@ -1512,7 +1544,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const
     __syncthreads();
     // (serial form only: 16384 shots 1.70 -> 1.76 M windows/s; in the parallel form the owner runs the main branch alone and parks
     // the tree -- staging 13 KB for that costs more than it saves, 1.21 -> 1.20 M at 4096 shots -- and neither do the tasks repay it)
-    if (!par) gdg_stage_graph<NT>(g_loc, g_in, s);
+    if (!par || ENS) gdg_stage_graph<NT>(g_loc, g_in, s); // (the ensemble's owner walks the shared steps, the main thread and the side threads: it repays the staging; gdg_staged_graph)
     for (int v = tid; v < L.npad; v += NT) {
         if (v < n) {
             const double sum = ((hist_b[v] + hist_b[n + v]) + hist_b[2 * n + v]) + hist_b[3 * n + v];
@@ -1592,6 +1624,13 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const
         R.exit_class = SWD_EXIT_FAIL_PEEL;
         return;
     }
+    if constexpr (ENS) { // bpgdg_decoder(multi_thread=True): the caller (pipeline_kernel) runs the threaded ensemble from here -- the walk
+        // (gdg_ensemble_tree) is inlined at ONE place of the kernel, where units and the tasks of parked ensembles meet
+        for (int j = tid; j < SWD_GDG_MAXGUESS; j += NT) G.alt_depth[j] = -1;
+        __syncthreads();
+        R.exit_class = -3; R.live_vn = dead_unsat ? 1 : 0;
+        return;
+    }
     GdgVC<VFP, DM> vcp; // the shortened graph's cache (the full graph's is dead from here on)
     using ST = GdgStatic<VFP, DM>;
     constexpr bool SPARSE = !std::is_same_v<ST, GdgNoStatic>;
@@ -1602,23 +1641,6 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const
     int nlive = gdg_caches<NT, VFP, DM, KG>(g, s, G, vst, vcp, cn, cmap);
     bp_init<VFP, DM>(s, vcp);
     __syncthreads();
-    if constexpr (ENS) {
-        for (int j = tid; j < SWD_GDG_MAXGUESS; j += NT) G.alt_depth[j] = -1;
-        __syncthreads();
-#ifdef SWD_ENS_FLAT_BUILD // development builds: round 3's form (the thread bodies one after the other) beside the prefix-tree walk, chosen by SWD_ENS_FLAT=1
-        if (P.ens_flat) gdg_ensemble_ref<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst, cmap);
-        else
-#endif
-        gdg_ensemble_tree<NT, VFP, DM, KG>(g, P, s, G, hist_b, snap_b, R, dead_unsat, vcp, cn, vst, cmap);
-        for (int v = tid; v < n; v += NT) s.hard[v] = 0;
-        __syncthreads();
-        for (int j = tid; j < new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
-        __syncthreads();
-        R.total_it = R.pre_it + R.post_it;
-        R.exit_class = SWD_EXIT_POST;
-        R.t[5] = wall_clock64();
-        return;
-    }
 
     double min_pm = 10000.0;
     int used_guess = 0, min_converge_depth = P.max_step, converge = 0, blocks = 0;
@@ -1626,7 +1648,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const
     // parallel form: the tree gets a context (snapshots, records) if one is free; without one it is walked serially
     int ctxid = -1;
     GdgCtx ctx{};
-    if (gdg && par) {
+    if (gdg && par && !ENS) {
         __syncthreads();
         if (tid == 0) { uint32_t id = 0; acc[1] = ring_pop(par->gdgp.fq, par->gdgp.fmask, &id) ? id : 0xFFFFFFFFu; }
         __syncthreads();

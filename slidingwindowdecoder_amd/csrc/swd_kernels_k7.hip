@@ -1,5 +1,5 @@
 // Instantiations of swd::pipeline_kernel for kind 7 (bpgdg_decoder(multi_thread=True): the reference's threaded ensemble,
-// swd_gdg_kernel.h: gdg_ensemble_ref) and their launchers; its own translation unit so that the serial and the parallel
+// swd_gdg_kernel.h: gdg_ensemble_tree) and their launchers; its own translation unit so that the serial and the parallel
 // tree-walk kernels (kinds 1, 2) keep their register allocation.
 #include "swd_plan.h"
 #include "swd_variants.h"

@@ -265,7 +265,6 @@ static void fill_params(const Plan *d, SwdDecodeParams &P, bool hist_is_state, b
         P.max_tree_depth = d->gp.max_tree_depth; P.max_side_depth = d->gp.max_side_depth;
         P.max_side_branch_step = d->gp.max_side_branch_step; P.low_error_mode = d->gp.low_error_mode;
         P.max_guess = d->max_guess; P.gdg_factor = d->gp.gdg_factor; P.max_tree_branch_step = d->gp.max_tree_branch_step;
-        P.ens_flat = getenv("SWD_ENS_FLAT") ? 1 : 0;
         P.zero_hist = (!hist_is_state && (hist_is_output || d->gp.max_iter < 4)) ? 1 : 0;
     }
 }
@@ -562,7 +561,7 @@ static void unpack_rows(const uint8_t *bits, size_t row_bytes, int num_col, uint
 static void unpack_bits_host(const uint8_t *bits, size_t B, int num_col, uint8_t *out) {
     const size_t row_bytes = ((size_t)num_col + 7) / 8;
     unsigned nthr = 1;
-    if (B * (size_t)num_col >= (8u << 20)) nthr = std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+    if (B * (size_t)num_col >= (8u << 20)) nthr = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     if (nthr <= 1) { unpack_rows(bits, row_bytes, num_col, out, 0, B); return; }
     std::vector<std::thread> th;
     for (unsigned i = 1; i < nthr; ++i) th.emplace_back(unpack_rows, bits, row_bytes, num_col, out, B * i / nthr, B * (i + 1) / nthr);
@@ -676,16 +675,18 @@ static int stream_pop(HostStream *hs, uint8_t *total, int32_t *stats, double *mi
     return (int)B;
 }
 
-// One host-buffer call on the plan's own stream object.  A large batch is cut into parts that go through the two lanes one after
-// the other, two in flight: the copy-out and the unpacking of part k overlap the launch of part k + 1 (whose grid also fills the
+// One host-buffer call on the plan's own stream object.  A very large batch is cut into parts that go through the two lanes one
+// after the other, two in flight: the copy-out and the unpacking of part k overlap the launch of part k + 1 (whose grid also fills the
 // tail of part k), so only the last part's unpacking is left after the device has finished.
 static int pipeline_decode_host(Plan *d, int32_t B, const uint8_t *det, uint8_t *total, int32_t *stats, double *min_pm,
                                 int32_t *shot_result, int packed) {
     std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
     static const int split_min = getenv("SWD_HOST_SPLIT_MIN") ? atoi(getenv("SWD_HOST_SPLIT_MIN")) : 2048; // shots from which a call is cut
-    static const int want_parts = getenv("SWD_HOST_PARTS") ? std::max(1, atoi(getenv("SWD_HOST_PARTS"))) : 4;
-    int parts = (B >= split_min) ? want_parts : 1;
+    // (measured, 4096 shots of the headline workload, OSD-CS 10: one part 13.8 ms per call, two 17.5, four 22.1, eight 27.1 -- a launch of
+    // 1024 shots is bound by its longest shot's chain of eleven windows, not by the device; only calls of 16384 shots and more are cut)
+    static const int want_parts = getenv("SWD_HOST_PARTS") ? std::max(1, atoi(getenv("SWD_HOST_PARTS"))) : 0;
+    int parts = want_parts ? ((B >= split_min) ? want_parts : 1) : std::max(1, B / 8192);
     while (parts > 1 && B / parts < 512) --parts; // (a part keeps the device busy)
     const int per = (B + parts - 1) / parts;
     if (!d->hstream || d->hstream->max_shots < per) {

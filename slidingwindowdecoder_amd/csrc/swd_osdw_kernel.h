@@ -80,7 +80,7 @@ struct SwdDecodeParams {
     int32_t max_guess;
     double gdg_factor;
     int32_t max_tree_branch_step; // threaded ensemble (kernel kind 7): steps of a tree thread after its last split
-    int32_t ens_flat;             // diagnostics (SWD_ENS_FLAT=1): the ensemble's thread bodies one after the other instead of the prefix-tree walk
+    int32_t pad_;
 };
 
 // one window of the sliding-window plan: its graph + where it sits in the global DEM
@@ -107,6 +107,8 @@ struct SwdGdgPar {
     uint8_t *ctx;         // [nctx][ctx_stride] contexts of parked trees
     int64_t ctx_stride;
     int32_t off_pos, off_rec, off_err, err_stride;
+    int32_t off_node;     // threaded ensemble (kind 7): table of the forks at depth D - 1 (guess, favoured value)
+    int32_t ens_hyps;     // ... and the number of hypotheses 1 + (2^D - 1) + (S - D) its offer table holds
     uint8_t *csnap;       // [nctx][csnap_stride] their snapshot areas
     int64_t csnap_stride;
     int32_t nctx;
@@ -2424,13 +2426,17 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
     uint32_t res_units = 0;
 #endif
     bool queued = false; // parallel form of the guessing decoders: work items instead of window-major tickets
-    if constexpr (KIND == 2) queued = a.gdgp.q != nullptr;
+    constexpr bool kQueue = KIND == 2 || KIND == 7; // (kind 7, the threaded ensemble: UNIT items only -- its units run from 50 us to several ms, and a
+                                                    //  workgroup that draws a ticket whose predecessor is such a unit would idle for that long)
+    if constexpr (kQueue) queued = a.gdgp.q != nullptr;
     // parallel form: every shot is admitted through the counter a.sched[0] -- by a workgroup that finds nothing unclaimed in the
     // ring, or by the one that finishes a shot -- so progress never depends on a workgroup that is not resident yet
     constexpr uint32_t shots0 = 0;
     for (;;) {
     const long long t_unit0 = wall_clock64();
     int wi, b, final_ctx = -1;
+    [[maybe_unused]] bool ens_task = false;      // kind 7: this turn runs a tree thread of a parked ensemble, not a unit
+    [[maybe_unused]] uint32_t ens_item = 0;
 #ifdef SWD_GDG_DEBUG
     long long dbg_ta = 0, dbg_tb = 0, dbg_tc = 0;
 #endif
@@ -2440,7 +2446,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         // another one, so a hard tree never blocks a workgroup that could do other work; the number of shots in
         // flight is bounded so that a continuation never queues behind the whole batch.
         uint32_t item = 0;
-        if constexpr (KIND == 2) {
+        if constexpr (kQueue) {
             __syncthreads();
             if (tid == 0) {
                 // nothing unclaimed in the ring: admit one more shot instead of waiting (the number of shots under way grows
@@ -2462,9 +2468,12 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         const uint32_t type = item >> 30;
         if (type == SWD_ITEM_SIDE) {
             if constexpr (KIND == 2) gdg_run_task<NT, VF, DM, KG, VFP>(a, smem, item, s.ctid, s.vtid);
-            continue;
+            if constexpr (KIND != 7) continue;
+            // (kind 7: a tree thread of a parked ensemble -- it meets the units at the one place where the walk is inlined, below)
+            ens_task = true; ens_item = item;
+            wi = (int)ag_ld(&((const uint32_t *)(a.gdgp.ctx + (int64_t)((item >> 8) & 0x3FFFFFu) * a.gdgp.ctx_stride))[4]); b = 0;
         }
-        if (type == SWD_ITEM_FINAL) {
+        else if (type == SWD_ITEM_FINAL) {
             final_ctx = (int)(item & 0x3FFFFFFFu);
             uint32_t *h = (uint32_t *)(a.gdgp.ctx + (int64_t)final_ctx * a.gdgp.ctx_stride);
             wi = (int)__hip_atomic_load(&h[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2491,7 +2500,8 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
     constexpr bool SLICE = SWD_P16(NT) && (KIND == 0 || KIND == 3); // (the other kernels keep the whole residual syndrome in LDS: dbase = 0)
     const int dbase = SLICE ? (a.wins[wi].row0 & ~3) : 0;
     const int dlen = (SLICE ? min((a.wins[wi].row0 + a.wins[wi].g.m + 3) & ~3, (a.num_det + 3) & ~3) : ((a.num_det + 3) & ~3)) - dbase;
-    if (wi == 0) {
+    if (ens_task) { // (a task of a parked ensemble has no syndrome of its own: its state comes from the context)
+    } else if (wi == 0) {
         const uint8_t *det_b = a.det + (int64_t)b * a.det_stride;
         if constexpr (SLICE) {
             for (int r = tid; r < dlen; r += NT) sdet[r] = (dbase + r < a.num_det && det_b[dbase + r]) ? 1 : 0;
@@ -2546,7 +2556,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
     s.fpar = 0;
     __syncthreads();
 #ifdef SWD_TSPROF // diagnostic build: when the unit started (a parked tree's commit happens in another iteration of this loop)
-    if (a.prof && tid == 0 && final_ctx < 0) a.prof[((int64_t)b * a.W + wi) * 8 + 4] = wall_clock64();
+    if (a.prof && tid == 0 && final_ctx < 0 && !ens_task) a.prof[((int64_t)b * a.W + wi) * 8 + 4] = wall_clock64();
 #endif
 #ifdef SWD_GDG_DEBUG
     asm volatile("" ::: "memory"); dbg_tb = wall_clock64(); asm volatile("" ::: "memory");
@@ -2575,6 +2585,15 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
         else {
             uint8_t *snap_b = a.snap + (int64_t)sidx * a.snap_stride;
             bool redo = false;
+            if (ens_task) { // kind 7: nothing to decode first -- the walk below starts from the context
+            } else if (final_ctx >= 0 && KIND == 7) { // the result of a parked ensemble: every hypothesis has written its offer
+                if constexpr (KIND == 7) {
+                    const EnsCtx ec = gdg_ens_ctx(a.gdgp, final_ctx);
+                    gdg_ens_finalize<NT>(g, a.P, s, ec, R);
+                    if (tid == 0) ring_push(a.gdgp.fq, a.gdgp.fmask, (uint32_t)final_ctx);
+                    __syncthreads();
+                }
+            } else
             if (final_ctx >= 0) { // the result of a parked tree
                 const GdgCtx c = gdg_ctx(a.gdgp, final_ctx);
 #ifdef SWD_GDG_CHECKS
@@ -2593,7 +2612,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 }
                 __syncthreads();
             }
-            if (final_ctx < 0 || redo) {
+            if (!ens_task && (final_ctx < 0 || redo)) {
 #ifdef SWD_GDG_DEBUG
                 asm volatile("" ::: "memory"); dbg_tc = wall_clock64(); asm volatile("" ::: "memory");
 #endif
@@ -2603,6 +2622,76 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 if (tid == 0 && queued) { uint32_t *dbg_status = a.gdgp.chk_status; GDG_COUNT(R.exit_class == -2 ? 9 : 10, 1); GDG_COUNT(R.exit_class == -2 ? 11 : 12, wall_clock64() - t_unit0); }
 #endif
                 if (R.exit_class == -2) continue; // parked: a FINAL item brings the result
+            }
+            if constexpr (KIND == 7) {
+                // The threaded ensemble (swd_gdg_kernel.h, gdg_ensemble_tree), inlined HERE and nowhere else: a unit whose pre-processing
+                // BP failed arrives with exit class -3 after BPGD::reset and the peeling (decode_window_gdg), a task of a parked
+                // ensemble arrives from the queue.  Roles: 1 = the unit's owner (a context is free and the tree has a level to share:
+                // the tree threads become tasks, a FINAL item brings the result), 0 = the whole ensemble here, 2 = one tree thread.
+                if (ens_task || R.exit_class == -3) {
+                    GdgLds G;
+                    gdg_bind(G, s.scratch, L, g.n, g.new_n);
+                    SwdGraphDev g_ens = g;
+                    int role = 0, hyp = 0;
+                    bool dead_unsat = false;
+                    EnsCtx ec{};
+                    if (ens_task) {
+                        role = 2; hyp = (int)(ens_item & 0xFFu);
+                        ec = gdg_ens_ctx(a.gdgp, (int)((ens_item >> 8) & 0x3FFFFFu));
+                        dead_unsat = ag_ld(&ec.hdr[6]) != 0u;
+                        s.fpar = 0;
+                        __syncthreads();
+                        for (int l = tid; l < g.m; l += NT) s.cn_deg0[l] = g.row_deg[l];
+                        for (int v = tid; v < g.n; v += NT) { s.vn_val[v] = 0; s.hard[v] = 0; }
+                        for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
+                        for (int i = tid; i < (g.new_n + 1) / 2; i += NT) {
+                            const uint32_t x = ag_ld(&ec.pos[i]);
+                            G.pos_lv[2 * i] = (uint16_t)x;
+                            if (2 * i + 1 < g.new_n) G.pos_lv[2 * i + 1] = (uint16_t)(x >> 16);
+                        }
+                        if (a.P.max_iter_per_step < 4)
+                            for (int i = a.P.max_iter_per_step * g.n + tid; i < 4 * g.n; i += NT) hist_b[i] = 0.0;
+                        __syncthreads();
+                        // the masks of the thread's fork decide which checks are live: the check-to-thread map of the walk comes from them
+                        {
+                            const int64_t fkb = gdg_ens_fork_bytes(g.m, g.new_n, gdg_ens_fork_cells(g.E + 1 + 2 * (NT / 64), NT, VFP, DM));
+                            const int Tt = (1 << a.P.max_tree_depth) - 1, nfk = 1 << (a.P.max_tree_depth - 1);
+                            gdg_snap_load<NT>(g, s, G, hyp <= Tt ? ec.fork + (int64_t)(hyp >> 1) * fkb
+                                                                  : ec.fork + (int64_t)nfk * fkb + (int64_t)(hyp - Tt - 1) * ((gdg_snap_bytes(g.m, g.new_n) + 15) & ~(int64_t)15));
+                        }
+                    } else {
+                        dead_unsat = R.live_vn != 0;
+                        gdg_staged_graph(g_ens, g, s); // (decode_window_gdg staged the window's edge columns and check order in LDS)
+                        if (queued && a.gdgp.ctx && a.P.max_tree_depth >= 1) {
+                            __syncthreads();
+                            if (tid == 0) { uint32_t id = 0; acc[1] = ring_pop(a.gdgp.fq, a.gdgp.fmask, &id) ? id : 0xFFFFFFFFu; }
+                            __syncthreads();
+                            const int ectx_id = (int)acc[1];
+                            if (ectx_id >= 0) {
+                                role = 1;
+                                ec = gdg_ens_ctx(a.gdgp, ectx_id);
+                                if (tid == 0) {
+                                    ag_st(&ec.hdr[0], 1u); ag_st(&ec.hdr[4], (uint32_t)wi); ag_st(&ec.hdr[5], (uint32_t)b); ag_st(&ec.hdr[6], dead_unsat ? 1u : 0u);
+                                    ag_st(&ec.hdr[8], 0u); ag_st(&ec.hdr[9], 0u); ag_st(&ec.hdr[10], 0u); ag_st(&ec.hdr[11], 0u); ag_st(&ec.hdr[12], (uint32_t)R.pre_it);
+                                }
+                                for (int k = tid; k < ec.nh; k += NT) ag_st(&ec.etab[4 * k], 0u);
+                                for (int i = tid; i < (g.new_n + 1) / 2; i += NT)
+                                    ag_st(&ec.pos[i], (uint32_t)G.pos_lv[2 * i] | ((2 * i + 1 < g.new_n) ? ((uint32_t)G.pos_lv[2 * i + 1] << 16) : 0u));
+                                ag_publish_barrier();
+                            }
+                        }
+                        R.live_vn = g.n; R.post_it = 0;
+                    }
+                    gdg_ensemble_tree<NT, VFP, DM, KG>(role, &g_ens, &a.P, s, G, hist_b, snap_b, &R, dead_unsat ? 1 : 0, &a.gdgp, &ec, hyp);
+                    if (role != 0) continue; // a task is done; an owner's unit is parked: a FINAL item brings the result
+                    for (int v = tid; v < g.n; v += NT) s.hard[v] = 0;
+                    __syncthreads();
+                    for (int j = tid; j < g.new_n; j += NT) s.hard[G.pos_lv[j]] = G.best_err[j];
+                    __syncthreads();
+                    R.total_it = R.pre_it + R.post_it;
+                    R.exit_class = SWD_EXIT_POST;
+                    R.t[5] = wall_clock64();
+                }
             }
         }
         __syncthreads();
@@ -2721,10 +2810,10 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
 #endif
             if (tid == 0) {
                 __hip_atomic_store(&a.sched[1 + b], (uint32_t)(wi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if constexpr (KIND == 2) { if (queued) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit(b, wi + 1)); } // the shot's next window is ready
+                if constexpr (kQueue) { if (queued) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit(b, wi + 1)); } // the shot's next window is ready
             }
         }
-        if constexpr (KIND == 2) {
+        if constexpr (kQueue) {
             if (queued && tid == 0) {
                 if (wi == a.W - 1) { // the shot is finished: admit the next one
                     const uint32_t nb = shots0 + atomicAdd(a.sched, 1u);

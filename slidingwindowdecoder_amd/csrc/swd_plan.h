@@ -321,6 +321,56 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     const long long units = (long long)a.B * a.W;
     static const int grid_pct = getenv("SWD_GRID_PCT") ? std::max(1, atoi(getenv("SWD_GRID_PCT"))) : 100; // diagnostics: how does the launch scale with the workgroups per CU?
     const unsigned grid = (unsigned)std::min<long long>(units, std::max(1, slots[d->device & 63] * grid_pct / 100));
+    if constexpr (KIND == 7) {
+        // The threaded ensemble on the work-item ring (sliding-window launches): UNIT items (a window is queued when its predecessor has
+        // committed), one TASK item per tree thread of a parked ensemble, FINAL (swd_gdg_kernel.h, gdg_ensemble_tree ROLE 1 / 2).
+        // Context: header | position list | forks at depth D - 1 | offer table | one vector per hypothesis + the main thread's exit
+        // vector; its fork records (masks + message cells, 2^(D-1) of them) in the csnap area.
+        const int Dp = d->gp.max_tree_depth, NS = std::max(d->gp.max_side_depth - d->gp.max_tree_depth, 0);
+        if (a.W > 1 && a.B < SWD_GDG_ITEM_MAX_SHOTS && a.W <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_ENS_TICKETS")) {
+            a.slot_scratch = 1;
+            const bool tasks = Dp >= 1 && !getenv("SWD_ENS_NO_TASKS");
+            unsigned nctx = 64;
+            while (nctx < 2 * grid) nctx <<= 1;
+            const int nh = 1 + ((1 << Dp) - 1) + NS, nforks = Dp >= 1 ? (1 << (Dp - 1)) : 0;
+            unsigned cap = 1024;
+            while (cap < (unsigned)a.B + (tasks ? nctx * (unsigned)((1 << Dp) + 2 + NS) : 0u) + 2u * grid + 1024u) cap <<= 1;
+            const size_t qbytes = 16 + (size_t)cap * 8, fbytes = 16 + (size_t)nctx * 8;
+            const int pos_b = align_up(d->new_n_max * 2, 16), vec_b = align_up(d->new_n_max, 16);
+            a.gdgp.off_pos = SWD_GDG_HDR_BYTES; a.gdgp.off_node = a.gdgp.off_pos + pos_b; a.gdgp.off_rec = a.gdgp.off_node + align_up(std::max(nforks, 1) * 8 + NS * 12, 16); // (forks: guess, favoured value; side threads: guess, value, depth)
+            a.gdgp.off_err = a.gdgp.off_rec + align_up(nh * 16, 16); a.gdgp.err_stride = vec_b; a.gdgp.ens_hyps = nh;
+            a.gdgp.ctx_stride = align_up(a.gdgp.off_err + (nh + 1) * vec_b, 256);
+            int64_t forkb = 0, rec16 = 0;
+            const int vfp = (d->post_depth2 && d->vf > 2) ? 2 : d->vf;
+            for (auto &w : d->wins) {
+                const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
+                const int64_t cells = std::max<int64_t>(w.g->E + 1 + 2 * (NT / 64), (int64_t)vfp * DM * NT);
+                forkb = std::max(forkb, ((rec + 15) & ~(int64_t)15) + ((cells * 8 + 15) & ~(int64_t)15));
+                rec16 = std::max(rec16, (rec + 15) & ~(int64_t)15);
+            }
+            a.gdgp.csnap_stride = ((int64_t)nforks * forkb + (int64_t)NS * rec16 + 255) & ~(int64_t)255; // fork records, then the side threads' masks
+            Plan::LaunchSlot &sl = *d->cur;
+            if (sl.gq.reserve(qbytes)) return -1;
+            a.gdgp.q = sl.gq.as<uint32_t>(); a.gdgp.qmask = cap - 1;
+            a.gdgp.shots_inflight = (int)std::min<long long>(a.B, grid);
+            SWD_HIP(hipMemsetAsync(a.gdgp.q, 0, qbytes, st));
+            if (tasks) {
+                if (sl.gfq.reserve(fbytes) || sl.gctx.reserve((size_t)nctx * a.gdgp.ctx_stride) || sl.gsnap.reserve((size_t)nctx * a.gdgp.csnap_stride + 256)) return -1;
+                if (sl.gfree_n != (int)nctx) { // template of the full free ring: ids 0..nctx-1 in order
+                    std::vector<uint64_t> tmpl(2 + nctx);
+                    tmpl[0] = (uint64_t)nctx << 32; tmpl[1] = 0; // head 0, tail = contexts available
+                    for (unsigned t = 0; t < nctx; ++t) tmpl[2 + t] = ((uint64_t)(t + 1) << 32) | t;
+                    if (sl.gfree_tmpl.reserve(fbytes)) return -1;
+                    SWD_HIP(hipMemcpy(sl.gfree_tmpl.p, tmpl.data(), fbytes, hipMemcpyHostToDevice));
+                    sl.gfree_n = (int)nctx;
+                }
+                a.gdgp.fq = sl.gfq.as<uint32_t>(); a.gdgp.fmask = nctx - 1;
+                a.gdgp.ctx = sl.gctx.as<uint8_t>(); a.gdgp.csnap = sl.gsnap.as<uint8_t>();
+                a.gdgp.nctx = (int)nctx;
+                SWD_HIP(hipMemcpyAsync(a.gdgp.fq, sl.gfree_tmpl.p, fbytes, hipMemcpyDeviceToDevice, st));
+            }
+        }
+    }
     if constexpr (KIND == 2) { // work-item ring + contexts of parked trees (swd_gdg_kernel.h); items need per-workgroup scratch
         a.slot_scratch = 1;
         static const int inflight = getenv("SWD_GDG_INFLIGHT") ? std::max(1, atoi(getenv("SWD_GDG_INFLIGHT"))) : 4; // (4096 shots: 3, 4: 1.202 M windows/s; 6: 1.191; 8: 1.179; 12: 1.175 -- every branch is queued anyway while workgroups wait)
