@@ -11,6 +11,6 @@ for ((i = 0; i < rounds; i++)); do
   timeout 900 python3 tests/fuzz_vs_oracle.py 8 $sd 500 1024 osdw 8300 9216 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400   # large-graph kernels (scratch region in HBM)
   timeout 600 python3 tests/fuzz_vs_oracle.py 30 $sd 6 300 ens 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400               # threaded ensemble (kernel kind 7)
   for md in gd gdg bp; do timeout 600 python3 tests/fuzz_vs_oracle.py 40 $sd 6 300 $md 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400; done
-  for d in osd_window bpgdg_decoder bpgd_decoder bp_history_decoder; do timeout 600 python3 tests/fuzz_pipeline.py 20 $sd $d 90 2>&1 | grep -v amdgpu | tail -3 | cut -c1-500; done
+  for d in osd_window bpgdg_decoder bpgd_decoder bp_history_decoder ens; do timeout 600 python3 tests/fuzz_pipeline.py 20 $sd $d 90 2>&1 | grep -v amdgpu | tail -3 | cut -c1-500; done
   timeout 600 python3 tests/fuzz_bp4.py 40 $sd 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400
 done

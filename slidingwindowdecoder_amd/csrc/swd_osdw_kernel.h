@@ -941,6 +941,10 @@ __device__ __forceinline__ void select_smallest(const uint64_t *key, int n, int 
     __syncthreads();
 }
 
+// the same behind a function boundary (its own register allocation; the Lds descriptor travels by value)
+template <int NT>
+__device__ __attribute__((noinline)) void select_smallest_call(const uint64_t *key, int n, int keep, int *hist, Lds s) { select_smallest<NT>(key, n, keep, hist, s); }
+
 // llr[list[0]] + llr[list[1]] + ... added one by one in list order (what the reference's loops do), by one wave: the loads of 64
 // entries are in flight together, the additions walk the lanes.  Every lane returns the sum.
 __device__ __forceinline__ double ordered_llr_sum_wave(const double *llr, const uint16_t *list, int total) {
@@ -2019,7 +2023,13 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     for (int e = tid; e < g.E; e += NT) rc[e] = g.row_col[e];
     __syncthreads();
     // ---- shortening: decide cols[new_n:] = 0 (osd_window.pyx:178-183)
-    if (g.new_n < n) select_smallest<NT>(key, n, g.new_n, (int *)s.aux, s);
+    if (g.new_n < n) {
+        // BIG kernels: s.aux is HBM there, and the select's eight passes of histogram atomics cost 187 us per decode of the 936 x 8784
+        // model.  The live masks (8 m bytes of LDS) are rewritten by the shortening step below and are not read before it: the three
+        // histograms go there (47 us)
+        if constexpr (BIG) select_smallest_call<NT>(key, n, g.new_n, (m * 8 >= 3 * 256 * 4) ? (int *)s.livemask : (int *)s.aux, s);
+        else select_smallest<NT>(key, n, g.new_n, (int *)s.aux, s);
+    }
     R.t[3] = wall_clock64();
     bool contra = false;
     for (int l = tid; l < m; l += NT) {
@@ -2330,7 +2340,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         }
         __syncthreads();
     }
-    R.pm = osd_run<NT, DM, !BIG>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted); // (the column-form elimination addresses LDS explicitly)
+    R.pm = osd_run<NT, DM, !BIG>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted); // (the column-form elimination addresses LDS explicitly;
+    // behind a function boundary -- its own register allocation -- the headline launch took 12.3 instead of 10.5 ms: round 4)
     R.exit_class = SWD_EXIT_OSD;
 }
 

@@ -121,7 +121,11 @@ while done < trials:
                   new_n=int(rng.integers(mmax, nmax + 1)))
         if decoder == "bpgdg_decoder":
             kw["low_error_mode"] = bool(rng.integers(2))
-        oc = getattr(O, decoder)
+        if decoder == "ens":  # bpgdg_decoder(multi_thread=True): the threaded ensemble -- in a pipeline its tree and side threads are work items
+            kw.update(multi_thread=True, low_error_mode=bool(rng.integers(2)), max_tree_depth=int(rng.integers(0, 5)),
+                      max_tree_branch_step=int(rng.integers(0, 6)))
+            kw["max_side_depth"] = kw["max_tree_depth"] + int(rng.integers(0, 5))
+        oc = getattr(O, "bpgdg_decoder" if decoder == "ens" else decoder)
         make = lambda w: Fresh(lambda: oc(w.mat, channel_probs=w.prior, **kw))  # noqa: E731
     try:
         for w in plan.windows:
@@ -134,7 +138,7 @@ while done < trials:
     det = ((sp.csr_matrix(e) @ plan.chk.T.astype(np.int32)).toarray() % 2).astype(np.uint8)
     det[B - 8:] = (rng.random((8, plan.chk.shape[0])) < 0.2).astype(np.uint8)  # inconsistent tail
     try:
-        dev = SlidingWindowDecoder(plan, decoder=decoder, **kw)
+        dev = SlidingWindowDecoder(plan, decoder="bpgdg_decoder" if decoder == "ens" else decoder, **kw)
     except (ValueError, RuntimeError) as ex:
         print(f"trial {done}: device rejected geo={geo} m<={mmax} n<={nmax}: {ex}")
         bad += 1

@@ -325,6 +325,81 @@ def test_ensemble_prefix_tree_shapes_vs_oracle():
         print(f"{sh}: {post} ensembles, {ties} with a tied different vector")
 
 
+@pytest.mark.parametrize("D,S_", [(3, 10), (5, 6)])
+def test_threaded_ensemble_pipeline_work_items_vs_oracle(D, S_, monkeypatch):
+    """The whole (3,1) window loop with bpgdg_decoder(multi_thread=True) in every window.  In a pipeline launch the unit's owner walks
+    the prefix tree and the main thread, the tree and side threads are TASKS on other workgroups and a FINAL item replays the offers
+    (swd_gdg_kernel.h, gdg_ensemble_tree roles 1 / 2): total_e_hat, converge flags, path metrics, winners, tie counts and BP block
+    counts of every (shot, window) against the oracle driven through the host-side window loop -- and the other two schedules
+    (units from the ring without tasks; window-major tickets) must give the same records word for word."""
+    import slidingwindowdecoder_amd as S
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd.windows import sliding_window_decode_host
+    from tests.test_gpu_pipeline import load_plan
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    kw.update(max_tree_depth=D, max_side_depth=S_)
+    B = 64
+    det = fx.unpack(f["det"], plan.chk.shape[0])[:B]
+    W = len(plan.windows)
+    rec = {k: np.zeros((B, W)) for k in ("pm", "winner", "ties", "blocks", "conv", "post")}
+
+    class Fresh:  # the device gives every decode the state of a newly built object
+        def __init__(self, w):
+            self.w = w
+
+        def decode(self, s):
+            self.d = O.bpgdg_decoder(self.w.mat, channel_probs=self.w.prior, multi_thread=True, **kw)
+            return self.d.decode(s)
+
+    def tap(wi, j, dec, s, e_hat):
+        d = dec.d
+        rec["conv"][j, wi] = bool(d.converge)
+        rec["post"][j, wi] = d._res.exit_class != 0
+        if d._res.exit_class != 0 and e_hat is not None:
+            pms, winner, nt = d.ensemble_info()
+            rec["pm"][j, wi], rec["winner"][j, wi], rec["ties"][j, wi] = d.min_pm, winner, nt
+            rec["blocks"][j, wi] = d.ensemble_blocks()[0]
+
+    want, _ = sliding_window_decode_host(plan, det, Fresh, on_decode=tap)
+    results = []
+    for env in ({}, {"SWD_ENS_NO_TASKS": "1"}, {"SWD_ENS_TICKETS": "1"}):
+        for k in ("SWD_ENS_NO_TASKS", "SWD_ENS_TICKETS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dec = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", multi_thread=True, **kw)
+        total = dec.decode(det)
+        results.append((total.copy(), dec.last_stats.copy(), dec.last_min_pm.copy()))
+    for k in ("SWD_ENS_NO_TASKS", "SWD_ENS_TICKETS"):
+        monkeypatch.delenv(k, raising=False)
+    total, st, pm = results[0]
+    bad = np.flatnonzero((total != want).any(axis=1))
+    assert bad.size == 0, f"{bad.size} shots differ from the oracle host loop: {bad[:8]}"
+    assert np.array_equal((st[..., 0] & 0x100) != 0, rec["conv"] != 0)
+    post = rec["post"] != 0
+    ens = post & ((st[..., 0] & 0xFF) == 1)  # (a window whose BPGD::reset fails runs no ensemble: exit class 4)
+    assert ens.sum() > 150, ens.sum()
+    assert np.array_equal(pm[ens], rec["pm"][ens])
+    assert np.array_equal(st[..., 6][ens], rec["winner"][ens]) and np.array_equal(st[..., 7][ens], rec["ties"][ens])
+    assert np.array_equal(st[..., 5][ens], rec["blocks"][ens]), "BP blocks (counted once per thread that would run them)"
+    for other, name in zip(results[1:], ("ring without tasks", "tickets")):
+        assert np.array_equal(other[0], total), name
+        assert np.array_equal(other[1], st), name
+        assert np.array_equal(other[2], pm), name
+    # more shots than workgroups and contexts to spare: the same shots tiled and shuffled, every copy the same record
+    reps = 28
+    perm = np.random.default_rng(D).permutation(B * reps)
+    big = np.tile(det, (reps, 1))[perm]
+    dec = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", multi_thread=True, **kw)
+    tot2 = dec.decode(big)
+    assert np.array_equal(tot2, np.tile(total, (reps, 1))[perm])
+    assert np.array_equal(dec.last_stats, np.tile(st, (reps, 1, 1))[perm]) and np.array_equal(dec.last_min_pm, np.tile(pm, (reps, 1))[perm])
+    dec.check_status()
+
+
 def test_threaded_ensemble_weight2_known_answer():
     """`Syndrome code.ipynb` cell 6 (:233-234): only (0,72) and (1,73) converge, both with 14 flipped variable nodes -- the stored
     output of the reference's multi_thread=True run (recorded again in the fixture)"""

@@ -93,10 +93,11 @@ def test_bb288_pipeline_vs_oracle_host_loop():
     assert bad.size == 0, f"shots {bad.tolist()} differ; exit classes {(dec.last_stats[bad, :, 0] & 0xFF).tolist()}, iterations {dec.last_stats[bad, :, 1].tolist()}"
 
 
-@pytest.mark.parametrize("decoder", ["osd_window", "bpgdg_decoder", "bpgd_decoder"])
+@pytest.mark.parametrize("decoder", ["osd_window", "bpgdg_decoder", "bpgd_decoder", "ens"])
 def test_fuzz_random_window_plans_vs_oracle_host_loop(decoder):
     """Random block-banded detector error models, (W, F), priors and decoder parameters: one device launch
-    against the host window loop driven with the oracle (tests/fuzz_pipeline.py, fixed seed)."""
+    against the host window loop driven with the oracle (tests/fuzz_pipeline.py, fixed seed).  "ens" =
+    bpgdg_decoder(multi_thread=True) with random tree shapes: the threaded ensemble with its threads as work items."""
     import os
     import subprocess
     import sys
