@@ -573,7 +573,10 @@ def main():
     wl = WORKLOADS[args.workload]
     headline = args.workload == "headline"
     osdw = args.workload in ("headline", "bb288", "global144")
-    streaming = not args.no_stream and args.workload != "bp4" and not STUB
+    # the two-lane stream is the step mode where overlapping consecutive launches pays (the osd_window workloads: the next launch's grid
+    # fills the tail of the previous one); the guessing decoders' launches keep the device busy to their end and lose 3-5 % when two
+    # of them share it (gdg 1.17 against 1.20 M windows/s, 64 hypotheses 0.57 against 0.60 M), so their steps run one launch at a time
+    streaming = not args.no_stream and osdw and not STUB
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)
@@ -607,7 +610,7 @@ def main():
     elif args.workload == "bp4":
         engine = Bp4Engine(args, rank, local_rank, lo, hi)
     else:
-        engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload, streaming=not args.no_stream)
+        engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload, streaming=streaming)
     W = engine.W
     elapsed, gathered = time_steps(engine, args, dist, world, total_shots)
     assert gathered.shape[0] == total_shots, (gathered.shape, total_shots)
