@@ -1296,7 +1296,7 @@ __device__ __forceinline__ void gdg_ensemble_tree(int ROLE, const SwdGraphDev *g
             if (first) { bp_init<VF, DM>(s, vc); __syncthreads(); }
             first = false;
             EPT(0);
-            cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4);
+            cv = bp_run<NT, VF, DM, KG, false, false, false, !std::is_same_v<ST, GdgNoStatic>>(g, P, s, P.max_iter_per_step, nlive, vc, cn, hist_b, it, P.gdg_factor, dead_unsat, nullptr, h4, with_main);
             blocks += share; R.post_it += it * share; // counted once per thread of the ensemble that runs this block
             EPT(1);
         }
@@ -1308,6 +1308,10 @@ __device__ __forceinline__ void gdg_ensemble_tree(int ROLE, const SwdGraphDev *g
             else if (ntree > 0) emit(1, ntree, pm_t);
         }
         int gpos = NONE, favor = 0, rc = 0;
+        if (cv && it < P.max_iter_per_step) { // (an early exit leaves the parity words re-armed with the syndrome bits by the iteration that noticed it:
+            for (int l = tid; l < m; l += NT) s.par[l] = 0u; // what the scan below counts is the checks the last iteration left unmet -- none)
+            __syncthreads();
+        }
         if (!cv || with_main) {
             const bool sidethr = !(mode == M_MAIN || (desc && p == 0)); // thresholds (0, -10) once an unfavoured branch has been taken
             rc = gdg_select_core<NT>(g, P, s, G, hist_b, sidethr ? 0.0 : -3.0, sidethr ? -10.0 : (d == 0 ? -16.0 : -12.0), d, gpos, favor, st, h4);

@@ -591,10 +591,12 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
-                      double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr) {
+                      double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr, bool rec_early = false) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
-    const bool record_all = P.record_all != 0;
+    // rec_early: the caller reads the history even when the run converges before its last four iterations (the threaded
+    // ensemble's main thread scans BEFORE its convergence test, bpgd.cpp:630-633)
+    const bool record_all = P.record_all != 0 || rec_early;
     const int l = cn.l >= 0 ? cn.l : 0;      // NT >= m: at most one check per thread
     const int cv = (cn.l >= 0) ? (int)s.cn_val[l] : -1;
     const int cnt = cn.cnt;
@@ -660,7 +662,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     for (int u = 0; u < 4; ++u) {
                         const int k = gq * 4 + u;
                         const double ax = vminabs64(xs[u], 50.0);
-                        argslot = (ax < min1) ? ad[u] : argslot;
+                        argslot = (ax < min1) ? ad[u] : argslot; // (as sign-of-difference mask + v_bfi instead of v_cmp + v_cndmask: 10.1 against 10.0 ms, round 4)
                         min2 = vmin64(min2, vmax64(min1, ax));
                         min1 = vmin64(min1, ax);
                         neg_shift_in(neg[k >> 5], xs[u]);
@@ -1627,10 +1629,16 @@ __device__ __forceinline__ bool cs_better(double pa, int la, double pb, int lb) 
     return (pa < pb) || (pa == pb && la < lb);
 }
 
+// The ordered sum is the expensive part: one term per pivot (216 for the [[144]] windows, 576 for [[288]]) for each of the ~260 /
+// ~620 candidates, although a candidate's solution has a few dozen ones.  So the rows of T -- and with them every candidate's y -- are
+// first PERMUTED into the order the sum walks: bit i of a permuted word is the pivot variable of rank i among the pivot columns
+// sorted by column (each thread permutes its own column of T in place: read it, zero it, OR the bits back at their ranks; rows
+// without a pivot are dropped -- they are no variables).  A candidate's sum then visits the SET bits of y in ascending order and adds
+// exactly the terms the term-by-term loop added (it added +0.0 for the others: x + 0.0 == x).  rank_of_row: m u16 of scratch.
 template <int NT>
 __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
-                            const uint16_t *idx, const uint64_t *Tc, const uint64_t *y0,
-                            const uint16_t *piv_col, const uint16_t *piv_row, int npiv, double pm0) {
+                            const uint16_t *idx, uint64_t *Tc, const uint64_t *y0,
+                            const uint16_t *piv_col, const uint16_t *piv_row, int npiv, double pm0, uint16_t *rank_of_row) {
     const int tid = threadIdx.x, n = g.n, wm = g.wm, kset = g.new_n - g.rank, CP = L.cs_par;
     const int order = P.osd_order;
     char *cs = s.scratch + L.off_cs;
@@ -1666,6 +1674,39 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
         int pos = block_exscan<NT>(cnt, s, tot);
         for (int v = v0; v < v1; ++v)
             if (prow_of[v] != 0xFFFF) { pcs[pos] = (uint16_t)v; prs[pos] = prow_of[v]; pllr[pos] = g.llr[v]; ++pos; }
+    }
+    __syncthreads();
+    uint64_t *y0p = ybuf + 48; // y0 in rank order (the candidates no longer use ybuf; its first words serve the arg-min and the winner)
+    {
+        const int m = g.m;
+        for (int r = tid; r < m; r += NT) rank_of_row[r] = 0xFFFF;
+        for (int w = tid; w < wm; w += NT) y0p[w] = 0ull;
+        __syncthreads();
+        for (int i = tid; i < npiv; i += NT) rank_of_row[prs[i]] = (uint16_t)i;
+        __syncthreads();
+        for (int r = tid; r < m; r += NT) {
+            const int rk = rank_of_row[r];
+            if (rk != 0xFFFF && ((y0[r >> 6] >> (r & 63)) & 1ull)) atomicOr((unsigned long long *)&y0p[rk >> 6], 1ull << (rk & 63));
+        }
+        for (int j = tid; j < m; j += NT) { // column j of T: bits by pivot row -> bits by rank, in place (the column is this thread's alone)
+            uint64_t col[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { col[w] = (w < wm) ? Tc[osd_tidx(j, w, m)] : 0ull; }
+#pragma unroll
+            for (int w = 0; w < 16; ++w) if (w < wm) Tc[osd_tidx(j, w, m)] = 0ull;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                if (w < wm) { // (uniform)
+                    uint64_t x = col[w];
+                    while (x) {
+                        const int b = __ffsll((long long)x) - 1;
+                        x &= x - 1;
+                        const int rk = rank_of_row[64 * w + b];
+                        if (rk != 0xFFFF) atomicOr((unsigned long long *)&Tc[osd_tidx(j, rk >> 6, m)], 1ull << (rk & 63));
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
     const bool exhaustive = (P.osd_method == 1);
@@ -1705,48 +1746,45 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
                 }
                 const int cA = min(c1, c2), cB = max(c1, c2); // cB = INF for a single column
                 const double llrA = g.llr[cA], llrB = (cB != INF) ? g.llr[cB] : 0.0;
-                for (int w = 0; w < wm; ++w) {
-                    uint64_t yw = y0[w];
-#pragma unroll
-                    for (int k = 0; k < 2 * SWD_DMAX; ++k)
-                        if (rw[k] >= 0) yw ^= Tc[osd_tidx(rw[k], w, g.m)];
-                    ybuf[w * CP + tid] = yw;
-                }
-                // number of pivot columns below cA / cB (pcs ascending)
+                // number of pivot columns below cA / cB (pcs ascending): the candidate's own columns enter the sum there
                 int posA = 0, posB = npiv;
                 { int lo = 0, hi = npiv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)pcs[mid] < cA) lo = mid + 1; else hi = mid; } posA = lo; }
                 if (cB != INF) { int lo = posA, hi = npiv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)pcs[mid] < cB) lo = mid + 1; else hi = mid; } posB = lo; }
-                auto stretch = [&](int i0, int i1) {
-                    for (int i = i0; i < i1; ++i) {
-                        const int r = prs[i];
-                        const bool on = (ybuf[(r >> 6) * CP + tid] >> (r & 63)) & 1ull;
-                        pm += on ? pllr[i] : 0.0; // x + 0.0 == x: the sum is the reference's, term by term
-                    }
-                };
-                stretch(0, posA);
-                pm += llrA;
-                stretch(posA, posB);
-                if (cB != INF) pm += llrB;
-                stretch(posB, npiv);
-            } else {
+                bool a_done = false, b_done = (cB == INF);
                 for (int w = 0; w < wm; ++w) {
-                    uint64_t yw = y0[w];
+                    uint64_t yw = y0p[w];
+#pragma unroll
+                    for (int k = 0; k < 2 * SWD_DMAX; ++k)
+                        if (rw[k] >= 0) yw ^= Tc[osd_tidx(rw[k], w, g.m)];
+                    while (yw) { // the set pivot variables of this word, in column order
+                        const int i = 64 * w + __ffsll((long long)yw) - 1;
+                        yw &= yw - 1;
+                        if (!a_done && i >= posA) { pm += llrA; a_done = true; }
+                        if (!b_done && i >= posB) { pm += llrB; b_done = true; }
+                        pm += pllr[i];
+                    }
+                }
+                if (!a_done) pm += llrA;
+                if (!b_done) pm += llrB;
+            } else {
+                int q = 0;
+                for (int w = 0; w < wm; ++w) {
+                    uint64_t yw = y0p[w];
                     for (int i = 0; i < order; ++i)
                         if ((l >> i) & 1) {
                             const int c = Ht[i], dc = g.col_deg[c];
                             for (int k = 0; k < dc; ++k) yw ^= Tc[osd_tidx((int)g.vn_row[k * n + c], w, g.m)];
                         }
-                    ybuf[w * CP + tid] = yw;
-                }
-                int q = 0;
-                for (int i = 0; i < npiv; ++i) {
-                    const int pc = pcs[i];
-                    while (q < order && (int)hts_col[q] < pc) {
-                        if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
-                        ++q;
+                    while (yw) {
+                        const int i = 64 * w + __ffsll((long long)yw) - 1;
+                        yw &= yw - 1;
+                        const int pc = pcs[i];
+                        while (q < order && (int)hts_col[q] < pc) { // the pattern's own columns that come before this pivot column
+                            if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
+                            ++q;
+                        }
+                        pm += pllr[i];
                     }
-                    const int r = prs[i];
-                    if ((ybuf[(r >> 6) * CP + tid] >> (r & 63)) & 1ull) pm += pllr[i];
                 }
                 while (q < order) {
                     if ((l >> hts_bit[q]) & 1) pm += g.llr[hts_col[q]];
@@ -1776,7 +1814,7 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
     const long l = best_l;
     for (int v = tid; v < n; v += NT) s.hard[v] = 0;
     for (int w = tid; w < wm; w += NT) {
-        uint64_t yw = y0[w];
+        uint64_t yw = y0p[w];
         if (!exhaustive) {
             int c1, c2 = INF;
             if (l < kset) c1 = Ht[l];
@@ -1798,10 +1836,7 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
         ybuf[32 + w] = yw; // wpm/wl occupy the first 24 words
     }
     __syncthreads();
-    for (int i = tid; i < npiv; i += NT) {
-        const int r = piv_row[i];
-        s.hard[piv_col[i]] = (uint8_t)((ybuf[32 + (r >> 6)] >> (r & 63)) & 1ull);
-    }
+    for (int i = tid; i < npiv; i += NT) s.hard[pcs[i]] = (uint8_t)((ybuf[32 + (i >> 6)] >> (i & 63)) & 1ull); // (bit i = the pivot variable of rank i)
     __syncthreads();
     if (tid == 0) {
         if (!exhaustive) {
@@ -1880,7 +1915,7 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
     if (osd0_b)
         for (int v = tid; v < n; v += NT) osd0_b[v] = s.hard[v];
     double pm = ordered_pm<NT>(g, s, list1);
-    if (P.osd_order > 0) pm = osd_sweep<NT>(g, L, P, s, idx, Tc, Sbuf, piv_col, piv_row, npiv, pm);
+    if (P.osd_order > 0) pm = osd_sweep<NT>(g, L, P, s, idx, Tc, Sbuf, piv_col, piv_row, npiv, pm, list1); // (list1: dead after ordered_pm)
     return pm;
 }
 

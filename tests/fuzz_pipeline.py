@@ -166,5 +166,29 @@ while done < trials:
               f"kw={kw} shots differing {d.size}/{B} first {d[:6].tolist()} threads {dev.threads} "
               f"flips_ok {np.array_equal(dev.last_obs_flips, mask)} flagged_ok {np.array_equal(dev.last_flagged, resid)} "
               f"conv_ok {np.array_equal((dev.last_stats[:, :, 0] & 0x100) != 0, conv)}")
+        if os.environ.get("SWD_FUZZ_DEBUG") and decoder == "ens" and d.size:
+            # which window, and does the single-window device decoder agree with the oracle on that window's syndrome?
+            from slidingwindowdecoder_amd import bpgdg_decoder
+            j = int(d[0])
+            chk_t = sp.csr_matrix(plan.chk.T.astype(np.int32))
+            tot = np.zeros(plan.chk.shape[1], np.uint8)
+            cur = det[j].copy()
+            for wi, w in enumerate(plan.windows):
+                synd = cur[w.row0:w.row1]
+                o = oc(w.mat, channel_probs=w.prior, **kw)
+                e_o = np.asarray(o.decode(synd))
+                dv = bpgdg_decoder(w.mat, channel_probs=w.prior, **kw)
+                e_d = np.asarray(dv.decode_batch(synd[None, :]))[0]
+                info = o.ensemble_info() if o._res.exit_class != 0 else None
+                print(f"  shot {j} window {wi}: oracle exit {o._res.exit_class} conv {o.converge} pm {o.min_pm} info {None if info is None else (info[0].tolist(), info[1], info[2])} blocks {o.ensemble_blocks() if info else None} | "
+                      f"single-window device == oracle: {np.array_equal(e_d, e_o)} stats {dv.last_stats[0].tolist()} pm {dv.last_min_pm[0]} | pipeline stats {dev.last_stats[j, wi].tolist()} pm {dev.last_min_pm[j, wi]} "
+                      f"committed equal {np.array_equal(total[j, w.col0:w.col0 + w.commit], e_o[:w.commit])}")
+                if not np.array_equal(e_d, e_o) and os.environ.get("SWD_FUZZ_DUMP"):
+                    import json
+                    m_ = sp.csr_matrix(w.mat)
+                    np.savez(os.environ["SWD_FUZZ_DUMP"], indptr=m_.indptr, indices=m_.indices, shape=np.array(m_.shape), prior=w.prior, synd=synd,
+                             kw=np.array(json.dumps(kw)))
+                tot[w.col0:w.col0 + w.commit] = e_o[:w.commit]
+                cur = ((det[j] + (sp.csr_matrix(tot[None, :]) @ chk_t).toarray()[0]) % 2).astype(np.uint8)
 print(f"{trials} trials, {bad} mismatching")
 sys.exit(1 if bad else 0)

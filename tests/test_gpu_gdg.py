@@ -1,8 +1,11 @@
 """GPU parity of the guessing decoders (bpgdg single-thread gdg(), bpgd, plain BP) against the
 reference's recorded runs and the oracle."""
+import os
+
 import numpy as np
 import pytest
 
+from oracle import oracle as O
 from tests import fixtures as fx
 
 pytestmark = pytest.mark.gpu
@@ -323,6 +326,29 @@ def test_ensemble_prefix_tree_shapes_vs_oracle():
     for sh in shapes:
         post, ties = _ensemble_vs_oracle(mat, priors, dict(base, **sh), tr.synd[:64], 8)
         print(f"{sh}: {post} ensembles, {ties} with a tied different vector")
+
+
+def test_ensemble_main_thread_scan_after_an_early_converged_block():
+    """tests/golden/ens_main_early_convergence.npz (found by tests/fuzz_pipeline.py, seed 13000): the main thread's block converges
+    in its second iteration of six and the thread still runs its scan on it (bpgd.cpp:630-633) -- the history slots the block did not
+    reach keep the previous block's values and no check is unmet.  The device has to record every iteration of a block the main
+    thread takes part in, and must not count the parity words the exiting iteration re-armed as unmet checks."""
+    import json
+    import scipy.sparse as sp
+    import slidingwindowdecoder_amd as S
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "ens_main_early_convergence.npz"))
+    mat = sp.csr_matrix((np.ones(len(f["indices"]), np.uint8), f["indices"], f["indptr"]), shape=tuple(f["shape"]))
+    kw = json.loads(str(f["kw"]))
+    for over in (dict(), dict(max_side_depth=0), dict(max_tree_depth=2, max_side_depth=4), dict(max_iter_per_step=9)):
+        k2 = dict(kw, **over)
+        dev = S.bpgdg_decoder(mat, channel_probs=f["prior"], **k2)
+        ora = O.bpgdg_decoder(mat, channel_probs=f["prior"], **k2)
+        out = dev.decode_batch(np.repeat(f["synd"][None, :], 3, axis=0))
+        want = ora.decode(f["synd"])
+        assert np.array_equal(out[0], want) and np.array_equal(out[2], want), over
+        assert dev.last_min_pm[0] == ora.min_pm, (over, dev.last_min_pm[0], ora.min_pm)
+        if not over:
+            assert np.array_equal(want, f["expect"]) and ora.min_pm == float(f["expect_pm"])
 
 
 @pytest.mark.parametrize("D,S_", [(3, 10), (5, 6)])

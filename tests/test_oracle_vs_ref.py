@@ -164,7 +164,7 @@ def _ensemble_case(R, mat, priors, kw, synds):
     dec = O.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
     p = Pcm(R, mat)
     llr = np.ascontiguousarray(np.log((1 - priors) / priors))
-    new_n = min(n, 2 * m)
+    new_n = kw.get("new_n") or min(n, 2 * m)
     R.ref_gdg_multi.argtypes = [C.c_void_p] + [C.c_int32] * 9 + [C.c_double] + [C.c_void_p] * 6
     ran = ties = conv = 0
     for s in synds:
@@ -236,6 +236,22 @@ def test_gdg_multi_64_hypotheses_bb144_window(R):
         r = _ensemble_case(R, mat, priors, kw, list(tr.synd[:64]))
         tot = [a + b for a, b in zip(tot, r)]
     assert tot[0] >= 30 and tot[1] >= 25, tot
+
+
+def test_threaded_ensemble_main_thread_scans_a_block_that_converged_early(R):
+    """A window found by tests/fuzz_pipeline.py (seed 13000, `ens`; dumped with SWD_FUZZ_DUMP): the main thread's fifth block
+    converges in its second iteration and the thread runs select_vn on it BEFORE testing convergence (bpgd.cpp:630-633), i.e. on a
+    history whose slots 2 and 3 are the previous block's and on a syndrome that is met.  The reference's real threads, the oracle
+    and the stored vector agree (round 4's device walk did not: it recorded the last four iterations of a block only)."""
+    import json
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "ens_main_early_convergence.npz"))
+    mat = sp.csr_matrix((np.ones(len(f["indices"]), np.uint8), f["indices"], f["indptr"]), shape=tuple(f["shape"]))
+    kw = json.loads(str(f["kw"]))
+    kw.pop("multi_thread")
+    ran, conv, ties = _ensemble_case(R, mat, f["prior"], kw, [f["synd"]])
+    assert (ran, conv, ties) == (1, 1, 0)
+    dec = O.bpgdg_decoder(mat, channel_probs=f["prior"], multi_thread=True, **kw)
+    assert np.array_equal(dec.decode(f["synd"]), f["expect"]) and dec.min_pm == float(f["expect_pm"])
 
 
 def test_threaded_ensemble_weight2_known_answer():
