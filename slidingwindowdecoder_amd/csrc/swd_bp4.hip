@@ -44,6 +44,11 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
 }
 
 static int bp4_dispatch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+    // one thread per qubit where the code is small: a workgroup of ceil(n / 64) waves (the decodes of the notebooks' codes take one or
+    // two iterations -- what a launch costs is the number of waves it occupies)
+    if (d->nt == 64) return d->dm == 4 ? bp4_launch<64, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<64, 8>(d, a, st) : bp4_launch<64, SWD_DMAX>(d, a, st));
+    if (d->nt == 128) return bp4_launch<128, 4>(d, a, st);
+    if (d->nt == 192) return bp4_launch<192, 4>(d, a, st);
     if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<256, 8>(d, a, st) : bp4_launch<256, SWD_DMAX>(d, a, st));
     return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<1024, 8>(d, a, st) : bp4_launch<1024, SWD_DMAX>(d, a, st));
 }
@@ -83,6 +88,9 @@ extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_des
     if (D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", D, SWD_DMAX); delete d; return nullptr; }
     d->dm = D <= 4 ? 4 : (D <= 8 ? 8 : SWD_DMAX); // SHYPS stabiliser matrices reach column weight 9
     d->nt = n <= 3072 ? 256 : 1024;
+    if (n <= 64) d->nt = 64;
+    else if (n <= 192 && d->dm == 4) d->nt = (n + 63) / 64 * 64;
+    if (const char *e = getenv("SWD_BP4_NT")) { const int v = atoi(e); if ((v == 256 || v == 1024) && v >= d->nt) d->nt = v; } // (diagnostics: the wider workgroups)
     if (d->gx.upload() || d->gz.upload()) { delete d; return nullptr; }
     d->gx.d.new_n = n; d->gz.d.new_n = n;
     make_layout_for_osd(d->gx, d->nt, d->Lx);

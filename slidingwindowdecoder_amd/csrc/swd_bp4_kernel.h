@@ -88,8 +88,11 @@ __device__ __forceinline__ bool bp4_cn_pass(const SwdGraphDev &g, double *msg, c
     return unsat;
 }
 
+#ifndef SWD_BP4_WAVES
+#define SWD_BP4_WAVES 6 // waves per SIMD the register allocation leaves room for (kernels of up to 256 threads): measured 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]]
+#endif
 template <int NT, int DM>
-__global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
+__global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SwdGraphDev &gx = a.gx, &gz = a.gz;
     const int tid = threadIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
@@ -127,6 +130,12 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
         }
         c_lx = a.llr_x[tid]; c_ly = a.llr_y[tid]; c_lz = a.llr_z[tid];
     }
+    // (the messages of bp_init depend on the channel only: three of a decode's ~14 exp / log1p evaluations, hoisted out of the unit loop)
+    double c_mx = 0.0, c_mz = 0.0;
+    if (mine) {
+        c_mx = bp4_log1pexp(-1. * c_lx) - bp4_logaddexp(-1. * c_ly, -1. * c_lz);
+        c_mz = bp4_log1pexp(-1. * c_lz) - bp4_logaddexp(-1. * c_ly, -1. * c_lz); // sic (bp4_osd.pyx:438)
+    }
     for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const int b = a.camel ? unit >> 2 : unit;
     s.fpar = 0;
@@ -143,9 +152,12 @@ __global__ void __launch_bounds__(NT) bp4_kernel(const SwdBp4Args a) {
     for (int r = tid; r < mz; r += NT) szo[r] = sz_b[r] ? 1 : 0;
     for (int v = tid; v < n; v += NT) {
         decx[v] = 0; decz[v] = 0;
-        const double llrx = one ? c_lx : a.llr_x[v], llry = one ? c_ly : a.llr_y[v], llrz = one ? c_lz : a.llr_z[v];
-        const double m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
-        const double m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz); // sic (bp4_osd.pyx:438)
+        double m_x = c_mx, m_z = c_mz;
+        if (!one) {
+            const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
+            m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
+            m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz); // sic (bp4_osd.pyx:438)
+        }
         const int dx = one ? c_dx : (int)gx.col_deg[v], dz = one ? c_dz : (int)gz.col_deg[v];
         if (one) {
 #pragma unroll
