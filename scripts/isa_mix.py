@@ -19,7 +19,7 @@ KERNELS = {
     "gdg": ("swd_kernels_k2.hip", "pipeline_kernelILi256ELi7ELi6ELi9ELi2ELb0ELb0ELi2E"),
     "gdg64": ("swd_kernels_k7.hip", "pipeline_kernelILi256ELi7ELi6ELi9ELi7ELb0ELb0ELi2E"),
     "global144": ("swd_kernels_k5.hip", "pipeline_kernelILi1024ELi9ELi6ELi9ELi3ELb0ELb1ELi9E"),
-    "bp4": ("swd_bp4.hip", "bp4_kernelILi256ELi4E"),
+    "bp4": ("swd_bp4.hip", "bp4_kernelILi192ELi4E"),
 }
 FLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=iterative-ilp "
          "-mllvm -amdgpu-atomic-optimizer-strategy=None -I../../include -I. --cuda-device-only -S").split()
