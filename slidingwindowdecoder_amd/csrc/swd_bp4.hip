@@ -15,7 +15,7 @@ struct Bp4 {
     int device = 0, nt = 256, dm = 4, n = 0;
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
-    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd, io;
+    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd, io, osd_q;
     PinnedBuf stage;
     const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
 };
@@ -38,8 +38,27 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
         slots_lds[d->device & 63] = d->L.total;
     }
     const int units = a.camel ? 4 * a.B : a.B;
+    const bool with_osd = !a.camel && a.osd_order >= 0;
+    if (with_osd) SWD_HIP(hipMemsetAsync(a.osd_count, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(std::min(units, slots[d->device & 63])), dim3(NT), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
+    if (with_osd) { // the queue of unconverged decodes (often empty: its workgroups then read the count and leave)
+        static int lds_limit2[64] = {0}, slots2[64] = {0}, slots2_lds[64] = {0};
+        if (d->L.total > lds_limit2[d->device & 63]) {
+            SWD_HIP(hipFuncSetAttribute((const void *)bp4_osd_kernel<NT, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
+            lds_limit2[d->device & 63] = d->L.total;
+        }
+        if (!slots2[d->device & 63] || slots2_lds[d->device & 63] != d->L.total) {
+            int per_cu = 0, cus = 0;
+            SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_osd_kernel<NT, DM>, NT, (size_t)d->L.total));
+            SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
+            while (per_cu > 1 && (long long)per_cu * ((d->L.total + 1279) / 1280 * 1280) > 160 * 1024) --per_cu;
+            slots2[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
+            slots2_lds[d->device & 63] = d->L.total;
+        }
+        hipLaunchKernelGGL((bp4_osd_kernel<NT, DM>), dim3(std::min(a.B, slots2[d->device & 63])), dim3(NT), d->L.total, st, a);
+        SWD_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -163,6 +182,8 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
     a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.bp_dec = bp_dec; a.stats = stats; a.lpr = lpr;
+    if (d->osd_q.reserve((size_t)B * 4 + 16)) return -1;
+    a.osd_count = d->osd_q.as<uint32_t>(); a.osd_list = d->osd_q.as<int32_t>() + 4;
     hipStream_t st = (hipStream_t)stream;
     return bp4_dispatch(d, a, st);
 }

@@ -31,6 +31,10 @@ struct SwdBp4Args {
     double *lpr;             // [B][3][n] posterior LLRs (x, y, z); also the OSD ordering input
     // camel_decode (bp4_osd.pyx:223-247): 4 workgroups per shot, workgroup 4b+v fixes the last qubit to Pauli v
     // (0 I, 1 X, 2 Z, 3 Y) and runs plain BP4; out/osd0 are unused, lpr is [4B][3][n] scratch
+    // decodes that leave BP unconverged are queued here and finished by bp4_osd_kernel on the same stream: the BP kernel then carries
+    // neither the elimination's code nor its scratch arrays (17.3 -> 20.4 M decodes/s on [[144,12,12]])
+    int32_t *osd_list;       // [B]
+    uint32_t *osd_count;     // zeroed before the launch
     int32_t camel;
     uint8_t *camel_dec;      // [4B][2][n] decisions of every run
     double *camel_pm;        // [4B] cal_pm of the converged runs
@@ -39,11 +43,16 @@ struct SwdBp4Args {
 
 namespace swd {
 
-__device__ __forceinline__ double bp4_log1pexp(double x) {
+#ifdef SWD_BP4_CALLS
+#define SWD_BP4_FN __device__ __attribute__((noinline))
+#else
+#define SWD_BP4_FN __device__ __forceinline__
+#endif
+SWD_BP4_FN double bp4_log1pexp(double x) {
     if (x > 36.04365338911715) return x + swd_log1p(swd_exp(-x)); // -log(DBL_EPSILON)
     return swd_log1p(swd_exp(x));
 }
-__device__ __forceinline__ double bp4_logaddexp(double x, double y) {
+SWD_BP4_FN double bp4_logaddexp(double x, double y) {
     const double tmp = x - y;
     if (x == y) return x + 0.693147180559945309417232121458176568;
     if (tmp > 0) return x + bp4_log1pexp(-tmp);
@@ -88,6 +97,9 @@ __device__ __forceinline__ bool bp4_cn_pass(const SwdGraphDev &g, double *msg, c
     return unsat;
 }
 
+#ifndef SWD_BP4_ROLLED
+#define SWD_BP4_ROLLED 1 // the variable-node update's per-edge loops as loops (one helper body per basis; SHYPS r = 3 +10 %, the BB codes unchanged, half the compile time)
+#endif
 #ifndef SWD_BP4_WAVES
 #define SWD_BP4_WAVES 6 // waves per SIMD the register allocation leaves room for (kernels of up to 256 threads): measured 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]]
 #endif
@@ -102,7 +114,6 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
     uint16_t *jpx = (uint16_t *)(smem + a.L.off_jptrx), *jpz = (uint16_t *)(smem + a.L.off_jptrz);
     int8_t *cnx = (int8_t *)(smem + a.L.off_cnx), *cnz = (int8_t *)(smem + a.L.off_cnz);
     uint32_t *parx = (uint32_t *)(smem + a.L.off_parx), *parz = (uint32_t *)(smem + a.L.off_parz);
-    uint8_t *sxo = (uint8_t *)(smem + a.L.off_sxo), *szo = (uint8_t *)(smem + a.L.off_szo);
     uint8_t *decx = (uint8_t *)(smem + a.L.off_decx), *decz = (uint8_t *)(smem + a.L.off_decz);
     Lds s;
     s.scratch = smem; s.msg = msgx; s.hard = (uint8_t *)(smem + a.L.off_hard);
@@ -148,8 +159,6 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
     // reset + bp_init (bp4_osd.pyx:371-386, 425-442)
     for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
     for (int l = tid; l < mz; l += NT) cnz[l] = (int8_t)(sz_b[gz.perm[l]] ? 1 : 0);
-    for (int r = tid; r < mx; r += NT) sxo[r] = sx_b[r] ? 1 : 0;
-    for (int r = tid; r < mz; r += NT) szo[r] = sz_b[r] ? 1 : 0;
     for (int v = tid; v < n; v += NT) {
         decx[v] = 0; decz[v] = 0;
         double m_x = c_mx, m_z = c_mz;
@@ -223,6 +232,29 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
             const int bx = idx & 1, bz = idx >> 1;
             decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz;
             const double num_hx = bp4_log1pexp(-1. * llrx_hx);
+#if SWD_BP4_ROLLED // one body of the helper per basis instead of DM: the edge word is picked by a select chain, the message re-read from LDS
+            auto pick = [&](const uint32_t (&ev)[DM], int k) { uint32_t e = ev[0];
+#pragma unroll
+                for (int j = 1; j < DM; ++j) e = (k == j) ? ev[j] : e;
+                return e; };
+#pragma unroll 1
+            for (int k = 0; k < dx; ++k) {
+                const uint32_t e = pick(ex, k);
+                const double c = msgx[swd_edge_slot(e)];
+                const double aa = llrz_hz - c, bb = llry_all - c;
+                msgx[swd_edge_slot(e)] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb);
+                if (bz) atomicXor(&parx[swd_edge_lane(e)], 1u); // Hx * z-string
+            }
+            const double num_hz = bp4_log1pexp(-1. * llrz_hz);
+#pragma unroll 1
+            for (int k = 0; k < dz; ++k) {
+                const uint32_t e = pick(ez, k);
+                const double c = msgz[swd_edge_slot(e)];
+                const double aa = llrx_hx - c, bb = llry_all - c;
+                msgz[swd_edge_slot(e)] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb);
+                if (bx) atomicXor(&parz[swd_edge_lane(e)], 1u); // Hz * x-string
+            }
+#else
 #pragma unroll
             for (int k = 0; k < DM; ++k)
                 if (k < dx) {
@@ -238,6 +270,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
                     msgz[swd_edge_slot(ez[k])] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb);
                     if (bx) atomicXor(&parz[swd_edge_lane(ez[k])], 1u); // Hz * x-string
                 }
+#endif
         }
         __syncthreads();
     }
@@ -271,14 +304,48 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
     uint8_t *out_b = a.out + (int64_t)b * 2 * n;
     if (a.bp_dec)
         for (int v = tid; v < n; v += NT) { a.bp_dec[(int64_t)b * 2 * n + v] = decx[v]; a.bp_dec[(int64_t)b * 2 * n + n + v] = decz[v]; }
-    int exit_class = SWD_EXIT_PRE, rowadds = 0;
+    int exit_class = SWD_EXIT_PRE;
     if (conv || a.osd_order < 0) {
         for (int v = tid; v < n; v += NT) { out_b[v] = decx[v]; out_b[n + v] = decz[v]; }
         if (a.osd0 && conv)
             for (int v = tid; v < n; v += NT) { a.osd0[(int64_t)b * 2 * n + v] = decx[v]; a.osd0[(int64_t)b * 2 * n + n + v] = decz[v]; }
         if (!conv) exit_class = SWD_EXIT_NO_OSD;
     } else {
-        exit_class = SWD_EXIT_OSD;
+        exit_class = SWD_EXIT_OSD; // finished by bp4_osd_kernel from the posteriors stored above
+        if (tid == 0) a.osd_list[atomicAdd(a.osd_count, 1u)] = b;
+    }
+    if (tid == 0) {
+        int32_t *st = a.stats + (int64_t)b * SWD_STAT_WORDS;
+        st[0] = exit_class | (conv ? SWD_STATUS_CONVERGE : 0);
+        st[1] = iters; st[2] = iters; st[3] = 0; st[4] = n; st[5] = mx + mz; st[6] = gx.E + gz.E; st[7] = 0;
+    }
+    } // next unit
+}
+
+// The decodes the BP kernel queued (bp4_osd.pyx:212-219: osd('x') and osd('z') when BP did not converge), one per workgroup at a time:
+// ordering keys from the stored posteriors, elimination + higher-order sweep per basis (osd_run), the Z string from Hx and the X string
+// from Hz.  Same LDS layout as the BP kernel.
+template <int NT, int DM>
+__global__ void __launch_bounds__(NT) bp4_osd_kernel(const SwdBp4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SwdGraphDev &gx = a.gx, &gz = a.gz;
+    const int tid = threadIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
+    uint8_t *sxo = (uint8_t *)(smem + a.L.off_sxo), *szo = (uint8_t *)(smem + a.L.off_szo);
+    Lds s;
+    s.scratch = smem; s.msg = (double *)smem; s.hard = (uint8_t *)(smem + a.L.off_hard);
+    s.flags = (int *)(smem + a.L.off_misc); s.scal = s.flags + 32; s.dbl = (double *)(s.scal + 32); s.iaux = (int *)(s.dbl + 24);
+    s.ctid = s.vtid = threadIdx.x;
+    const int count = (int)*a.osd_count;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const int b = a.osd_list[q];
+        s.fpar = 0;
+        const uint8_t *sx_b = a.sx + (int64_t)b * mx, *sz_b = a.sz + (int64_t)b * mz;
+        const double *lpr_b = a.lpr + (int64_t)b * 3 * n;
+        uint8_t *out_b = a.out + (int64_t)b * 2 * n;
+        __syncthreads(); // the previous unit is done with LDS
+        for (int r = tid; r < mx; r += NT) sxo[r] = sx_b[r] ? 1 : 0;
+        for (int r = tid; r < mz; r += NT) szo[r] = sz_b[r] ? 1 : 0;
+        int rowadds = 0;
         SwdDecodeParams P{};
         P.osd_method = a.osd_method; P.osd_order = a.osd_order;
         long long t0, t1;
@@ -308,13 +375,8 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
             for (int v = tid; v < n; v += NT) dst[v] = s.hard[v];
             __syncthreads();
         }
+        if (tid == 0) a.stats[(int64_t)b * SWD_STAT_WORDS + 7] = rowadds;
     }
-    if (tid == 0) {
-        int32_t *st = a.stats + (int64_t)b * SWD_STAT_WORDS;
-        st[0] = exit_class | (conv ? SWD_STATUS_CONVERGE : 0);
-        st[1] = iters; st[2] = iters; st[3] = 0; st[4] = n; st[5] = mx + mz; st[6] = gx.E + gz.E; st[7] = rowadds;
-    }
-    } // next unit
 }
 
 // camel_decode's choice among the four runs of a shot: the converged run of smallest path metric, strict < keeps
