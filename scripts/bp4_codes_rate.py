@@ -9,7 +9,7 @@ from slidingwindowdecoder_amd.codes import bb_code
 from slidingwindowdecoder_amd import shyps
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cases = []
-for N in (72, 144, 288):
+for N in (72, 144, 288, 360, 756):
     c, _, _ = bb_code(N)
     cases.append((f"bb{N}", np.asarray(c.hx), np.asarray(c.hz), 0.02))
 hx, hz = shyps.shyps_stabilizers(3)

@@ -12,7 +12,7 @@ int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L); // swd_osdw.hi
 struct Bp4 {
     Graph gx, gz;
     swd_bp4_params p{};
-    int device = 0, nt = 256, dm = 4, n = 0;
+    int device = 0, nt = 256, nt_osd = 256, dm = 4, n = 0; // nt: threads of the BP kernel (a launch parameter), nt_osd: of the OSD kernel (its layouts)
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
     DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd, io, osd_q;
@@ -20,56 +20,58 @@ struct Bp4 {
     const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
 };
 
-template <int NT, int DM>
+template <int WMAX, int NTO, int DM>
 static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
     static int lds_limit[64] = {0};
     if (d->L.total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<NT, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
+        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<WMAX, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
         lds_limit[d->device & 63] = d->L.total;
     }
     // persistent grid: as many workgroups as the device holds at once, each walks its share of the units
-    static int slots[64] = {0}, slots_lds[64] = {0};
-    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total) {
+    static int slots[64] = {0}, slots_lds[64] = {0}, slots_nt[64] = {0};
+    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total || slots_nt[d->device & 63] != d->nt) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<NT, DM>, NT, (size_t)d->L.total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM>, d->nt, (size_t)d->L.total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         while (per_cu > 1 && (long long)per_cu * ((d->L.total + 1279) / 1280 * 1280) > 160 * 1024) --per_cu; // LDS is granted in granules of 1280 B (swd_plan.h)
         slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
-        slots_lds[d->device & 63] = d->L.total;
+        slots_lds[d->device & 63] = d->L.total; slots_nt[d->device & 63] = d->nt;
     }
     const int units = a.camel ? 4 * a.B : a.B;
     const bool with_osd = !a.camel && a.osd_order >= 0;
     if (with_osd) SWD_HIP(hipMemsetAsync(a.osd_count, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL((bp4_kernel<NT, DM>), dim3(std::min(units, slots[d->device & 63])), dim3(NT), d->L.total, st, a);
+    hipLaunchKernelGGL((bp4_kernel<WMAX, DM>), dim3(std::min(units, slots[d->device & 63])), dim3(d->nt), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
     if (with_osd) { // the queue of unconverged decodes (often empty: its workgroups then read the count and leave)
         static int lds_limit2[64] = {0}, slots2[64] = {0}, slots2_lds[64] = {0};
         if (d->L.total > lds_limit2[d->device & 63]) {
-            SWD_HIP(hipFuncSetAttribute((const void *)bp4_osd_kernel<NT, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
+            SWD_HIP(hipFuncSetAttribute((const void *)bp4_osd_kernel<NTO, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
             lds_limit2[d->device & 63] = d->L.total;
         }
         if (!slots2[d->device & 63] || slots2_lds[d->device & 63] != d->L.total) {
             int per_cu = 0, cus = 0;
-            SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_osd_kernel<NT, DM>, NT, (size_t)d->L.total));
+            SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_osd_kernel<NTO, DM>, NTO, (size_t)d->L.total));
             SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
             while (per_cu > 1 && (long long)per_cu * ((d->L.total + 1279) / 1280 * 1280) > 160 * 1024) --per_cu;
             slots2[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
             slots2_lds[d->device & 63] = d->L.total;
         }
-        hipLaunchKernelGGL((bp4_osd_kernel<NT, DM>), dim3(std::min(a.B, slots2[d->device & 63])), dim3(NT), d->L.total, st, a);
+        hipLaunchKernelGGL((bp4_osd_kernel<NTO, DM>), dim3(std::min(a.B, slots2[d->device & 63])), dim3(NTO), d->L.total, st, a);
         SWD_HIP(hipGetLastError());
     }
     return 0;
 }
 
+template <int WMAX, int NTO>
+static int bp4_dispatch_dm(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8>(d, a, st) : bp4_launch<WMAX, NTO, SWD_DMAX>(d, a, st));
+}
 static int bp4_dispatch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
-    // one thread per qubit where the code is small: a workgroup of ceil(n / 64) waves (the decodes of the notebooks' codes take one or
-    // two iterations -- what a launch costs is the number of waves it occupies)
-    if (d->nt == 64) return d->dm == 4 ? bp4_launch<64, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<64, 8>(d, a, st) : bp4_launch<64, SWD_DMAX>(d, a, st));
-    if (d->nt == 128) return bp4_launch<128, 4>(d, a, st);
-    if (d->nt == 192) return bp4_launch<192, 4>(d, a, st);
-    if (d->nt == 256) return d->dm == 4 ? bp4_launch<256, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<256, 8>(d, a, st) : bp4_launch<256, SWD_DMAX>(d, a, st));
-    return d->dm == 4 ? bp4_launch<1024, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<1024, 8>(d, a, st) : bp4_launch<1024, SWD_DMAX>(d, a, st));
+    // BP kernel: one thread per qubit while ceil(n / 64) waves fit a workgroup (the decodes of the notebooks' codes take a few
+    // iterations -- what a launch costs is the number of waves it occupies); OSD kernel: the workgroups its layouts were made for
+    if (d->nt <= 256) return bp4_dispatch_dm<4, 256>(d, a, st); // (n <= 3072: the OSD layouts are those of 256 threads)
+    if (d->nt <= 512) return bp4_dispatch_dm<8, 256>(d, a, st); // (still six waves per SIMD: three workgroups of up to eight waves per CU)
+    return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256>(d, a, st) : bp4_dispatch_dm<16, 1024>(d, a, st);
 }
 } // namespace swd
 
@@ -106,14 +108,13 @@ extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_des
     const int D = std::max(d->gx.D, d->gz.D);
     if (D > SWD_DMAX) { set_error("column weight %d exceeds this build's bound %d", D, SWD_DMAX); delete d; return nullptr; }
     d->dm = D <= 4 ? 4 : (D <= 8 ? 8 : SWD_DMAX); // SHYPS stabiliser matrices reach column weight 9
-    d->nt = n <= 3072 ? 256 : 1024;
-    if (n <= 64) d->nt = 64;
-    else if (n <= 192 && d->dm == 4) d->nt = (n + 63) / 64 * 64;
-    if (const char *e = getenv("SWD_BP4_NT")) { const int v = atoi(e); if ((v == 256 || v == 1024) && v >= d->nt) d->nt = v; } // (diagnostics: the wider workgroups)
+    d->nt_osd = n <= 3072 ? 256 : 1024;
+    d->nt = n <= 1024 ? std::max(64, (n + 63) / 64 * 64) : 1024;
+    if (const char *e = getenv("SWD_BP4_NT")) { const int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) d->nt = v; } // (diagnostics)
     if (d->gx.upload() || d->gz.upload()) { delete d; return nullptr; }
     d->gx.d.new_n = n; d->gz.d.new_n = n;
-    make_layout_for_osd(d->gx, d->nt, d->Lx);
-    make_layout_for_osd(d->gz, d->nt, d->Lz);
+    make_layout_for_osd(d->gx, d->nt_osd, d->Lx);
+    make_layout_for_osd(d->gz, d->nt_osd, d->Lz);
     auto al = [](int x, int a) { return (x + a - 1) / a * a; };
     const int msgx_b = al((d->gx.E + 1) * 8, 16), msgz_b = al((d->gz.E + 1) * 8, 16);
     int scratch = std::max(msgx_b + msgz_b, std::max(d->Lx.off_livemask, d->Lz.off_livemask));
@@ -289,7 +290,9 @@ extern "C" int swd_bp4_decode_batch(swd_bp4 *h, int32_t B, const uint8_t *sx, co
                                       (int32_t *)(ds + o_stats), (double *)(ds + o_lpr), (uint8_t *)(ds + o_osd0),
                                       (uint8_t *)(ds + o_bpd), st);
     if (rc) return rc;
-    SWD_HIP(hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, st));
+    // only what the caller asked for travels back (the posteriors are 24 n bytes per decode against 2 n of decisions)
+    const size_t o_end = bp_dec ? total : (osd0 ? o_bpd : (lpr ? o_osd0 : o_lpr));
+    SWD_HIP(hipMemcpyAsync(hs + o_out, ds + o_out, o_end - o_out, hipMemcpyDeviceToHost, st));
     SWD_HIP(hipStreamSynchronize(st));
     memcpy(out, hs + o_out, B * 2 * n);
     memcpy(stats, hs + o_stats, (size_t)B * SWD_STAT_WORDS * 4);

@@ -60,12 +60,21 @@ SWD_BP4_FN double bp4_logaddexp(double x, double y) {
     return tmp;
 }
 
+// block_any (swd_osdw_kernel.h) for a workgroup whose size is a launch parameter
+__device__ __forceinline__ bool bp4_block_any(bool p, Lds &s, int nwaves) {
+    const int par = (s.fpar++) & 1;
+    const unsigned long long b = __ballot(p);
+    if ((threadIdx.x & 63) == 0) s.flags[par * 16 + (threadIdx.x >> 6)] = (b != 0ull);
+    __syncthreads();
+    int r = 0;
+    for (int w = 0; w < nwaves; ++w) r |= s.flags[par * 16 + w];
+    return __builtin_amdgcn_readfirstlane(r) != 0;
+}
+
 // plain min-sum CN pass over one graph: lanes [lane0, lane0 + g.m) of the block own its checks
-template <int NT>
-__device__ __forceinline__ bool bp4_cn_pass(const SwdGraphDev &g, double *msg, const uint16_t *jptr, const int8_t *cn,
+__device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, double *msg, const uint16_t *jptr, const int8_t *cn,
                                             uint32_t *par, int lane0, int it, double alpha) {
     bool unsat = false;
-    const int nthreads = NT;
     for (int l = (int)threadIdx.x - lane0; l < g.m; l += nthreads) {
         if (l < 0) continue;
         const int cv = cn[l];
@@ -103,9 +112,13 @@ __device__ __forceinline__ bool bp4_cn_pass(const SwdGraphDev &g, double *msg, c
 #ifndef SWD_BP4_WAVES
 #define SWD_BP4_WAVES 6 // waves per SIMD the register allocation leaves room for (kernels of up to 256 threads): measured 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]]
 #endif
-template <int NT, int DM>
-__global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kernel(const SwdBp4Args a) {
+// WMAX: the most waves a workgroup of this instantiation is launched with (4 / 8: up to 256 / 512 threads, SWD_BP4_WAVES waves per SIMD;
+// 16: up to 1024 threads, 128 registers).  The workgroup size itself is a launch parameter: ceil(n / 64) waves while that is at most 16, so that every qubit has
+// a thread of its own and the node's edges / LLRs / bp_init messages stay in registers.
+template <int WMAX, int DM>
+__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NT = (int)blockDim.x;
     const SwdGraphDev &gx = a.gx, &gz = a.gz;
     const int tid = threadIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
     const int fixed = a.camel ? n - 1 : -1; // the decided qubit of a camel run
@@ -189,9 +202,9 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
     int conv = 0, iters = 0;
     const int lane0z = (mx + mz <= NT) ? mx : 0; // Hz checks on the lanes after the Hx ones when both fit
     for (int it = 0; it < a.max_iter; ++it) {
-        bool unsat = bp4_cn_pass<NT>(gx, msgx, jpx, cnx, parx, 0, it, a.alpha);
-        unsat |= bp4_cn_pass<NT>(gz, msgz, jpz, cnz, parz, lane0z, it, a.alpha);
-        const bool any = block_any<NT>(unsat, s);
+        bool unsat = bp4_cn_pass(NT, gx, msgx, jpx, cnx, parx, 0, it, a.alpha);
+        unsat |= bp4_cn_pass(NT, gz, msgz, jpz, cnz, parz, lane0z, it, a.alpha);
+        const bool any = bp4_block_any(unsat, s, NT >> 6);
         if (it > 0 && !any) { conv = 1; iters = it; break; }
         for (int v = tid; v < n; v += NT) { // vn_update (bp4_osd.pyx:533-589)
             if (v == fixed) { // decided (bp4_osd.pyx:456-458): its bit-to-check messages stay the priors of bp_init; the
@@ -281,7 +294,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? SWD_BP4_WAVES : 1)) bp4_kerne
             for (int l = tid; l < mx; l += NT) if (parx[l] != 0u) unsat = true;
             for (int l = tid; l < mz; l += NT) if (parz[l] != 0u) unsat = true;
         } else unsat = true;
-        const bool any = block_any<NT>(unsat, s);
+        const bool any = bp4_block_any(unsat, s, NT >> 6);
         iters = a.max_iter;
         conv = any ? 0 : 1;
     }

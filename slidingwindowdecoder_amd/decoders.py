@@ -369,7 +369,10 @@ class bp4_osd:
                 pass
             self._h = None
 
-    def decode_batch(self, synd_x, synd_z, return_llr=False):
+    def decode_batch(self, synd_x, synd_z, return_llr=False, details=True):
+        """[B, mx], [B, mz] -> uint8 [B, 2, n] (X string, Z string per decode).  ``details=False`` leaves the posteriors, the OSD-0
+        vectors and the BP decisions on the device (``last_llr`` / ``last_osd0`` / ``last_bp_decoding`` become None): 2 n + 32 bytes
+        come back per decode instead of 30 n."""
         sx, sz = np.asarray(synd_x), np.asarray(synd_z)
         if sx.ndim != 2 or sx.shape[1] != self.mx or sz.ndim != 2 or sz.shape[1] != self.mz or sx.shape[0] != sz.shape[0]:
             raise ValueError(f"syndromes must have shapes [B, {self.mx}] and [B, {self.mz}]")
@@ -378,11 +381,12 @@ class bp4_osd:
         B = sx.shape[0]
         out = np.zeros((B, 2, self.n), np.uint8)
         st = np.zeros((B, _lib.STAT_WORDS), np.int32)
-        lpr = np.zeros((B, 3, self.n))
-        osd0 = np.zeros((B, 2, self.n), np.uint8)
-        bpd = np.zeros((B, 2, self.n), np.uint8)
+        lpr = np.zeros((B, 3, self.n)) if details else None
+        osd0 = np.zeros((B, 2, self.n), np.uint8) if details else None
+        bpd = np.zeros((B, 2, self.n), np.uint8) if details else None
         rc = _lib.lib().swd_bp4_decode_batch(self._h, B, sx.ctypes.data, sz.ctypes.data, out.ctypes.data, st.ctypes.data,
-                                             lpr.ctypes.data, osd0.ctypes.data, bpd.ctypes.data)
+                                             lpr.ctypes.data if details else None, osd0.ctypes.data if details else None,
+                                             bpd.ctypes.data if details else None)
         if rc:
             raise RuntimeError(f"swd_bp4_decode_batch failed: {_lib.last_error()}")
         self.last_stats, self.last_status, self.last_iterations = st, st[:, 0].copy(), st[:, 1].copy()

@@ -99,7 +99,7 @@ def random_plan():
     return WindowPlan(chk, obs, priors, np.arange(num_col), anchors, wins, noisy_prior, h), (h, R, W, F)
 
 
-bad = done = 0
+bad = done = refused = 0
 while done < trials:
     r = random_plan()
     if r is None:
@@ -140,6 +140,9 @@ while done < trials:
     try:
         dev = SlidingWindowDecoder(plan, decoder="bpgdg_decoder" if decoder == "ens" else decoder, **kw)
     except (ValueError, RuntimeError) as ex:
+        if decoder != "osd_window" and "bytes of LDS" in str(ex):
+            refused += 1  # the guessing decoders have no large-graph form: a documented refusal, not a result
+            continue
         print(f"trial {done}: device rejected geo={geo} m<={mmax} n<={nmax}: {ex}")
         bad += 1
         continue
@@ -190,5 +193,5 @@ while done < trials:
                              kw=np.array(json.dumps(kw)))
                 tot[w.col0:w.col0 + w.commit] = e_o[:w.commit]
                 cur = ((det[j] + (sp.csr_matrix(tot[None, :]) @ chk_t).toarray()[0]) % 2).astype(np.uint8)
-print(f"{trials} trials, {bad} mismatching")
+print(f"{trials} trials, {bad} mismatching" + (f" ({refused} windows beyond one CU's LDS refused by the guessing decoder)" if refused else ""))
 sys.exit(1 if bad else 0)

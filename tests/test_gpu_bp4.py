@@ -36,6 +36,10 @@ def test_bp4_matches_reference(tag):
     dec = bp4_osd(c["code"].hx, c["code"].hz, channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"], **c["kw"])
     out = dec.decode_batch(c["sx"], c["sz"])
     assert _check_all_shots(dec, out, c, tag) == 1.0
+    # decisions only (the posteriors, OSD-0 vectors and BP decisions stay on the device): the same vectors and status words
+    st = dec.last_stats.copy()
+    out2 = dec.decode_batch(c["sx"], c["sz"], details=False)
+    assert np.array_equal(out2, out) and np.array_equal(dec.last_stats, st) and dec.last_llr is None and dec.last_osd0 is None
 
 
 @pytest.mark.parametrize("tag", SHYPS_TAGS)
