@@ -158,6 +158,20 @@ while done < trials:
     ok = np.array_equal(total, want) and np.array_equal((dev.last_stats[:, :, 0] & 0x100) != 0, conv)
     if decoder == "osd_window":
         ok = ok and np.array_equal(dev.last_stats[:, :, 1], its)
+    if ok and done % 3 == 0:  # every third trial: the packed transport and the two-lane stream must give what the one-shot decode gave
+        st0, pm0, fl0, fg0 = dev.last_stats.copy(), dev.last_min_pm.copy(), dev.last_obs_flips.copy(), dev.last_flagged.copy()
+        bits = dev.decode(det, packed=True)
+        ok = ok and np.array_equal(np.unpackbits(bits, axis=1, count=plan.chk.shape[1], bitorder="little"), total) and np.array_equal(dev.last_stats, st0)
+        cuts = sorted(set(int(x) for x in rng.integers(1, B, size=3)))
+        parts = [det[a:b] for a, b in zip([0] + cuts, cuts + [B])]
+        got = list(dev.decode_stream(parts, packed=bool(done % 2)))
+        tot_s = np.concatenate([np.unpackbits(g[0], axis=1, count=plan.chk.shape[1], bitorder="little") if done % 2 else g[0] for g in got])
+        ok = ok and np.array_equal(tot_s, total) and np.array_equal(np.concatenate([g[1] for g in got]), st0)
+        ok = ok and np.array_equal(np.concatenate([g[2] for g in got]), pm0, equal_nan=True)
+        ok = ok and np.array_equal(np.concatenate([g[3] for g in got]).astype(np.uint32), fl0) and np.array_equal(np.concatenate([g[4] for g in got]).astype(bool), fg0)
+        dev.last_stats, dev.last_min_pm, dev.last_obs_flips, dev.last_flagged = st0, pm0, fl0, fg0
+        if not ok:
+            print(f"trial {done}: packed / streamed decode differs from the one-shot decode")
     pred = (sp.csr_matrix(want) @ plan.obs.T.astype(np.int32)).toarray() % 2
     mask = (pred.astype(np.uint32) << np.arange(plan.obs.shape[0], dtype=np.uint32)).sum(axis=1).astype(np.uint32)
     resid = ((det + (sp.csr_matrix(want) @ plan.chk.T.astype(np.int32)).toarray()) % 2).any(axis=1)
