@@ -13,4 +13,5 @@ for ((i = 0; i < rounds; i++)); do
   for md in gd gdg bp; do timeout 600 python3 tests/fuzz_vs_oracle.py 40 $sd 6 300 $md 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400; done
   for d in osd_window bpgdg_decoder bpgd_decoder bp_history_decoder ens; do timeout 600 python3 tests/fuzz_pipeline.py 20 $sd $d 90 2>&1 | grep -v amdgpu | tail -3 | cut -c1-500; done
   timeout 600 python3 tests/fuzz_bp4.py 40 $sd 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400
+  timeout 900 python3 tests/fuzz_bp4.py 8 $sd 500 1500 2>&1 | grep -v amdgpu | tail -3 | cut -c1-400   # workgroups of 8 .. 16 waves, several qubits per thread beyond 1024
 done

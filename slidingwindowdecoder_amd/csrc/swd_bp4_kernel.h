@@ -110,7 +110,7 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 #define SWD_BP4_ROLLED 1 // the variable-node update's per-edge loops as loops (one helper body per basis; SHYPS r = 3 +10 %, the BB codes unchanged, half the compile time)
 #endif
 #ifndef SWD_BP4_WAVES
-#define SWD_BP4_WAVES 6 // waves per SIMD the register allocation leaves room for (kernels of up to 256 threads): measured 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]]
+#define SWD_BP4_WAVES 6 // waves per SIMD the register allocation leaves room for (kernels of up to 256 threads): measured 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]] when the switch was introduced; final kernel 4 / 5 / 6 / 8 -> 14.9 / 19.0 / 18.5 / 14.9 M, [[360]] 7.7 / 7.1 / 8.5 / 9.2 M, SHYPS r = 3 10.4 / 10.8 / 12.5 / 11.1 M
 #endif
 // WMAX: the most waves a workgroup of this instantiation is launched with (4 / 8: up to 256 / 512 threads, SWD_BP4_WAVES waves per SIMD;
 // 16: up to 1024 threads, 128 registers).  The workgroup size itself is a launch parameter: ceil(n / 64) waves while that is at most 16, so that every qubit has

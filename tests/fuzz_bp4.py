@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised bp4_osd device-vs-oracle comparison (run by hand or from the GPU suite):
-    python tests/fuzz_bp4.py [trials] [seed]
+    python tests/fuzz_bp4.py [trials] [seed] [min qubits] [max qubits]
 Random ragged Hx / Hz, X/Y/Z priors, iteration counts, scaling factors and OSD methods.  The device evaluates
 exp / log1p like glibc's FMA build (csrc/swd_libm.h); on a host whose libm selects that build (x86-64 with FMA,
 glibc >= 2.28) the oracle and the device must agree on EVERY shot and every posterior LLR bit for bit.  On any
@@ -25,6 +25,7 @@ def _host_fma():
 EXACT = _host_fma()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+NMIN, NMAX = (int(sys.argv[3]) if len(sys.argv) > 3 else 12), (int(sys.argv[4]) if len(sys.argv) > 4 else 400)  # qubits: the BP kernel runs on ceil(n / 64) waves up to 1024 threads
 
 
 def rand_h(m, n):
@@ -40,7 +41,7 @@ def rand_h(m, n):
 
 bad = done = 0
 while done < trials:
-    n = int(rng.integers(12, 400))
+    n = int(rng.integers(NMIN, NMAX))
     mx, mz = int(rng.integers(4, max(5, n // 2))), int(rng.integers(4, max(5, n // 2)))
     Hx, Hz = rand_h(mx, n), rand_h(mz, n)
     if max(Hx.sum(0).max(), Hz.sum(0).max()) > 8 or max(Hx.sum(1).max(), Hz.sum(1).max()) > 40 or (Hx.sum(0) == 0).any() or (Hz.sum(0) == 0).any():
