@@ -48,16 +48,20 @@ namespace swd {
 #else
 #define SWD_BP4_FN __device__ __forceinline__
 #endif
+// (bpgd.cpp:399-416.  Written without branches: the reference's two cases of each routine differ in the ARGUMENT of one and the same
+// evaluation, so a lane selects the argument, evaluates once and selects the result -- the same operations on the same values per
+// lane, and a wave whose lanes disagree about the case no longer walks both inlined copies of exp / log1p, four per logaddexp.)
 SWD_BP4_FN double bp4_log1pexp(double x) {
-    if (x > 36.04365338911715) return x + swd_log1p(swd_exp(-x)); // -log(DBL_EPSILON)
-    return swd_log1p(swd_exp(x));
+    const bool big = x > 36.04365338911715; // -log(DBL_EPSILON)
+    const double r = swd_log1p(swd_exp(big ? -x : x));
+    return big ? x + r : r;
 }
 SWD_BP4_FN double bp4_logaddexp(double x, double y) {
     const double tmp = x - y;
+    const bool gt = tmp > 0, le = tmp <= 0;
+    const double r = (gt ? x : y) + bp4_log1pexp(gt ? -tmp : tmp);
     if (x == y) return x + 0.693147180559945309417232121458176568;
-    if (tmp > 0) return x + bp4_log1pexp(-tmp);
-    else if (tmp <= 0) return y + bp4_log1pexp(tmp);
-    return tmp;
+    return (gt || le) ? r : tmp; // (NaN: neither case)
 }
 
 // block_any (swd_osdw_kernel.h) for a workgroup whose size is a launch parameter
