@@ -90,7 +90,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9   # same guide: max clock
 NUM_CU, SIMD_PER_CU = 256, 4
-PROFILE_TAGS = ("r04", "r03")  # newest first; find_profile falls back to the round-2 headline files
+PROFILE_TAGS = ("r05", "r04", "r03")  # newest first; find_profile falls back to the round-2 headline files
 STUB = os.environ.get("SWD_BENCH_STUB") == "1"  # launcher test on CPU: gloo + a stand-in decoder, never a measurement
 
 
@@ -197,10 +197,18 @@ def parse_args(argv=None):
                     help="skip the extra measurement at the other OSD order (N = 1): order 0 next to the default 10, or 10 next to 0")
     ap.add_argument("--distinct-batches", type=int, default=4, help="pre-sampled batches cycled over the steps")
     ap.add_argument("--no-stream", action="store_true", help="time one launch at a time instead of the two-lane streaming entry")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip config.other_workloads (N = 1, headline): a few launches each of bb288, gdg, gdg64, global144 and bp4 after the timed region")
     args = ap.parse_args(argv)
     if args.shots is None:
-        args.shots = 65536 if args.workload == "bp4" else 4096
+        args.shots = default_shots(args.workload)
     return args
+
+
+def default_shots(workload):
+    """shots (decodes) per GPU per step: BASELINE's batch of 4096 for the sliding-window workloads; 65536 decodes for bp4 (a launch that
+    fills the 256 CUs) and 2048 for the un-windowed model (one 1024-thread workgroup per decode, 2-8 ms each)"""
+    return {"bp4": 65536, "global144": 2048}.get(workload, 4096)
 
 
 def self_launch(args):
@@ -412,6 +420,18 @@ def find_profile(workload):
     return None, None, None, None
 
 
+def find_stream_profile(workload):
+    """The committed kernel trace of this command in its STREAMED step mode (scripts/profile_stream.sh ->
+    profiles/<tag>_<workload>_stream_summary.json): per-launch durations under overlap, the overlap fraction, the makespan per step."""
+    for tag in PROFILE_TAGS:
+        name = f"{tag}_{workload}_stream_summary.json"
+        j = load_profile(name)
+        if j:
+            keep = ("launches", "avg_kernel_ms_under_overlap", "makespan_ms_per_step", "overlap_fraction", "avg_concurrent_launches", "git")
+            return dict({k: j.get(k) for k in keep}, source="profiles/" + name)
+    return None
+
+
 def lds_algorithmic_bytes(plan, stats):
     """LDS bytes the BP iterations have to move: every live edge's message is read and written once by each of the
     two passes = 32 bytes per live edge and executed iteration (full graph in the pre phase, the shot's own live edges
@@ -426,7 +446,7 @@ def lds_algorithmic_bytes(plan, stats):
 LDS_MIX_PEAK_GBS = 79000.0  # what a half-read / half-write ds_*_b64 mix can move with every CU streaming (MI355X_MICROARCH.md, LDS: ~150 TB/s reads, 38-51 TB/s writes)
 
 
-def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducible):
+def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducible, step_s=None, step_mode=None):
     """Utilisation of the resources the kernel could be bound by.  Counters: the committed per-launch means of separate
     rocprofv3 --pmc passes of this same command (profiles/); time: the kernel time measured live with HIP events.
     `frac` is the largest of the capacity-bounded ones (each <= 1 by construction):
@@ -523,6 +543,19 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
                    "row adds + I/O) exceed what HBM could carry; frac = the highest capacity-bounded utilisation among the CU's LDS "
                    "pipeline, the vector ALUs priced by instruction width, and HBM (counters from profiles/, time measured here with "
                    "HIP events on single launches)")
+    if fr and step_s:
+        # The same counters priced at the STEP time of the timed region (this rank's shots per step): with the two-lane stream,
+        # consecutive launches overlap -- a launch's grid fills the workgroup slots the previous launch's tail leaves empty -- so a step
+        # takes less than one launch does alone (ms_per_step < avg_kernel_ms) and the device does one launch's work per step.
+        sc = avg_kernel_s / step_s
+        out["at_step_time"] = {"ms_per_step": step_s * 1e3, "avg_kernel_ms_single_launch": avg_kernel_s * 1e3, "step_mode": step_mode,
+                               "fractions": {k: v["frac"] * sc for k, v in fr.items()},
+                               "frac": max(v["frac"] for v in fr.values()) * sc,
+                               "note": "one launch's counters (profiles/, single launches) over the step time of the timed region; "
+                                       "`frac` above is priced at the single-launch kernel time that the committed kernel-trace describes"}
+        ss = find_stream_profile(workload)
+        if ss:
+            out["at_step_time"]["streamed_profile"] = ss
     if fr:
         bound = max(fr, key=lambda k: fr[k]["frac"])
         out.update({"bound": bound, "frac": fr[bound]["frac"]})
@@ -532,6 +565,45 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
             out.update({"achieved": fr[bound]["busy_ms_at_peak_clock"], "peak": avg_kernel_s * 1e3,
                         "unit": "ms busy at 2.4 GHz per launch (of the launch's duration)"})
     return out
+
+
+def measure_other_workload(workload, args, rank, local_rank, steps=5):
+    """One of the other workloads on this GPU after the headline's timed region: `steps` steps in the step mode `bench.py --workload
+    <w>` uses (after one warm-up step), then three single launches under HIP events -> a compact record for config.other_workloads."""
+    import copy
+    wl = WORKLOADS[workload]
+    a = copy.copy(args)
+    a.workload, a.shots, a.steps, a.warmup = workload, default_shots(workload), steps, 1
+    osdw = workload in ("bb288", "global144")
+    streaming = osdw and not args.no_stream
+    t_setup = time.perf_counter()
+    if workload == "bp4":
+        eng = Bp4Engine(a, rank, local_rank, 0, a.shots)
+    else:
+        plan = build_problem(**wl["problem"])
+        eng = GpuEngine(a, rank, local_rank, 0, a.shots, plan, args.osd_order, workload, streaming=streaming)
+    eng.step(0)
+    eng.sync()
+    t_setup = time.perf_counter() - t_setup
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.step(1 + i)
+    eng.finish()
+    eng.sync()
+    el = time.perf_counter() - t0
+    eng.check_status()
+    st = eng.stats.cpu().numpy()
+    ms, n, _ = eng.kernel_timing(1 + steps, 3)
+    eng.check_status()
+    avg_s = ms / max(n, 1) / 1e3
+    r = roofline(workload, "swd::bp4_kernel" if workload == "bp4" else "swd::pipeline_kernel", None, None, avg_s, None)
+    cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
+    return {"workload": workload, "metric": wl["metric"], "value": a.shots * eng.W * steps / el, "unit": wl.get("unit", "windows/s"),
+            "shots_per_step": a.shots, "steps": steps, "ms_per_step": el / steps * 1e3,
+            "step_mode": "two-lane stream" if streaming else "one launch at a time",
+            "ms_per_launch": avg_s * 1e3, "launches_timed": int(n), "exit_classes": [int(x) for x in cls[:7]],
+            "roofline_bound": r["bound"], "roofline_frac": r["frac"], "profile": (r.get("profile") or {}).get("counters"),
+            "profile_stale": r.get("profile_stale"), "setup_s": t_setup}
 
 
 def time_steps(engine, args, dist, world, total_shots):
@@ -608,6 +680,7 @@ def main():
 
     total_shots = args.shots * world if args.scaling == "weak" else args.total_shots
     lo, hi = shard_bounds(total_shots, rank, world)
+    per_rank = [b - a for a, b in (shard_bounds(total_shots, r, world) for r in range(world))]
     plan = None if (STUB or wl["problem"] is None) else build_problem(**wl["problem"])
     if STUB:
         engine = StubEngine(args, rank, lo, hi)
@@ -639,7 +712,8 @@ def main():
     if STUB:
         ok = np.array_equal(gathered.numpy(), StubEngine.expected(0, total_shots))
         line["config"] = {"workload": "launcher test", "world_size": world, "shots_total": total_shots,
-                          "shots_this_rank": hi - lo, "gather_ok": bool(ok), "collective_backend": backend, "collective_ranks": dist_ranks}
+                          "shots_this_rank": hi - lo, "shots_per_rank": per_rank, "gather_ok": bool(ok),
+                          "collective_backend": backend, "collective_ranks": dist_ranks}
         if rank == 0:
             print(json.dumps(line))
         if dist.is_initialized():
@@ -664,7 +738,7 @@ def main():
         "workload": (wl["desc"] % args.osd_order if "%d" in wl["desc"] else wl["desc"]) + ", "
                     + ("".join(f"DIAGNOSTIC RUN {k}={DECODER_KW[k]}, " for k in ("pre_max_iter", "post_max_iter") if os.environ.get("SWD_BENCH_" + k.upper())))
                     + (f"{args.shots} shots per GPU per step" if args.scaling == "weak" else f"{total_shots} shots per step split over the GPUs"),
-        "world_size": world, "shots_total": total_shots, "shots_rank0": hi - lo, "windows_per_shot": W,
+        "world_size": world, "shots_total": total_shots, "shots_rank0": hi - lo, "shots_per_rank": per_rank, "windows_per_shot": W,
         "parallelism": f"shots sharded over {world} GPU(s), no data-path collective; one all_gather of 8 B per shot",
         # what closed the timed region: the RCCL (backend nccl) all_gather over this many ranks, or nothing (plain one-process run)
         "collective_backend": backend, "collective_ranks": dist_ranks,
@@ -707,9 +781,18 @@ def main():
         cfg[f"osd_cs_order{side}_windows_per_s"] = total_shots * W * k2 / (time.perf_counter() - t0)  # (same step mode)
         e2.check_status()
 
+    if rank == 0 and world == 1 and headline and not args.no_other_workloads:
+        # the other five workloads, a few launches each, so that the driver's record carries every rate this repository claims
+        # (each has its own `bench.py --workload <w>` line and committed counter profile; here: value, ms per launch, staleness)
+        del engine
+        torch.cuda.empty_cache()
+        cfg["other_workloads"] = [measure_other_workload(w, args, rank, local_rank) for w in ("bb288", "gdg", "gdg64", "global144", "bp4")]
+
     if rank == 0:
         line["config"] = cfg
-        line["roofline"] = roofline(args.workload, kernel, alg_bytes, lds_alg, avg_kernel_s, irr)
+        # (per-GPU step time: under weak scaling every rank runs the same number of shots per step)
+        line["roofline"] = roofline(args.workload, kernel, alg_bytes, lds_alg, avg_kernel_s, irr, step_s=elapsed / args.steps,
+                                    step_mode=cfg["step_mode"])
         line["cpu_baseline"] = cpu
         print(json.dumps(line))
     if dist.is_initialized():

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SWD_ABI_VERSION 3
+#define SWD_ABI_VERSION 4
 
 /* exit class of one window decode, low byte of status[]; bit 8 = converge flag */
 enum {
@@ -274,11 +274,20 @@ int swd_pipeline_decode_packed(swd_pipeline *pl, int32_t B, const uint8_t *det, 
  * SWD_STREAM_PACKED; stats / min_pm / shot_result nullable), returns its B.  At most two batches in flight: a third push without a
  * pop fails.  A scheduling fault of the batch (see swd_pipeline_status) makes its pop fail.
  * Device form: push_dev launches on the next lane with the caller's device buffers (the caller keeps one set of output buffers
- * per lane, i.e. alternates between two); `after` (hipStream_t, nullable) = a stream whose work so far must precede the launch
- * (e.g. the producer of det).  wait(stream): `stream` waits for both lanes (device-side), or with NULL the host does. */
+ * per lane, i.e. alternates between two); `after` (hipStream_t) = a stream whose work so far must precede the launch: the
+ * producer of det and whoever still reads the lane's output buffers.  NULL means the legacy default stream, as everywhere in HIP
+ * (the lanes are non-blocking streams and do not synchronise with it by themselves); SWD_STREAM_NO_DEPENDENCY skips the wait
+ * (inputs and output buffers already synchronised by the caller).  wait(stream): `stream` waits for both lanes (device-side), or
+ * with NULL the host does.
+ * Lifetime: destroy the stream objects of a pipeline before the pipeline.  The other order is tolerated -- swd_pipeline_destroy
+ * drains and detaches the live stream objects, every later call on them fails with a message, swd_pipeline_stream_destroy still
+ * frees them -- but must not race with calls on those stream objects from other threads.
+ * A scheduling fault (see swd_pipeline_status) is reported by the pop of the batch it happened in: every launch has a fault word
+ * of its own next to the decoder's sticky one. */
 typedef struct swd_stream swd_stream;
 #define SWD_STREAM_PACKED 1
 #define SWD_STREAM_NO_STATS 2
+#define SWD_STREAM_NO_DEPENDENCY ((void *)(intptr_t)-1)
 swd_stream *swd_pipeline_stream_create(swd_pipeline *pl, int32_t max_shots, int32_t flags);
 void swd_pipeline_stream_destroy(swd_stream *s);
 int swd_pipeline_stream_push(swd_stream *s, int32_t B, const uint8_t *det);
@@ -291,8 +300,10 @@ int swd_pipeline_stream_wait(swd_stream *s, void *stream);
 /* Threading and streams: every entry point may be called from any host thread.  Launches of ONE decoder /
  * pipeline handle are serialised on the host while they are prepared; on the device, launches on different streams
  * run concurrently -- each launch takes its scheduling scratch from a ring of four launch slots, and a fifth launch
- * in flight makes its stream wait for the first (hipStreamWaitEvent).  Host-buffer entry points of one handle are
- * mutually exclusive for their whole duration (they share staging buffers). */
+ * in flight makes its stream wait for the first (hipStreamWaitEvent).  The same holds for swd_bp4 handles (the queue
+ * of unconverged decodes between the BP and the OSD kernel, the internal posterior buffer and the camel_decode
+ * scratch belong to the launch slot).  Host-buffer entry points of one handle are mutually exclusive for their
+ * whole duration (they share staging buffers). */
 
 /* diagnostics: device-side phase timers (100 MHz ticks) of the last launch, out [B*W*8]:
  * init, pre BP, sort, shorten+peel, post BP, OSD sort, OSD elimination, OSD sweep + epilogue */

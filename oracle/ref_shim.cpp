@@ -97,4 +97,29 @@ int ref_gdg_multi(void *Hv, int m, int new_n, int num_iter, int max_step, int ma
     return mt.num_tree_threads | (mt.num_side_threads << 16);
 }
 
+// The same, on ONE BPGD_main_thread object that the caller keeps across decodes -- what the reference's bpgdg_decoder does
+// (bp_guessing_decoder.pyx:238-251 calls do_work on the object built in __cinit__).  do_work resets min_pm but not min_pm_error
+// (bpgd.cpp:599), and returns early when BPGD::reset fails (:619-625): a re-used object then hands back its PREVIOUS decode's
+// vector, where a fresh object (ref_gdg_multi above, the oracle, the device) hands back zeros.  tests/test_oracle_vs_ref.py
+// measures exactly that difference.
+void *ref_gdg_multi_new(int m, int new_n, int num_iter, int max_step, int max_tree_depth, int max_side_depth, int max_tree_step,
+                        int max_side_step, int low_error_mode, double factor) {
+    return new BPGD_main_thread(m, new_n, num_iter, max_step, max_tree_depth, max_side_depth, max_tree_step, max_side_step, low_error_mode, factor);
+}
+void ref_gdg_multi_free(void *o) { delete (BPGD_main_thread *)o; }
+int ref_gdg_multi_decode(void *o, void *Hv, int m, int new_n, int32_t *cols, double *llr, const uint8_t *synd, uint8_t *min_pm_error,
+                         double *min_pm, double *pms) {
+    BPGD_main_thread &mt = *(BPGD_main_thread *)o;
+    char *s = (char *)malloc(m);
+    for (int i = 0; i < m; i++) s[i] = (char)synd[i];
+    mt.do_work((mod2sparse *)Hv, (int *)cols, llr, s);
+    free(s);
+    for (int v = 0; v < new_n; v++) min_pm_error[v] = (uint8_t)mt.min_pm_error[v];
+    *min_pm = mt.min_pm;
+    int k = 0;
+    for (auto &t : mt.bpgd_tree_vec) pms[k++] = t->min_pm;
+    for (auto &t : mt.bpgd_side_vec) pms[k++] = t->min_pm;
+    return mt.num_tree_threads | (mt.num_side_threads << 16);
+}
+
 }  // extern "C"

@@ -3,6 +3,7 @@
 
   config 3  [[144,12,12]] circuit-level p=0.003, (W,F)=(3,1), bpgdg_decoder windows (guessing.py:160-173)
   config 4  [[288,12,18]] circuit-level p=0.003, (W,F)=(4,1), osd_window windows
+  4gdg      [[288,12,18]] (4,1) windows with the reference's guessing-decoder shape D4 / S20 (`Sliding Window GDG.ipynb` cell 8)
   config 5  SHYPS r=3 circuit-level p=0.001, 12 rounds, (3,1), osd_window windows (stim-free DEM, shyps.py)
   bp4       [[144,12,12]] depolarizing code-capacity noise, bp4_osd (Misc.ipynb cell 2 setting)
   order10   configs[1] with the notebooks' default OSD-CS order 10
@@ -16,7 +17,7 @@ from slidingwindowdecoder_amd import SlidingWindowDecoder, bp4_osd
 from slidingwindowdecoder_amd.windows import sample_dem
 from slidingwindowdecoder_amd.codes import bb_code
 
-which = sys.argv[1:] or ["3", "3small", "3ens", "3mt", "4", "5", "5w12", "bp4", "bp4shyps", "order10"]
+which = sys.argv[1:] or ["3", "3small", "3ens", "3mt", "4", "4gdg", "5", "5w12", "bp4", "bp4shyps", "order10"]
 
 
 def run_pipeline(name, plan, shots, reps, **kw):
@@ -57,6 +58,15 @@ if "3mt" in which:   # the reference's threaded ensemble (multi_thread=True: mai
 if "4" in which:
     run_pipeline("configs[3]: [[288,12,18]] p=0.003 (4,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(N=288, W=4, F=1), 4096, 2,
                  **dict(bench.DECODER_KW, osd_order=0))
+if "4gdg" in which:  # the reference's [[288,12,18]] guessing-decoder run (`Sliding Window GDG.ipynb` cell 8 / cell 4: (4,1) windows, max_iter 16,
+    # max_step 60, D4 / S20, branch steps 40), single-thread gdg() and the 32-thread ensemble, at the notebook's p = 0.005 / 6 rounds and at p = 0.003 / 12 rounds
+    G288 = dict(decoder="bpgdg_decoder", max_iter=16, max_iter_per_step=6, max_step=60, max_tree_depth=4, max_side_depth=20,
+                max_tree_branch_step=40, max_side_branch_step=40)
+    for p288, rounds in ((0.005, 6), (0.003, 12)):
+        plan288 = bench.build_problem(N=288, p=p288, rounds=rounds, W=4, F=1)
+        run_pipeline(f"[[288,12,18]] p={p288} {rounds} rounds (4,1) bpgdg_decoder(max_iter=16, R=60, D=4, S=20, branch steps 40), gdg()", plan288, 2048, 2, **G288)
+        run_pipeline(f"[[288,12,18]] p={p288} {rounds} rounds (4,1) bpgdg_decoder(multi_thread=True, max_iter=16, R=60, D=4, S=20): 32 threads", plan288, 2048, 2,
+                     **dict(G288, multi_thread=True))
 if "5" in which:
     from slidingwindowdecoder_amd import shyps
     from slidingwindowdecoder_amd.windows import plan_windows

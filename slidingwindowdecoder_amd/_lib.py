@@ -96,6 +96,7 @@ SYMBOLS = [
 
 STAT_WORDS = 8
 STREAM_PACKED, STREAM_NO_STATS = 1, 2
+STREAM_NO_DEPENDENCY = C.c_void_p(-1).value  # include/swd.h: SWD_STREAM_NO_DEPENDENCY
 
 
 def _preload_torch_hip_runtime():

@@ -20,9 +20,9 @@ boxes, so this module derives the same model directly:
 Host-side, runs once per experiment.  The structural known answers of the reference's
 notebooks (shape 936 x 8784 for 12 rounds of the [[144,12,12]] code, column-weight
 histogram, window anchors, merged "noisy syndrome" prior 0.027499817877069083 at p=0.003)
-are asserted in tests/test_circuit.py.  Column order is this module's own (first
-appearance in circuit order); the decoder results depend on it only through stable-sort
-ties and parity is always checked on identical matrices.
+are asserted in tests/test_circuit.py.  Column order and the merging of a symptom's
+probabilities follow the reference's ``dem_to_check_matrices`` by default (``bb_dem``,
+``column_order="stim"``); "circuit" keeps this module's own order of rounds 1-4.
 """
 from __future__ import annotations
 
@@ -149,8 +149,7 @@ class DEM:
 
 def dem_from_ops(ops, segments=None) -> DEM:
     """``segments is None``: columns in circuit order of first appearance, equal symptoms merged with p <- p(1-q) + q(1-p)
-    (the order every z-basis fixture and measurement of this repository was made with; for the z-basis circuits nothing the
-    reference computes depends on the order inside a region of columns).
+    (bb_dem's "circuit" mode: the order the z-basis fixtures of rounds 1-4 were made with).
     ``segments`` (bb_memory_ops(..., return_segments=True)): the column order and priors of
     ``dem_to_check_matrices(circuit.detector_error_model())`` (/root/reference/src/build_circuit.py:251-299) -- Stim analyses
     the circuit backwards and flushes its mechanisms per unit (what precedes the REPEAT block, every iteration of it, what
@@ -287,22 +286,19 @@ def dem_from_ops(ops, segments=None) -> DEM:
     return DEM(chk, obs, priors)
 
 
-def bb_dem(code, A_list, B_list, p: float, num_repeat: int, z_basis: bool = True, column_order: str | None = None) -> DEM:
+def bb_dem(code, A_list, B_list, p: float, num_repeat: int, z_basis: bool = True, column_order: str = "stim") -> DEM:
     """(chk, obs, priors) of the BB memory experiment -- counterpart of
     ``dem_to_check_matrices(build_circuit(..., z_basis=z_basis).detector_error_model())``
-    (/root/reference/osd.py:35-37).  ``column_order``: "circuit" (first appearance in circuit order; default for z-basis, where
-    the reference's results do not depend on it) or "stim" (the reference's own order; default for x-basis, whose windows
-    are cut inside a column region -- dem_from_ops).
-    The two modes also MERGE a mechanism's probabilities differently: "stim" merges the faults of one unit of the circuit (what
-    precedes the REPEAT block, each iteration, what follows) by p(1-q) + q(1-p) and ADDS the merged probabilities of the same symptom
-    across units, which is what ``dem_to_check_matrices`` does (/root/reference/src/build_circuit.py:262-270); "circuit" merges every
-    fault of the whole circuit by p(1-q) + q(1-p).  A symptom emitted by two units therefore gets p + q in "stim" and
-    p + q - 2pq in "circuit": the z-basis priors of the two modes differ by O(p^2) (at most 4.1e-5 absolute for p = 0.003,
-    tests/test_circuit.py::test_z_basis_prior_merge_modes).  The recorded fixtures, the headline bench and the notebook known
-    answers reproduced in tests/test_circuit.py all use the z-basis default "circuit"; every parity claim is on the decoder given
-    the SAME priors as the reference (make_golden.py feeds these priors to the reference), not on the DEM construction."""
-    if column_order is None:
-        column_order = "circuit" if z_basis else "stim"
+    (/root/reference/osd.py:35-37).  ``column_order``:
+    "stim" (default, both bases): the reference's own column order and priors -- mechanisms flushed per unit of the circuit (what
+    precedes the REPEAT block, each iteration, what follows), sorted by symptom inside a unit, faults of one unit merged by
+    p(1-q) + q(1-p) and the merged probabilities of a symptom that several units emit ADDED, which is what
+    ``dem_to_check_matrices`` does (/root/reference/src/build_circuit.py:262-270).  The x-basis windows are cut inside a column
+    region (osd.py:83, 105), so there the order is part of the result; for z-basis it decides stable-sort ties only.
+    "circuit": columns in circuit order of first appearance and every fault of the whole circuit merged by p(1-q) + q(1-p) --
+    rounds 1-4 used this for z-basis (a symptom emitted by two units gets p + q - 2pq instead of the reference's p + q: 1 584 of
+    the 8 784 priors of the [[144,12,12]] experiment differ, by at most 4.1e-5; tests/test_circuit.py::test_z_basis_prior_merge_modes).
+    Since round 5 the default, every recorded fixture, the headline bench and the full-size tests use the reference's inputs."""
     if column_order == "circuit":
         return dem_from_ops(bb_memory_ops(code, A_list, B_list, p, num_repeat, z_basis))
     if column_order != "stim":

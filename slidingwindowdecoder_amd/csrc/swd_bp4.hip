@@ -3,6 +3,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "swd_host.h"
 #include "swd_bp4_kernel.h"
 
@@ -15,13 +17,37 @@ struct Bp4 {
     int device = 0, nt = 256, nt_osd = 256, dm = 4, n = 0; // nt: threads of the BP kernel (a launch parameter), nt_osd: of the OSD kernel (its layouts)
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
-    DevBuf llr, sx, sz, out, osd0, stats, lpr, cdec, cpm, cst, pm, bpd, io, osd_q;
+    DevBuf llr, sx, sz, out, osd0, stats, pm, bpd, io, lpr; // (sx .. lpr: staging of the host-buffer entry points)
     PinnedBuf stage;
     const double *d_llr_x = nullptr, *d_llr_y = nullptr, *d_llr_z = nullptr;
+    // What a launch writes and reads back besides the caller's arrays -- the queue of unconverged decodes between the BP and the OSD
+    // kernel, the posterior buffer when the caller passes none, the four runs of camel_decode -- comes from a ring of launch slots
+    // (as Plan::LaunchSlot does for the window decoders): launches of one handle on different streams never share it, and a launch
+    // that re-uses a slot first makes its stream wait for the slot's previous launch.
+    struct LaunchSlot {
+        DevBuf osd_q, lpr, cdec, cpm, cst;
+        hipEvent_t done = nullptr;
+    };
+    static constexpr int kSlots = 4;
+    LaunchSlot slot[kSlots];
+    int next_slot = 0;
+    std::mutex mu;
+    ~Bp4() { for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done); }
+    // the next slot, ordered behind its previous launch on `st` (call under mu)
+    int take_slot(hipStream_t st, LaunchSlot **out) {
+        LaunchSlot &sl = slot[next_slot];
+        next_slot = (next_slot + 1) % kSlots;
+        if (!sl.done) SWD_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        else SWD_HIP(hipStreamWaitEvent(st, sl.done, 0));
+        *out = &sl;
+        return 0;
+    }
 };
 
 template <int WMAX, int NTO, int DM>
 static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+    static std::mutex fn_mu; // the attributes and occupancy answers belong to the functions, not to a handle
+    std::lock_guard<std::mutex> fn_lock(fn_mu);
     static int lds_limit[64] = {0};
     if (d->L.total > lds_limit[d->device & 63]) {
         SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<WMAX, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
@@ -174,19 +200,24 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     if (B <= 0) return 0;
     if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(d->mu);
+    Bp4::LaunchSlot *sl = nullptr;
+    if (d->take_slot(st, &sl)) return -1;
     if (!lpr) {
-        if (d->lpr.reserve((size_t)B * 3 * d->n * 8)) return -1;
-        lpr = d->lpr.as<double>();
+        if (sl->lpr.reserve((size_t)B * 3 * d->n * 8)) return -1;
+        lpr = sl->lpr.as<double>();
     }
     SwdBp4Args a{};
     a.gx = d->gx.d; a.gz = d->gz.d; a.Lx = d->Lx; a.Lz = d->Lz; a.L = d->L;
     a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
     a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.bp_dec = bp_dec; a.stats = stats; a.lpr = lpr;
-    if (d->osd_q.reserve((size_t)B * 4 + 16)) return -1;
-    a.osd_count = d->osd_q.as<uint32_t>(); a.osd_list = d->osd_q.as<int32_t>() + 4;
-    hipStream_t st = (hipStream_t)stream;
-    return bp4_dispatch(d, a, st);
+    if (sl->osd_q.reserve((size_t)B * 4 + 16)) return -1;
+    a.osd_count = sl->osd_q.as<uint32_t>(); a.osd_list = sl->osd_q.as<int32_t>() + 4;
+    if (bp4_dispatch(d, a, st)) return -1;
+    SWD_HIP(hipEventRecord(sl->done, st));
+    return 0;
 }
 
 extern "C" int swd_bp4_camel_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx, const uint8_t *sz, uint8_t *out,
@@ -197,21 +228,25 @@ extern "C" int swd_bp4_camel_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8
     if (!sx || !sz || !out || !stats) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
     const size_t n = d->n;
-    if (d->lpr.reserve((size_t)4 * B * 3 * n * 8) || d->cdec.reserve((size_t)4 * B * 2 * n) || d->cpm.reserve((size_t)4 * B * 8) ||
-        d->cst.reserve((size_t)4 * B * 2 * 4))
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(d->mu);
+    Bp4::LaunchSlot *sl = nullptr;
+    if (d->take_slot(st, &sl)) return -1;
+    if (sl->lpr.reserve((size_t)4 * B * 3 * n * 8) || sl->cdec.reserve((size_t)4 * B * 2 * n) || sl->cpm.reserve((size_t)4 * B * 8) ||
+        sl->cst.reserve((size_t)4 * B * 2 * 4))
         return -1;
     SwdBp4Args a{};
     a.gx = d->gx.d; a.gz = d->gz.d; a.Lx = d->Lx; a.Lz = d->Lz; a.L = d->L;
     a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
-    a.B = B; a.sx = sx; a.sz = sz; a.out = nullptr; a.osd0 = nullptr; a.stats = nullptr; a.lpr = d->lpr.as<double>();
-    a.camel = 1; a.camel_dec = d->cdec.as<uint8_t>(); a.camel_pm = d->cpm.as<double>(); a.camel_st = d->cst.as<int32_t>();
-    hipStream_t st = (hipStream_t)stream;
+    a.B = B; a.sx = sx; a.sz = sz; a.out = nullptr; a.osd0 = nullptr; a.stats = nullptr; a.lpr = sl->lpr.as<double>();
+    a.camel = 1; a.camel_dec = sl->cdec.as<uint8_t>(); a.camel_pm = sl->cpm.as<double>(); a.camel_st = sl->cst.as<int32_t>();
     int rc;
     rc = bp4_dispatch(d, a, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bp4_camel_select, dim3(B), dim3(256), 0, st, (int)n, a.camel_dec, a.camel_pm, a.camel_st, out, stats, min_pm);
     SWD_HIP(hipGetLastError());
+    SWD_HIP(hipEventRecord(sl->done, st));
     return 0;
 }
 

@@ -120,14 +120,14 @@ __device__ __forceinline__ void ring_push(uint32_t *r, uint32_t mask, uint32_t p
 // milliseconds) and waits on ITS OWN ring slot until a producer fills it.  Every waiter is eventually served: the
 // workgroup that completes the launch's last unit pushes one SWD_ITEM_EXIT per workgroup.  A 20 s bound (100 MHz
 // ticks) turns a bug into SWD_ITEM_EXIT + a status flag instead of a hung device.
-__device__ __forceinline__ uint32_t ring_pop_wait(uint32_t *r, uint32_t mask, uint32_t *status) { // one thread
+__device__ __forceinline__ uint32_t ring_pop_wait(uint32_t *r, uint32_t mask, uint32_t *status, uint32_t *launch_fault) { // one thread
     const uint32_t h = atomicAdd(&r[0], 1u);
     unsigned long long *ring = (unsigned long long *)(r + 4);
     unsigned long long e;
     const long long t0 = wall_clock64();
     while ((uint32_t)((e = __hip_atomic_load(&ring[h & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != h + 1u) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 2000000000ll) { atomicOr(status, 2u); return 0xFFFFFFFFu; }
+        if (wall_clock64() - t0 > 2000000000ll) { atomicOr(status, 2u); atomicOr(launch_fault, 2u); return 0xFFFFFFFFu; }
     }
     return (uint32_t)e;
 }

@@ -199,10 +199,12 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     if (!sl.done) SWD_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     else SWD_HIP(hipStreamWaitEvent(st, sl.done, 0)); // the slot's previous launch (possibly on another stream) is done first
     a.state_stride = 16 + align_up(d->num_det, 16);
-    if (sl.sched.reserve((size_t)(a.B + 1) * 4) || sl.state.reserve((size_t)a.B * a.state_stride)) return -1;
+    // [ ticket counter | per-shot progress [B] | this LAUNCH's fault word ]: the kernel raises a scheduling fault in the decoder's
+    // sticky word (swd_pipeline_status) and in sched[B + 1], which belongs to this launch alone (the stream lanes read it)
+    if (sl.sched.reserve((size_t)(a.B + 2) * 4) || sl.state.reserve((size_t)a.B * a.state_stride)) return -1;
     a.sched = sl.sched.as<uint32_t>(); a.state = sl.state.as<uint8_t>();
     a.status = d->status.as<uint32_t>();
-    SWD_HIP(hipMemsetAsync(a.sched, 0, (size_t)(a.B + 1) * 4, st));
+    SWD_HIP(hipMemsetAsync(a.sched, 0, (size_t)(a.B + 2) * 4, st));
     if (d->timing) {
         if (!d->ev0) { SWD_HIP(hipEventCreate(&d->ev0)); SWD_HIP(hipEventCreate(&d->ev1)); }
         SWD_HIP(hipEventRecord(d->ev0, st));
@@ -585,7 +587,9 @@ static int stream_alloc_lane(HostStream *hs, StreamLane &l) {
     l.out_bytes = l.h_status + 256;
     l.o_stats = l.o_bits + l.h_stats; l.o_pm = l.o_bits + l.h_pm; l.o_shot = l.o_bits + l.h_shot; l.o_status = l.o_bits + l.h_status;
     l.dev_bytes = l.o_bits + l.out_bytes;
+    l.allocated = false;
     if (l.dev.reserve(l.dev_bytes) || l.hin.reserve(B * d->num_det) || l.hout.reserve(l.out_bytes)) return -1;
+    l.allocated = true;
     return 0;
 }
 
@@ -607,30 +611,42 @@ static HostStream *stream_new(Plan *d, int max_shots, int flags) {
     return hs;
 }
 
+// the plan a stream call works on; NULL (with a message) once the pipeline has been destroyed
+static Plan *stream_plan(HostStream *hs) {
+    if (!hs->plan) set_error("the pipeline of this stream object has been destroyed");
+    return hs->plan;
+}
+
 static int stream_push(HostStream *hs, int B, const uint8_t *det) {
-    Plan *d = hs->plan;
+    std::lock_guard<std::mutex> lk(hs->mu);
+    Plan *d = stream_plan(hs);
+    if (!d) return -1;
     if (B <= 0 || B > hs->max_shots) { set_error("stream push: %d shots, the stream was created for 1..%d", B, hs->max_shots); return -1; }
     if (!det) { set_error("null input pointer"); return -1; }
-    std::lock_guard<std::mutex> lk(hs->mu);
     StreamLane &l = hs->lane[hs->npush & 1];
     if (l.busy) { set_error("stream push: two batches are in flight, pop the oldest first"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
-    if (!l.dev.p && stream_alloc_lane(hs, l)) return -1;
+    if (!l.allocated && stream_alloc_lane(hs, l)) return -1;
     const size_t W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
     const bool stats = !(hs->flags & SWD_STREAM_NO_STATS);
     char *dv = (char *)l.dev.p;
     memcpy(l.hin.p, det, (size_t)B * d->num_det);
     SWD_HIP(hipMemcpyAsync(dv, l.hin.p, (size_t)B * d->num_det, hipMemcpyHostToDevice, l.st));
-    int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, (const uint8_t *)dv, 0, (uint8_t *)(dv + l.o_total), 0,
-                                     stats ? (int32_t *)(dv + l.o_stats) : nullptr, stats ? (double *)(dv + l.o_pm) : nullptr,
-                                     (int32_t *)(dv + l.o_shot), l.st);
-    if (rc) return rc;
+    const uint32_t *fault = nullptr; // this launch's own fault word (launch(): sched[B + 1] of its launch slot)
+    {
+        std::lock_guard<std::recursive_mutex> lkp(d->mu);
+        int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, (const uint8_t *)dv, 0, (uint8_t *)(dv + l.o_total), 0,
+                                         stats ? (int32_t *)(dv + l.o_stats) : nullptr, stats ? (double *)(dv + l.o_pm) : nullptr,
+                                         (int32_t *)(dv + l.o_shot), l.st);
+        if (rc) return rc;
+        fault = d->cur->sched.as<uint32_t>() + B + 1;
+    }
     const long long nb = (long long)B * (long long)row_bytes;
     hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, l.st, (const uint8_t *)(dv + l.o_total),
                        (int64_t)d->num_col, d->num_col, B, (uint8_t *)(dv + l.o_bits), (int)row_bytes);
     SWD_HIP(hipGetLastError());
-    // the decoder's fault word as this batch left it (read-and-clear happens at pop, on the host copy)
-    SWD_HIP(hipMemcpyAsync(dv + l.o_status, d->status.p, 4, hipMemcpyDeviceToDevice, l.st));
+    // the fault word of THIS launch (batches in flight on the other lane have their own)
+    SWD_HIP(hipMemcpyAsync(dv + l.o_status, fault, 4, hipMemcpyDeviceToDevice, l.st));
     // what travels back: only the used prefix of every array (four copies into the page-locked block)
     char *ho = (char *)l.hout.p;
     SWD_HIP(hipMemcpyAsync(ho, dv + l.o_bits, (size_t)nb, hipMemcpyDeviceToHost, l.st));
@@ -648,19 +664,20 @@ static int stream_push(HostStream *hs, int B, const uint8_t *det) {
 
 // packed_out: the caller's `total` takes the packed rows whatever the stream's flag says (swd_pipeline_decode_packed)
 static int stream_pop(HostStream *hs, uint8_t *total, int32_t *stats, double *min_pm, int32_t *shot_result, int packed_out) {
-    Plan *d = hs->plan;
     std::lock_guard<std::mutex> lk(hs->mu);
+    Plan *d = stream_plan(hs);
+    if (!d) return -1;
     StreamLane &l = hs->lane[hs->npop & 1];
     if (!l.busy) { set_error("stream pop: no batch in flight"); return -1; }
-    SWD_HIP(hipSetDevice(d->device));
-    SWD_HIP(hipEventSynchronize(l.done));
+    // the batch leaves the stream whatever happens below (a caller draining `pending` must terminate on a persistent device error)
     l.busy = false;
     hs->npop++;
+    SWD_HIP(hipSetDevice(d->device));
+    SWD_HIP(hipEventSynchronize(l.done));
     const size_t B = (size_t)l.B, W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
     const char *ho = (const char *)l.hout.p;
     const uint32_t err = *(const uint32_t *)(ho + l.h_status);
-    if (err) {
-        (void)hipMemsetAsync(d->status.p, 0, 4, l.st);
+    if (err) { // (the decoder's sticky word keeps the flag for swd_pipeline_status)
         set_error("internal: a window waited more than 10 s for its predecessor (scheduling fault, flags 0x%x)", err);
         return -1;
     }
@@ -736,13 +753,19 @@ extern "C" int swd_pipeline_decode_packed(swd_pipeline *h, int32_t B, const uint
 extern "C" swd_stream *swd_pipeline_stream_create(swd_pipeline *h, int32_t max_shots, int32_t flags) {
     Plan *d = (Plan *)h;
     if (!d) { set_error("null pipeline"); return nullptr; }
-    return (swd_stream *)stream_new(d, max_shots, flags);
+    HostStream *hs = stream_new(d, max_shots, flags);
+    if (hs) { std::lock_guard<std::recursive_mutex> lk(d->mu); d->streams.push_back(hs); }
+    return (swd_stream *)hs;
 }
 
 extern "C" void swd_pipeline_stream_destroy(swd_stream *s) {
     HostStream *hs = (HostStream *)s;
     if (!hs) return;
-    (void)hipSetDevice(hs->plan->device);
+    if (Plan *d = hs->plan) { // (a stream whose pipeline went first was detached by ~Plan and only frees its own lanes)
+        (void)hipSetDevice(d->device);
+        std::lock_guard<std::recursive_mutex> lk(d->mu);
+        d->streams.erase(std::remove(d->streams.begin(), d->streams.end(), hs), d->streams.end());
+    }
     delete hs;
 }
 
@@ -771,10 +794,14 @@ extern "C" int swd_pipeline_stream_push_dev(swd_stream *s, int32_t B, const uint
     if (!hs) { set_error("null stream"); return -1; }
     std::lock_guard<std::mutex> lk(hs->mu);
     if (hs->npush != hs->npop) { set_error("stream push_dev: host batches are in flight on this stream object"); return -1; }
-    Plan *d = hs->plan;
+    Plan *d = stream_plan(hs);
+    if (!d) return -1;
     SWD_HIP(hipSetDevice(d->device));
     StreamLane &l = hs->lane[hs->npush & 1];
-    if (after) { // the producer of the inputs (and whoever still reads the output buffers) comes first
+    // The producer of the inputs (and whoever still reads the lane's output buffers) comes first.  The lanes are non-blocking
+    // streams: they do not synchronise with the legacy default stream by themselves, so after == NULL -- what a framework hands
+    // over for "the default stream" -- is an event on that stream like any other; only the sentinel skips the wait.
+    if (after != SWD_STREAM_NO_DEPENDENCY) {
         SWD_HIP(hipEventRecord(l.ready, (hipStream_t)after));
         SWD_HIP(hipStreamWaitEvent(l.st, l.ready, 0));
     }
@@ -789,6 +816,7 @@ extern "C" int swd_pipeline_stream_wait(swd_stream *s, void *stream) {
     HostStream *hs = (HostStream *)s;
     if (!hs) { set_error("null stream"); return -1; }
     std::lock_guard<std::mutex> lk(hs->mu);
+    if (!stream_plan(hs)) return -1;
     SWD_HIP(hipSetDevice(hs->plan->device));
     for (auto &l : hs->lane) {
         if (stream) {

@@ -143,8 +143,8 @@ struct SwdPipeArgs {
     int32_t *shot_result;     // nullable [B][2]: predicted observable flips, residual syndrome != 0
     int64_t *prof;            // nullable [B][W][8]: 100 MHz ticks per phase (diagnostics only)
     // work-unit scheduling (one workgroup = one window of one shot, see pipeline_kernel)
-    uint32_t *sched;          // [1 + B]: ticket counter, then per shot the number of windows finished (zeroed per launch)
-    uint32_t *status;         // one word owned by the decoder, never reset by a launch: bit 0 = a window gave up waiting for its predecessor
+    uint32_t *sched;          // [2 + B]: ticket counter, then per shot the number of windows finished, then the fault word of THIS launch (all zeroed per launch)
+    uint32_t *status;         // one word owned by the decoder, never reset by a launch: bit 0 = a window gave up waiting for its predecessor (mirrored in sched[B + 1])
     uint8_t *state;           // [B][state_stride]: residual syndrome + accumulators handed to the next window
     int64_t state_stride;
     int32_t slot_scratch;     // hist / snap are private to the workgroup (indexed by blockIdx.x), not to the shot
@@ -2501,7 +2501,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                     const uint32_t nb = shots0 + atomicAdd(a.sched, 1u);
                     if (nb < (uint32_t)a.B) ring_push(a.gdgp.q, a.gdgp.qmask, item_unit(a.order ? (int)a.order[nb] : (int)nb, 0));
                 }
-                acc[2] = ring_pop_wait(a.gdgp.q, a.gdgp.qmask, a.status); acc[3] = 0u;
+                acc[2] = ring_pop_wait(a.gdgp.q, a.gdgp.qmask, a.status, &a.sched[a.B + 1]); acc[3] = 0u;
             }
             __syncthreads();
             item = acc[2];
@@ -2577,7 +2577,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 __builtin_amdgcn_s_sleep(8);
                 // cannot happen by construction (the awaited ticket is older and running); a bound keeps a bug
                 // from hanging the device: flag the launch and go on (wall_clock64 ticks at 100 MHz -> 10 s)
-                if (wall_clock64() - t_wait0 > 1000000000ll) { atomicOr(a.status, 1u); acc[3] = 1u; break; }
+                if (wall_clock64() - t_wait0 > 1000000000ll) { atomicOr(a.status, 1u); atomicOr(&a.sched[a.B + 1], 1u); acc[3] = 1u; break; } // (the decoder's sticky word and this launch's own)
             }
 #ifndef SWD_HANDOFF_NOFENCE
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -36,13 +36,14 @@ struct StreamLane {
     hipEvent_t done = nullptr, ready = nullptr;
     int B = 0;
     bool busy = false;       // a host batch is in flight on this lane (pushed, not popped)
+    bool allocated = false;  // dev / hin / hout all hold what stream_alloc_lane sized (set after the three reserves succeeded)
     DevBuf dev;              // [ det | total bytes | bits | stats | min_pm | shot_result | status copy ]
     PinnedBuf hin, hout;     // det in; [ bits | stats | min_pm | shot_result | status ] out
     size_t o_total = 0, o_bits = 0, o_stats = 0, o_pm = 0, o_shot = 0, o_status = 0, dev_bytes = 0; // offsets inside dev
     size_t h_stats = 0, h_pm = 0, h_shot = 0, h_status = 0, out_bytes = 0;                            // offsets inside hout
 };
 struct HostStream {
-    Plan *plan = nullptr;
+    Plan *plan = nullptr;    // nulled by ~Plan when the pipeline is destroyed first: every later call on the stream fails cleanly
     int max_shots = 0, flags = 0;
     StreamLane lane[2];
     long long npush = 0, npop = 0;
@@ -119,9 +120,17 @@ struct Plan {
     int64_t t_launches = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_ptr<HostStream> hstream; // the host-buffer entry point swd_pipeline_decode runs on its own two-lane stream object
+    std::vector<HostStream *> streams;   // live stream objects of the caller (swd_pipeline_stream_create), under mu
 
     ~Plan() {
         hstream.reset();
+        // stream objects that outlive their pipeline: drain their lanes (they read this plan's buffers) and detach them
+        for (HostStream *hs : streams) {
+            std::lock_guard<std::mutex> lk(hs->mu);
+            for (auto &l : hs->lane) { if (l.st) (void)hipStreamSynchronize(l.st); l.busy = false; }
+            hs->npop = hs->npush;
+            hs->plan = nullptr;
+        }
         if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
         for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
     }

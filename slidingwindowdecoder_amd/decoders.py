@@ -695,16 +695,21 @@ class SlidingWindowStream:
 
     def push_device(self, det, total, stats=None, min_pm=None, shot_result=None, after=None):
         """CUDA tensors as in ``SlidingWindowDecoder.decode_device``; ``after``: a torch stream whose work so far must precede
-        the launch (default: the current stream)."""
+        the launch -- the producer of ``det`` and the last reader of this lane's output tensors (default: the current stream,
+        also when that is PyTorch's default stream, whose handle is 0); ``after=False``: no dependency, the caller has
+        synchronised inputs and outputs itself."""
         import torch
         dec = self.dec
         if det.dtype != torch.uint8 or det.dim() != 2 or det.shape[1] != dec.num_det or det.stride(1) != 1 or not det.is_cuda:
             raise ValueError(f"det must be a uint8 CUDA tensor [B, {dec.num_det}] with unit column stride")
-        aft = torch.cuda.current_stream(det.device) if after is None else after
+        if after is False:
+            aft = _lib.STREAM_NO_DEPENDENCY
+        else:
+            aft = (torch.cuda.current_stream(det.device) if after is None else after).cuda_stream or None  # 0 -> NULL = the legacy default stream
         rc = _lib.lib().swd_pipeline_stream_push_dev(self._h, det.shape[0], det.data_ptr(), det.stride(0), total.data_ptr(), total.stride(0),
                                                      stats.data_ptr() if stats is not None else None,
                                                      min_pm.data_ptr() if min_pm is not None else None,
-                                                     shot_result.data_ptr() if shot_result is not None else None, aft.cuda_stream)
+                                                     shot_result.data_ptr() if shot_result is not None else None, aft)
         if rc:
             raise RuntimeError(f"swd_pipeline_stream_push_dev failed: {_lib.last_error()}")
 

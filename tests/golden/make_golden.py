@@ -290,6 +290,48 @@ def gen_bb288(ref, shots=24):
     save("bb288_circuit_p005_w4f1.npz", **arrs)
 
 
+def gen_bb288_gdg(ref, shots=48):
+    """The reference's [[288,12,18]] guessing-decoder run (`Sliding Window GDG.ipynb` cell 8 = guessing.py:160-197 with N = 288:
+    p = 0.005, 6 rounds, (W,F) = (4,1), max_iter = 16, max_step = 60, max_tree_depth = 4, max_side_depth = 20,
+    max_side_branch_step = max_tree_branch_step = 40 -> the 32-thread ensemble shape D4/S20) on the 576 x 4752 / 4896 windows, recorded
+    from the deterministic single-thread gdg() (`multi_thread=False`, the parity target), plus the notebooks' default shape D3/S10
+    on the same windows.  The matrices are those of bb288_circuit_p005_w4f1.npz (same generator, same seed for the shots)."""
+    from slidingwindowdecoder_amd.codes import bb_code
+    from slidingwindowdecoder_amd.circuit import bb_dem
+    from slidingwindowdecoder_amd.windows import plan_windows, sample_dem, sliding_window_decode_host
+    code, A, B = bb_code(288)
+    dem = bb_dem(code, A, B, 0.005, 6)
+    plan = plan_windows(dem.chk, dem.obs, dem.priors, 144, 4, 1, method=1)
+    det, obs, faults = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=288)
+    arrs = {"det": pack(det), "obs_data": pack(obs), "num_shots": np.int32(shots)}
+    arrs.update(graph_arrays(plan.chk, plan.priors, "chk_"))
+    arrs.update(graph_arrays(plan.obs, plan.priors, "obs_"))
+    arrs["anchors"] = np.array(plan.anchors, dtype=np.int32)
+    arrs["noisy_prior"] = np.float64(plan.noisy_prior)
+    for wi, w in enumerate(plan.windows):
+        arrs.update(graph_arrays(w.mat, w.prior, f"win{wi}_"))
+        arrs[f"win{wi}_meta"] = np.array([w.row0, w.row1, w.col0, w.ncols_global, w.commit, int(w.is_last)], dtype=np.int32)
+    base = dict(max_iter=16, max_iter_per_step=6, ms_scaling_factor=1.0, gdg_factor=1.0, multi_thread=False, low_error_mode=False)
+    sets = [("d4s20", dict(base, max_step=60, max_tree_depth=4, max_side_depth=20, max_tree_branch_step=40, max_side_branch_step=40)),
+            ("d3s10", dict(base, max_step=25, max_tree_depth=3, max_side_depth=10, max_tree_branch_step=10, max_side_branch_step=10))]
+    for tag, kw in sets:
+        arrs[tag + "_params"] = json.dumps(kw)
+        recs = []
+
+        def fac(w):
+            r = Recorder(ref.bpgdg_decoder(w.mat, channel_probs=w.prior, **kw), w.mat.shape[1], has_hist=False)
+            recs.append(r)
+            return r
+        t = time.time()
+        total, flagged = sliding_window_decode_host(plan, det, fac)
+        print(f"  bb288_gdg/{tag}: {time.time() - t:.1f}s flagged/window {flagged} converge "
+              f"{[int(np.sum(r.conv)) for r in recs]} of {shots}")
+        for wi, r in enumerate(recs):
+            arrs.update(r.arrays(f"{tag}_win{wi}_"))
+        arrs[f"{tag}_total"] = pack(total)
+    save("bb288_gdg_p005_w4f1.npz", **arrs)
+
+
 def gen_global144(ref, shots=288):
     """Row J: osd_window on the UN-windowed detector error model, as /root/reference/IBM.ipynb:119-135 configures it
     (`decode(..., shorten=True)`: pre_max_iter=16, post_max_iter=1000, new_n=None -> 2 x 936 columns kept, osd_cs order 10) on the
@@ -470,13 +512,15 @@ def gen_bp4_shyps(ref):
 def main():
     ensure_reference()
     import src as ref
-    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "kat288", "bp4", "camel", "bp4_shyps", "global144"]
+    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "bb288_gdg", "kat288", "bp4", "camel", "bp4_shyps", "global144"]
     if "bb72" in which:
         gen_bb72(ref)
     if "bb144" in which:
         gen_bb144(ref)
     if "bb288" in which:
         gen_bb288(ref)
+    if "bb288_gdg" in which:
+        gen_bb288_gdg(ref)
     if "kat288" in which:
         gen_kat288(ref)
     if "global144" in which:

@@ -12,6 +12,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    """a rendezvous port nobody listens on (concurrent test runs must not collide on a hard-coded one)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def run_bench(*argv, env_extra=None, timeout=300):
     env = dict(os.environ, SWD_BENCH_STUB="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -39,6 +47,39 @@ def test_self_launch_strong_scaling_uneven_shards():
     j = lines[0]
     assert j["n_gpus"] == 2 and j["scaling"] == "strong"
     assert j["config"]["shots_total"] == 101 and j["config"]["shots_this_rank"] == 51 and j["config"]["gather_ok"]
+
+
+def test_self_launch_eight_ranks_weak_and_strong():
+    """the shape of the driver's 8-GPU run (stub decoder, gloo): eight ranks started by bench.py itself, weak scaling with 4096-shot
+    semantics scaled down, and strong scaling with shards that do not divide evenly; the line describes the collective itself"""
+    r, lines = run_bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--shots", "16", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    j = lines[0]
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and c["world_size"] == 8 and c["shots_total"] == 128 and c["gather_ok"]
+    assert c["collective_backend"] == "gloo" and c["collective_ranks"] == 8
+    assert c["shots_per_rank"] == [16] * 8
+    r, lines = run_bench("--gpus", "8", "--steps", "2", "--warmup", "0", "--scaling", "strong", "--total-shots", "203", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = lines[0]
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and c["shots_total"] == 203 and c["gather_ok"]
+    assert sum(c["shots_per_rank"]) == 203 and max(c["shots_per_rank"]) - min(c["shots_per_rank"]) <= 1
+    assert c["shots_this_rank"] == c["shots_per_rank"][0]
+
+
+def test_torchrun_launch_two_ranks():
+    """the driver's own launch line for N > 1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N (stub, gloo)"""
+    env = dict(os.environ, SWD_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--shots", "21"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["config"]["collective_ranks"] == 2 and lines[0]["config"]["gather_ok"]
 
 
 def test_single_process_default():
@@ -88,7 +129,7 @@ def test_roofline_is_a_bounded_utilisation():
 def test_one_rank_job_still_runs_the_collective():
     """started by torch.distributed.run with one rank, the bench initialises the process group and closes the timed
     region with the all_gather (gloo here; RCCL on the GPU box: tests/test_gpu_rccl.py)"""
-    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29611"}
+    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": free_port()}
     r, lines = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--shots", "23", env_extra=env)
     assert r.returncode == 0, r.stderr[-2000:]
     c = lines[0]["config"]

@@ -26,7 +26,7 @@ def test_header_symbols_are_bound_and_exported():
     for nme in names:
         assert hasattr(L, nme), f"{nme} declared in include/swd.h but not exported"
         assert nme in bound, f"{nme} has no ctypes prototype in _lib.SYMBOLS"
-    assert L.swd_abi_version() == 3
+    assert L.swd_abi_version() == 4
 
 
 def test_no_cpu_fallback():

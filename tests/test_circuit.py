@@ -133,7 +133,7 @@ def test_x_basis_experiment_known_answer():
     """`Sliding Window OSD.ipynb` (x-basis run: N = 144, p = 0.004, 12 rounds, (W,F) = (5,2), method 1, z_basis=False) prints
     "prior for noisy syndrome 0.05900506726184526".  The x-basis windows are cut `c[1] + n` columns into a region
     (/root/reference/osd.py:83, 105), so the value depends on Stim's column order inside a region; the general two-sensitivity
-    sweep + the reference's column order (bb_dem(..., z_basis=False), default column_order="stim") reproduce it to the last digit."""
+    sweep + the reference's column order (bb_dem's default, column_order="stim") reproduce it to the last digit."""
     code, A, B = bb_code(144)
     dem = bb_dem(code, A, B, 0.004, 12, z_basis=False)
     assert dem.chk.shape == (936, 8784) and dem.obs.shape == (12, 8784)
@@ -144,30 +144,34 @@ def test_x_basis_experiment_known_answer():
     assert not ((code.hz.astype(int) @ code.lx.T) % 2).any()
 
 
-def test_reference_column_order_reproduces_the_z_basis_known_answers_too():
-    """column_order="stim" for the z-basis circuit: same shape and weights, the three notebook priors to the last digit; the
-    priors of the few mechanisms that several loop iterations emit are SUMS there (build_circuit.py:262-270), i.e. up to 4e-5
-    above the XOR-merged values of the default order."""
+def test_default_is_the_reference_column_order_and_prior_merge():
+    """bb_dem's default (both bases) is the reference's dem_to_check_matrices order and its SUMMED priors across circuit units
+    (column_order="stim", build_circuit.py:251-299): the three notebook priors come out of the DEFAULT to the last digit
+    (test_noisy_syndrome_prior_known_answers) and the committed fixtures hold exactly these priors (test_dem_matches_committed_fixture).
+    "circuit" (this module's own order of rounds 1-4) stays available: the same mechanisms in another order."""
     code, A, B = bb_code(144)
-    for p, expect in ((0.003, 0.027499817877069083),):
-        d = bb_dem(code, A, B, p, 12, column_order="stim")
-        assert d.chk.shape == (936, 8784)
-        plan = plan_windows(d.chk, d.obs, d.priors, 72, 3, 1, method=1)
-        assert plan.noisy_prior == expect
-        c = bb_dem(code, A, B, p, 12)
-        key = lambda m: sorted(tuple(m.indices[m.indptr[j]:m.indptr[j + 1]]) for j in range(m.shape[1]))
-        assert key(sp.csc_matrix(d.chk)) == key(sp.csc_matrix(c.chk))  # the same mechanisms, another order
-        assert 0.0 <= np.sort(d.priors)[-1] - np.sort(c.priors)[-1] < 1e-4
+    p, expect = 0.003, 0.027499817877069083
+    d = bb_dem(code, A, B, p, 12)
+    s = bb_dem(code, A, B, p, 12, column_order="stim")
+    assert (sp.csc_matrix(d.chk) != sp.csc_matrix(s.chk)).nnz == 0 and np.array_equal(d.priors, s.priors)
+    plan = plan_windows(d.chk, d.obs, d.priors, 72, 3, 1, method=1)
+    assert plan.noisy_prior == expect
+    c = bb_dem(code, A, B, p, 12, column_order="circuit")
+    assert c.chk.shape == (936, 8784)
+    key = lambda m: sorted(tuple(m.indices[m.indptr[j]:m.indptr[j + 1]]) for j in range(m.shape[1]))
+    assert key(sp.csc_matrix(d.chk)) == key(sp.csc_matrix(c.chk))  # the same mechanisms, another order
+    assert 0.0 <= np.sort(d.priors)[-1] - np.sort(c.priors)[-1] < 1e-4
+    with pytest.raises(ValueError):
+        bb_dem(code, A, B, p, 12, column_order="other")
 
 
 def test_z_basis_prior_merge_modes():
-    """The z-basis default ("circuit") XOR-merges a mechanism's probabilities over the whole circuit, the reference's
-    dem_to_check_matrices ADDS them across the units of the circuit ("stim" mode, build_circuit.py:262-270).  Mechanism by
-    mechanism (matched by symptom): the summed prior is never smaller, the gap is O(p^2) -- measured here so that the deviation of
-    the default's priors from the reference's is a number, not a remark."""
+    """"circuit" XOR-merges a mechanism's probabilities over the whole circuit, the reference's dem_to_check_matrices ADDS them
+    across the units of the circuit (the default "stim" mode, build_circuit.py:262-270).  Mechanism by mechanism (matched by
+    symptom): the summed prior is never smaller, the gap is O(p^2) -- what rounds 1-4's fixtures and bench inputs deviated by."""
     code, A, B = bb_code(144)
     p = 0.003
-    d, c = bb_dem(code, A, B, p, 12, column_order="stim"), bb_dem(code, A, B, p, 12)
+    d, c = bb_dem(code, A, B, p, 12), bb_dem(code, A, B, p, 12, column_order="circuit")
 
     def by_symptom(dem):
         chk, obs = sp.csc_matrix(dem.chk), sp.csc_matrix(dem.obs)

@@ -115,3 +115,40 @@ def test_bp4_camel_decode_matches_reference(tag):
     one = dec.camel_decode(c["sx"][k], c["sz"][k])
     assert one.dtype == np.int64 and (one == c["out"][k]).all() and dec.converge == 1 and dec.min_pm == dec.last_min_pm[0]
     assert (np.stack([dec.osd0_decoding_x, dec.osd0_decoding_z]) == one).all()
+
+
+def test_bp4_concurrent_launches_of_one_handle_on_two_streams():
+    """Round-4 advisor finding: the queue of unconverged decodes between the BP and the OSD kernel was one buffer per handle, so
+    two launches of one handle on different streams raced for it (decodes dropped or solved against the other batch's pointers).
+    The queue, the internal posterior buffer and the camel scratch now belong to a launch slot.  Many launches with a large
+    share of OSD exits, alternating between two streams, must each equal the single-launch result."""
+    import torch
+    from slidingwindowdecoder_amd import bp4_osd
+    c = load_case(TAGS[0])
+    rng = np.random.default_rng(11)
+    dec = bp4_osd(c["code"].hx, c["code"].hz, channel_probs_x=c["pr"], channel_probs_y=c["pr"], channel_probs_z=c["pr"], **c["kw"])
+    # random (mostly unconverging) syndromes next to the recorded ones: the OSD queue is busy in every launch
+    B = 2048
+    sxs, szs, wants = [], [], []
+    for k in range(2):
+        sx = (rng.random((B, dec.mx)) < (0.02 + 0.03 * k)).astype(np.uint8)
+        sz = (rng.random((B, dec.mz)) < (0.02 + 0.03 * k)).astype(np.uint8)
+        sx[: len(c["sx"])] = c["sx"][: B]
+        sz[: len(c["sz"])] = c["sz"][: B]
+        out = dec.decode_batch(sx, sz, details=False)
+        assert (np.bincount(dec.last_status & 0xFF, minlength=3)[2]) > B // 8
+        sxs.append(sx); szs.append(sz); wants.append((out.copy(), dec.last_stats.copy()))
+    dev = torch.device("cuda", 0)
+    t_sx = [torch.from_numpy(x).to(dev) for x in sxs]
+    t_sz = [torch.from_numpy(x).to(dev) for x in szs]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+    res = []
+    for i in range(12):  # more launches in flight than launch slots
+        k = i & 1
+        with torch.cuda.stream(streams[k]):
+            res.append((k, dec.decode_batch_device(t_sx[k], t_sz[k], stream=streams[k])))
+    torch.cuda.synchronize()
+    for i, (k, (out, st)) in enumerate(res):
+        assert np.array_equal(out.cpu().numpy(), wants[k][0]), f"launch {i} (stream {k}): vectors differ from the single launch"
+        assert np.array_equal(st.cpu().numpy(), wants[k][1]), f"launch {i} (stream {k}): status words differ"

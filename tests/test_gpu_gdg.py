@@ -104,6 +104,81 @@ def test_gdg_pipeline_more_shots_than_workgroups():
         assert bad.size == 0, f"serial={serial}: {bad.size} shots differ: {bad[:8]}"
 
 
+@pytest.mark.parametrize("tag", ["d4s20", "d3s10"])
+def test_bb288_gdg_windows_and_pipeline(tag):
+    """The reference's [[288,12,18]] guessing-decoder run (`Sliding Window GDG.ipynb` cell 8, guessing.py:160-197 with N = 288:
+    (W,F) = (4,1) windows of 576 x 4752 / 4896, max_iter 16, max_step 60, D4 / S20, branch steps 40; and the default D3 / S10 on
+    the same windows), recorded from the reference's single-thread gdg(): every window decode (vector, converge flag) and the whole
+    window loop, in the parallel form (side branches as work items) and in the serial tree walk."""
+    import os
+    import slidingwindowdecoder_amd as S
+    from tests.test_gpu_pipeline import load_plan
+    f = fx.load("bb288_gdg_p005_w4f1.npz")
+    kw = fx.params(f, tag + "_params")
+    kw.pop("multi_thread")
+    post = 0
+    for wi in range(4):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        dec = S.bpgdg_decoder(mat, channel_probs=priors, **kw)
+        tr = fx.Trace(f, f"{tag}_win{wi}_", *mat.shape)
+        out = dec.decode_batch(tr.synd)
+        bad = np.flatnonzero((out != tr.out).any(axis=1))
+        assert bad.size == 0, f"window {wi}: {bad.size} vectors differ, first {bad[:8]}"
+        assert np.array_equal((dec.last_status & 0x100) != 0, tr.converge != 0)
+        post += int(((dec.last_status & 0xFF) == 1).sum())
+    assert post > 60  # the decimation search really ran
+    plan = load_plan(f, 4)
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    want = fx.unpack(f[tag + "_total"], plan.chk.shape[1])
+    for serial in (False, True):
+        if serial:
+            os.environ["SWD_GDG_SERIAL"] = "1"
+        try:
+            pl = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", **kw)
+        finally:
+            os.environ.pop("SWD_GDG_SERIAL", None)
+        assert pl.threads == 1024
+        total = pl.decode(det)
+        bad = np.flatnonzero((total != want).any(axis=1))
+        assert bad.size == 0, f"serial={serial}: {bad.size} shots differ: {bad[:8]}"
+        pl.check_status()
+
+
+def test_threaded_ensemble_bb288_windows_vs_oracle():
+    """bpgdg_decoder(multi_thread=True) with the reference's [[288,12,18]] shape D4 / S20 (32 threads, the notebook's own call) on
+    the (4,1) windows: device against the oracle's ensemble (pinned to the reference's real threads on these windows in
+    tests/test_oracle_vs_ref.py::test_threaded_ensemble_bb288_window_d4s20) on every shot, single windows and the window loop."""
+    import slidingwindowdecoder_amd as S
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd.windows import sliding_window_decode_host
+    from tests.test_gpu_pipeline import load_plan
+    f = fx.load("bb288_gdg_p005_w4f1.npz")
+    kw = fx.params(f, "d4s20_params")
+    kw.pop("multi_thread")
+    for wi in (1, 3):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        tr = fx.Trace(f, f"d4s20_win{wi}_", *mat.shape)
+        post, ties = _ensemble_vs_oracle(mat, priors, kw, tr.synd[:32], 10)
+        print(f"bb288 window {wi}: {post} ensembles, {ties} with a tied different vector")
+    plan = load_plan(f, 4)
+    det = fx.unpack(f["det"], plan.chk.shape[0])[:24]
+
+    class Fresh:
+        def __init__(self, w):
+            self.w = w
+
+        def decode(self, s):
+            self.d = O.bpgdg_decoder(self.w.mat, channel_probs=self.w.prior, multi_thread=True, **kw)
+            return self.d.decode(s)
+
+    want, _ = sliding_window_decode_host(plan, det, Fresh)
+    pl = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", multi_thread=True, **kw)
+    total = pl.decode(det)
+    bad = np.flatnonzero((total != want).any(axis=1))
+    assert bad.size == 0, f"{bad.size} shots differ from the oracle host loop: {bad[:8]}"
+    pl.check_status()
+
+
 def test_bb288_weight_two_kat():
     """Syndrome code.ipynb cell 6 (see tests/test_kat_syndrome_code.py): the device follows the
     deterministic single-thread search and reproduces its 22 converging syndromes vector for vector."""

@@ -238,3 +238,50 @@ def test_packed_output_and_streaming_equal_the_one_shot_decode():
     s.wait(torch.cuda.current_stream(dev))
     dec.check_status()
     s.close()
+
+
+def test_push_device_orders_behind_the_default_stream_and_survives_destroy_order():
+    """Round-4 advisor findings on the streaming form: (1) the lanes are non-blocking streams, and PyTorch's default stream has
+    handle 0 -- `after` = NULL must still order the launch behind the producer of det on that stream (a long sleep kernel followed
+    by the copy that fills det) and behind the last reader of the lane's outputs; (2) a pipeline destroyed before its stream object
+    leaves a stream whose calls fail cleanly instead of touching freed memory."""
+    import torch
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "osd10_params")
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    want = fx.unpack(f["osd10_total"], plan.chk.shape[1])
+    ncol = plan.chk.shape[1]
+    dec = SlidingWindowDecoder(plan, **kw)
+    dev = torch.device("cuda", 0)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0  # the case the finding is about
+    src = torch.from_numpy(det).to(dev)
+    d_t = torch.zeros_like(src)
+    outs = [dict(total=torch.empty((len(det), ncol), dtype=torch.uint8, device=dev),
+                 shot_result=torch.empty((len(det), 2), dtype=torch.int32, device=dev)) for _ in range(2)]
+    s = dec.stream(len(det))
+    torch.cuda.synchronize()
+    for i in range(4):
+        d_t.zero_()
+        torch.cuda._sleep(200_000_000)       # ~0.1 s of default-stream work in front of the producer
+        d_t.copy_(src)                       # det is only valid once this has run
+        s.push_device(d_t, **outs[i % 2])    # after=None -> the current (= default) stream
+        s.wait(torch.cuda.current_stream(dev))
+        assert np.array_equal(outs[i % 2]["total"].cpu().numpy(), want), f"push {i}: the launch did not wait for its input"
+    # explicit opt-out still works when the caller has synchronised
+    torch.cuda.synchronize()
+    s.push_device(d_t, after=False, **outs[0])
+    s.wait()
+    assert np.array_equal(outs[0]["total"].cpu().numpy(), want)
+    dec.check_status()
+    # destroy order: the pipeline first, then calls on the orphaned stream fail with a message, then the stream is freed
+    h = dec._h
+    dec._h = None
+    from slidingwindowdecoder_amd import _lib
+    _lib.lib().swd_pipeline_destroy(h)
+    with pytest.raises(RuntimeError, match="destroyed"):
+        s.push_device(d_t, **outs[0])
+    with pytest.raises(RuntimeError, match="destroyed"):
+        s.push(det)
+    s.close()

@@ -58,6 +58,9 @@ def test_gather_decisions_on_a_cuda_tensor_in_a_one_rank_rccl_group():
         "g = gather_decisions(t, 7)\n"
         "assert g.is_cuda and torch.equal(g, t)\n"
         "dist.barrier(); dist.destroy_process_group(); print('ok')\n")
-    env = dict(_env(), MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", PYTHONPATH=ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(_env(), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]

@@ -90,6 +90,21 @@ def test_bb144_gdg_trace():
         replay(dec, fx.Trace(f, f"gdg_win{wi}_", *mat.shape))
 
 
+@pytest.mark.parametrize("tag", ["d4s20", "d3s10"])
+def test_bb288_gdg_trace(tag):
+    """The reference's [[288,12,18]] guessing-decoder run (`Sliding Window GDG.ipynb` cell 8 / guessing.py:160-197 with N = 288:
+    (W,F) = (4,1), 576 x 4752 / 4896 windows, max_iter 16, max_step 60, D4 / S20, branch steps 40) and the default shape D3 / S10 on
+    the same windows, recorded from the reference's deterministic single-thread gdg()."""
+    f = fx.load("bb288_gdg_p005_w4f1.npz")
+    kw = fx.params(f, tag + "_params")
+    kw.pop("multi_thread")
+    for wi in range(4):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        assert mat.shape[0] == 576 and mat.shape[1] in (4752, 4896)
+        dec = O.bpgdg_decoder(mat, channel_probs=priors, **kw)
+        replay(dec, fx.Trace(f, f"{tag}_win{wi}_", *mat.shape))
+
+
 def test_bb144_fresh_history_values():
     """Full LLR history (n x 4) for 24 decodes, one fresh reference object each: equal to the
     last bit, which is stronger than the 1e-5 relative tolerance the north star asks for."""

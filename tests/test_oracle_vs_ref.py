@@ -238,6 +238,22 @@ def test_gdg_multi_64_hypotheses_bb144_window(R):
     assert tot[0] >= 30 and tot[1] >= 25, tot
 
 
+def test_threaded_ensemble_bb288_window_d4s20(R):
+    """The reference's [[288,12,18]] (4,1) guessing-decoder shape (`Sliding Window GDG.ipynb` cell 8: max_iter 16, max_step 60,
+    max_tree_depth 4, max_side_depth 20, branch steps 40 -> 1 + 15 + 16 = 32 threads) on the 576 x 4896 windows of the recorded
+    run: every thread's path metric of the oracle's ensemble against the reference's REAL threads."""
+    f = fx.load("bb288_gdg_p005_w4f1.npz")
+    kw = fx.params(f, "d4s20_params")
+    kw.pop("multi_thread")
+    tot = [0, 0, 0]
+    for wi in (1, 3):
+        mat, priors = fx.graph(f, f"win{wi}_")
+        tr = fx.Trace(f, f"d4s20_win{wi}_", *mat.shape)
+        r = _ensemble_case(R, mat, priors, kw, list(tr.synd[:32]))
+        tot = [a + b for a, b in zip(tot, r)]
+    assert tot[0] >= 20 and tot[1] >= 15, tot
+
+
 def test_threaded_ensemble_main_thread_scans_a_block_that_converged_early(R):
     """A window found by tests/fuzz_pipeline.py (seed 13000, `ens`; dumped with SWD_FUZZ_DUMP): the main thread's fifth block
     converges in its second iteration and the thread runs select_vn on it BEFORE testing convergence (bpgd.cpp:630-633), i.e. on a
@@ -272,3 +288,69 @@ def test_threaded_ensemble_weight2_known_answer():
         if dec.converge:
             ok.append((int(i), int(j), int(e.sum())))
     assert ok == [tuple(int(x) for x in r) for r in f["multi"]] == [(0, 72, 14), (1, 73, 14)]
+
+
+def test_reused_ensemble_object_keeps_its_previous_vector_when_reset_fails(R):
+    """The documented deviation, measured (include/swd.h, swd_gdg_params.multi_thread): the reference's bpgdg_decoder keeps ONE
+    BPGD_main_thread for its lifetime (bp_guessing_decoder.pyx:238-251).  do_work clears min_pm but not min_pm_error
+    (bpgd.cpp:597-599) and returns early when BPGD::reset fails (:619-625), so a RE-USED object returns its previous decode's vector
+    there (converge False), while a freshly built object -- ref_gdg_multi, the oracle, the device -- returns zeros.  Everything else
+    (every thread's path metric, the shared minimum, the vector of every decode whose reset succeeds) is the same on the re-used
+    object as on fresh ones when max_iter_per_step >= 4 (no stale history slot is ever read)."""
+    f = fx.load("bb72_capacity.npz")
+    mat, _ = fx.graph(f, "gdg_")
+    m, n = mat.shape
+    rng = np.random.default_rng(5)
+    priors = rng.uniform(0.03, 0.08, size=n)
+    new_n = 24  # a short kept set: some checks keep one column, and an inconsistent syndrome makes the peeling in reset fail
+    kw = dict(max_iter=8, ms_scaling_factor=1.0, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+              max_tree_branch_step=10, max_side_branch_step=10, gdg_factor=1.0, new_n=new_n)
+    H = sp.csr_matrix(mat).astype(np.int64)
+    synds = [(H @ (rng.random(n) < priors * 1.3).astype(np.int64) % 2).astype(np.uint8) for _ in range(120)]
+    synds += [(rng.random(m) < 0.3).astype(np.uint8) for _ in range(120)]  # random syndromes: mostly outside the kept columns' span
+    order = rng.permutation(len(synds))
+    dec = O.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
+    p = Pcm(R, mat)
+    llr = np.ascontiguousarray(np.log((1 - priors) / priors))
+    vp, i32 = C.c_void_p, C.c_int32
+    R.ref_gdg_multi_new.restype = vp
+    R.ref_gdg_multi_new.argtypes = [i32] * 9 + [C.c_double]
+    R.ref_gdg_multi_free.argtypes = [vp]
+    R.ref_gdg_multi_decode.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    obj = R.ref_gdg_multi_new(m, new_n, kw["max_iter_per_step"], kw["max_step"], kw["max_tree_depth"], kw["max_side_depth"],
+                              kw["max_tree_branch_step"], kw["max_side_branch_step"], 0, 1.0)
+    prev = np.zeros(new_n, np.uint8)  # min_pm_error of a new object: zeros (vector<char>(n))
+    ran = fails = kept_stale = ties = 0
+    for k in order:
+        s = synds[k]
+        dec.clear_history()
+        out = dec.decode(s)
+        if dec._res.exit_class == 0:
+            continue  # pre-processing BP converged: the ensemble object is not touched
+        cols = np.ascontiguousarray(dec.cols)
+        err, rpm, rpms = np.zeros(new_n, np.uint8), C.c_double(), np.zeros(256)
+        su = np.ascontiguousarray(s, np.uint8)
+        rc = R.ref_gdg_multi_decode(obj, p.h, m, new_n, cols.ctypes.data, llr.ctypes.data, su.ctypes.data, err.ctypes.data,
+                                    C.byref(rpm), rpms.ctypes.data)
+        T, S = rc & 0xFFFF, rc >> 16
+        ran += 1
+        if dec.ensemble_blocks()[0] == 0:  # BPGD::reset failed: no thread ran a BP block
+            fails += 1
+            assert rpm.value > 9999.0 and not dec.converge
+            assert not out.any(), "fresh-object semantics: the zero vector"
+            assert np.array_equal(err, prev), "the re-used reference object hands back its previous decode's vector"
+            kept_stale += int(prev.any())
+            continue
+        pms, winner, nt = dec.ensemble_info()
+        assert np.array_equal(pms[1:], rpms[:T + S]), "per-thread path metrics differ between a re-used and a fresh object"
+        assert dec.min_pm == rpm.value
+        if nt == 0:
+            ref_out = np.zeros(n, np.uint8)
+            ref_out[cols[:new_n]] = err
+            assert np.array_equal(out, ref_out)
+        else:
+            ties += 1
+        prev = err.copy()
+    R.ref_gdg_multi_free(obj)
+    print(f"re-used BPGD_main_thread: {ran} ensemble decodes, {fails} reset failures, {kept_stale} of them returned a stale non-zero vector, {ties} ties")
+    assert ran >= 80 and fails >= 5 and kept_stale >= 3, (ran, fails, kept_stale)
