@@ -17,6 +17,8 @@ if os.environ.get('SWD_CONFIG') == 'shyps12':  # SHYPS r=3, twelve-round windows
     plan = plan_windows(_dem.chk, _dem.obs, _dem.priors, 21, 12, 1, method=1)
 elif os.environ.get('SWD_CONFIG') == 'global144':  # the un-windowed 936 x 8784 DEM on the large-graph kernels (IBM.ipynb:119-135)
     plan = bench.build_problem(**bench.WORKLOADS["global144"]["problem"])
+elif os.environ.get('SWD_CONFIG') == '288w3':  # [[288,12,18]] (3,1) windows: 432 x 3456
+    plan = bench.build_problem(N=288, W=3, F=1)
 else:
     plan = bench.build_problem(N=288, W=4, F=1) if os.environ.get('SWD_CONFIG') == '288' else bench.build_problem()
 dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=order, **(bench.WORKLOADS["global144"]["decoder_kw"] if os.environ.get('SWD_CONFIG') == 'global144' else {})))

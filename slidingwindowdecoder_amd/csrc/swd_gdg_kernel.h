@@ -157,6 +157,8 @@ struct GdgLds {
     uint8_t *cat;      // [new_n] select_vn classification per position
 };
 
+// smem: the workgroup's LDS block (NOT the scratch region, which large-graph kernels keep in HBM): gdg_lds_base
+__device__ __forceinline__ char *gdg_lds_base(const Lds &s, const SwdLdsLayout &L) { return (char *)s.hard - L.off_hard; }
 __device__ __forceinline__ void gdg_bind(GdgLds &G, char *smem, const SwdLdsLayout &L, int n, int new_n) {
     char *b = smem + L.off_gdg;
     G.pos_lv = (uint16_t *)b; b += new_n * 2;
@@ -1506,7 +1508,7 @@ __device__ __forceinline__ void decode_window_gdg(const SwdGraphDev &g_in, const
     const SwdGraphDev &g = g_loc;
     const int tid = threadIdx.x, m = g.m, n = g.n, new_n = g.new_n;
     GdgLds G;
-    gdg_bind(G, s.scratch, L, n, new_n);
+    gdg_bind(G, gdg_lds_base(s, L), L, n, new_n);
 #pragma unroll
     for (int i = 0; i < 9; ++i) R.t[i] = 0;
 #ifdef SWD_GDGPROF

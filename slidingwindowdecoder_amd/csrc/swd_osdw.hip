@@ -78,7 +78,7 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     // large graphs: what fits beside the state goes back into LDS -- the messages of the shortened graph (one column of cells per
     // live variable node: D x new_n cells + the sink, far and zero slots) and the arrays of the OSD phase that start at off_aux
     L.off_pmsg = -1; L.pmsg_bytes = 0; L.post_lds = 0; L.osd_lds = 0;
-    if (big && !getenv("SWD_BIG_NO_LDS")) {
+    if (big && kind == 0 && !getenv("SWD_BIG_NO_LDS")) {
         const int post_b = align_up((g.D * new_n + 1 + 2 * (nt / 64)) * 8, 16);
         // (transform matrix, pivots; the ordered list behind them stays in the scratch region -- osd_run)
         const int aux_b = align_up(std::max(std::max(osd_bytes_at_aux - n * 2, rare_bytes) - L.off_aux, L.off_hs + n * 8 - L.off_aux), 16);
@@ -149,18 +149,20 @@ static const Variant kVariants[] = {
 #undef X
 };
 
-#define X(nt, vf, dm, kg) SWD_DECLARE_LAUNCHER(5, nt, vf, dm, kg, 0) SWD_DECLARE_LAUNCHER(6, nt, vf, dm, kg, 0)
+#define X(nt, vf, dm, kg) SWD_DECLARE_LAUNCHER(5, nt, vf, dm, kg, 0) SWD_DECLARE_LAUNCHER(6, nt, vf, dm, kg, 0) SWD_DECLARE_LAUNCHER(8, nt, vf, dm, kg, 0) SWD_DECLARE_LAUNCHER(9, nt, vf, dm, kg, 0)
 SWD_BIG_VARIANTS(X)
 #undef X
 static const Variant kBigVariants[] = {
-#define X(nt, vf, dm, kg) {nt, vf, dm, kg, 0, SWD_LAUNCHER_NAME(5, nt, vf, dm, kg, 0), nullptr, nullptr, SWD_LAUNCHER_NAME(6, nt, vf, dm, kg, 0), nullptr},
+#define X(nt, vf, dm, kg) {nt, vf, dm, kg, 0, SWD_LAUNCHER_NAME(5, nt, vf, dm, kg, 0), SWD_LAUNCHER_NAME(8, nt, vf, dm, kg, 0), nullptr, SWD_LAUNCHER_NAME(6, nt, vf, dm, kg, 0), SWD_LAUNCHER_NAME(9, nt, vf, dm, kg, 0)},
     SWD_BIG_VARIANTS(X)
 #undef X
 };
 
-const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax) {
-    for (const Variant &v : kBigVariants)
+const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax, int kind) {
+    for (const Variant &v : kBigVariants) {
+        if (kind != 0 && !v.launch_gdg) continue;
         if (v.nt >= mmax && v.nt * v.vf >= nmax && v.dm >= dm && 4 * v.kg >= kmax) return &v;
+    }
     return nullptr;
 }
 

@@ -2451,7 +2451,7 @@ __global__ void __launch_bounds__(NT) shot_order_kernel(const uint32_t *wt, int 
 
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false, int VFP = VF>
 __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 512 && SWD_TUNED_NT >= 512 && (KIND == 0 || KIND == 3)) ? 6 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2)))) pipeline_kernel(const SwdPipeArgs a) {
-    static_assert(!BIG || KIND == 0 || KIND == 3, "the HBM-resident scratch region exists for the osd_window kernels");
+    static_assert(!BIG || KIND == 0 || KIND == 3 || KIND == 1 || KIND == 7, "the HBM-resident scratch region exists for the osd_window kernels and for the guessing decoders' serial walk / ticket-scheduled ensemble");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     // One workgroup decodes ONE window of one shot.  Units are handed out by an atomic ticket in
@@ -2676,7 +2676,7 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT =
                 // the tree threads become tasks, a FINAL item brings the result), 0 = the whole ensemble here, 2 = one tree thread.
                 if (ens_task || R.exit_class == -3) {
                     GdgLds G;
-                    gdg_bind(G, s.scratch, L, g.n, g.new_n);
+                    gdg_bind(G, gdg_lds_base(s, L), L, g.n, g.new_n);
                     SwdGraphDev g_ens = g;
                     int role = 0, hyp = 0;
                     bool dead_unsat = false;

@@ -69,7 +69,7 @@ struct Variant {
     int (*launch_ens)(Plan *, const SwdPipeArgs &, hipStream_t);  // bpgdg_decoder(multi_thread=True): the reference's threaded ensemble (kind 7)
 };
 const Variant *select_variant(const std::vector<WindowHost> &wins, int mmax, int nmax, int dm, int kmax, int kind);
-const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax); // osd_window on graphs beyond one CU's LDS: scratch region in HBM
+const Variant *select_big_variant(int mmax, int nmax, int dm, int kmax, int kind = 0); // graphs beyond one CU's LDS: scratch region in HBM
 bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);
 
 
@@ -206,12 +206,20 @@ struct Plan {
         // large-graph form of the osd_window kernels, whose scratch region lives in HBM
         for (int attempt = 0; attempt < 2; ++attempt) {
             big = attempt == 1;
-            if (big && kind != 0) break;
-            variant = big ? select_big_variant(mtop, nmax, dm, ktop) : select_variant(wins, mtop, nmax, dm, ktop, kind);
+            // (large graphs under a guessing decoder: the serial tree walk / the ticket-scheduled ensemble with every message in HBM --
+            // a functional path for graphs such as the reference's [[288,12,18]] (4,1) windows, not a tuned one)
+            variant = big ? select_big_variant(mtop, nmax, dm, ktop, kind) : select_variant(wins, mtop, nmax, dm, ktop, kind);
+            if (variant && big && kind == 1 && gp.multi_thread == 1 && !variant->launch_ens) variant = nullptr;
             if (!variant) {
                 set_error("no kernel variant for m=%d n=%d column weight %d row weight %d%s", mtop, nmax, dm, ktop,
                           big ? " (large-graph kernels: up to 1024 checks, 9216 columns, column weight 10, row weight 64)" : "");
                 continue;
+            }
+            if (big && kind != 0) {
+                bool d2 = true;
+                for (auto &w : wins) d2 = d2 && w.new_n <= 2 * variant->nt;
+                if (!d2) { set_error("guessing decoders on large graphs keep at most %d columns (new_n <= 2 x threads)", 2 * variant->nt); variant = nullptr; continue; }
+                gdg_parallel = false; // (no work items: the serial tree walk)
             }
             nt = variant->nt; vf = variant->vf;
             mmax = 0; lmax = 0; big_stride = 0;
@@ -335,8 +343,9 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         // committed), one TASK item per tree thread of a parked ensemble, FINAL (swd_gdg_kernel.h, gdg_ensemble_tree ROLE 1 / 2).
         // Context: header | position list | forks at depth D - 1 | offer table | one vector per hypothesis + the main thread's exit
         // vector; its fork records (masks + message cells, 2^(D-1) of them) in the csnap area.
+        // (large-graph form: window-major tickets, every thread body on the unit's workgroup)
         const int Dp = d->gp.max_tree_depth, NS = std::max(d->gp.max_side_depth - d->gp.max_tree_depth, 0);
-        if (a.W > 1 && a.B < SWD_GDG_ITEM_MAX_SHOTS && a.W <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_ENS_TICKETS")) {
+        if (!BIG && a.W > 1 && a.B < SWD_GDG_ITEM_MAX_SHOTS && a.W <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_ENS_TICKETS")) {
             a.slot_scratch = 1;
             const bool tasks = Dp >= 1 && !getenv("SWD_ENS_NO_TASKS");
             unsigned nctx = 64;
@@ -470,6 +479,10 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, 0)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, (kind) == 6 ? 3 : 0, false, true>(d, a, st); }
 #define SWD_DEFINE_LAUNCHER(kind, nt, vf, dm, kg, sf) \
     int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, sf)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, kind, (sf) != 0>(d, a, st); }
+// large-graph form of the guessing decoders' kernels: kind 8 = kind 1 (serial tree walk), kind 9 = kind 7 (threaded ensemble, tickets);
+// depth-2 register cache for the kept columns (Plan::finalize admits only plans with new_n <= 2 nt)
+#define SWD_DEFINE_BIG_GDG_LAUNCHER(kind, nt, vf, dm, kg) \
+    int SWD_LAUNCHER_NAME(kind, nt, vf, dm, kg, 0)(Plan *d, const SwdPipeArgs &a, hipStream_t st) { return launch_nt<nt, vf, dm, kg, (kind) == 9 ? 7 : 1, false, true, 2>(d, a, st); }
 // guessing decoders: a second instantiation with a depth-2 register cache for the shortened graph, taken when every window of the
 // plan keeps new_n <= 2 nt columns (Plan::post_depth2)
 #define SWD_DEFINE_GDG_LAUNCHER(kind, nt, vf, dm, kg, sf)                                                                  \
