@@ -9,7 +9,7 @@ import bench
 from slidingwindowdecoder_amd import SlidingWindowDecoder
 from slidingwindowdecoder_amd.windows import sample_dem
 shots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-plan = bench.build_problem()
+plan = bench.build_problem(N=288, W=4, F=1) if os.environ.get("SWD_CONFIG") == "288" else bench.build_problem()
 dec = SlidingWindowDecoder(plan, **dict(bench.DECODER_KW, osd_order=0))
 det, obs, _ = sample_dem(plan.chk, plan.obs, plan.priors, shots, seed=1)
 d = torch.from_numpy(det).cuda()

@@ -35,6 +35,12 @@ struct SwdGraphDev {
     const uint16_t *vn_row;  // [D*n]
     const uint8_t *col_deg;  // [n]
     const double *llr;       // [n]
+    // The full-graph variable-node pass in TIERS (round 5): the nodes listed by decreasing degree in steps of two (stable in the
+    // column index), so that the 64 nodes a wave serves in one cache row need the same number of message positions and the pass
+    // skips the rest -- vperm[i] = the i-th listed node, vn_edge_s / llr_s = vn_edge / llr in listed order (no dependent load).
+    const uint16_t *vperm;     // [n]
+    const uint32_t *vn_edge_s; // [D*n]
+    const double *llr_s;       // [n]
 };
 
 __host__ __device__ inline uint32_t swd_edge_slot(uint32_t e) { return e & 0xFFFFu; }

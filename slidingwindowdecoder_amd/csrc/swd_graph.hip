@@ -119,6 +119,20 @@ int Graph::build(const swd_graph_desc *g) {
         const double p = g->channel_probs[v];
         llr[v] = log((1 - p) / p); // osd_window.pyx:113
     }
+    // listed order of the nodes for the tiered full-graph pass: degree tiers of two positions, heaviest first, stable in the index
+    // (a window's column types -- runs of consecutive columns of one degree -- stay runs: neighbouring lanes keep neighbouring slots)
+    {
+        std::vector<int> ord(n);
+        for (int v = 0; v < n; ++v) ord[v] = v;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return (cdeg[a] + 1) / 2 > (cdeg[b] + 1) / 2; });
+        vperm.resize(n); llr_s.resize(n);
+        vn_edge_s.assign((size_t)std::max(D, 1) * n, SWD_PAD_EDGE);
+        for (int i = 0; i < n; ++i) {
+            vperm[i] = (uint16_t)ord[i];
+            llr_s[i] = llr[ord[i]];
+            for (int k = 0; k < D; ++k) vn_edge_s[(size_t)k * n + i] = vn_edge[(size_t)k * n + ord[i]];
+        }
+    }
     rank = gf2_rank(m, n, row_ptr, col_idx);
     wm = (m + 63) / 64;
     return 0;
@@ -135,7 +149,10 @@ int Graph::upload() {
     size_t o_vnrow = al(o_vnedge + vn_edge.size() * 4);
     size_t o_coldeg = al(o_vnrow + vn_row.size() * 2);
     size_t o_llr = al(o_coldeg + col_deg.size());
-    size_t total = al(o_llr + llr.size() * 8);
+    size_t o_vperm = al(o_llr + llr.size() * 8);
+    size_t o_vnedge_s = al(o_vperm + vperm.size() * 2);
+    size_t o_llr_s = al(o_vnedge_s + vn_edge_s.size() * 4);
+    size_t total = al(o_llr_s + llr_s.size() * 8);
     std::vector<char> h(total, 0);
     memcpy(&h[o_jptr], jptr.data(), jptr.size() * 2);
     memcpy(&h[o_rowcol], row_col.data(), row_col.size() * 2);
@@ -146,6 +163,9 @@ int Graph::upload() {
     memcpy(&h[o_vnrow], vn_row.data(), vn_row.size() * 2);
     memcpy(&h[o_coldeg], col_deg.data(), col_deg.size());
     memcpy(&h[o_llr], llr.data(), llr.size() * 8);
+    memcpy(&h[o_vperm], vperm.data(), vperm.size() * 2);
+    memcpy(&h[o_vnedge_s], vn_edge_s.data(), vn_edge_s.size() * 4);
+    memcpy(&h[o_llr_s], llr_s.data(), llr_s.size() * 8);
     if (dev.reserve(total)) return -1;
     SWD_HIP(hipMemcpy(dev.p, h.data(), total, hipMemcpyHostToDevice));
     char *b = (char *)dev.p;
@@ -159,6 +179,9 @@ int Graph::upload() {
     d.vn_row = (const uint16_t *)(b + o_vnrow);
     d.col_deg = (const uint8_t *)(b + o_coldeg);
     d.llr = (const double *)(b + o_llr);
+    d.vperm = (const uint16_t *)(b + o_vperm);
+    d.vn_edge_s = (const uint32_t *)(b + o_vnedge_s);
+    d.llr_s = (const double *)(b + o_llr_s);
     return 0;
 }
 

@@ -81,8 +81,9 @@ struct Graph {
     int m = 0, n = 0, E = 0, K = 0, D = 0, rank = 0, wm = 0;
     std::vector<uint16_t> jptr, row_col, perm, iperm, vn_row;
     std::vector<uint8_t> row_deg, col_deg;
-    std::vector<uint32_t> vn_edge;
-    std::vector<double> llr;
+    std::vector<uint32_t> vn_edge, vn_edge_s;
+    std::vector<uint16_t> vperm;
+    std::vector<double> llr, llr_s;
     // original CSR/CSC kept for host-side use (rank, OSD-CS setup)
     std::vector<int32_t> row_ptr, col_idx, col_ptr, row_idx;
     DevBuf dev;

@@ -41,7 +41,8 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     // the staged row lists of the sorted columns end before it
     L.off_oslot = -1;
     if (wm > 4 && wm <= 9 && nt >= 1024) {
-        const int nbc = nt / 16, sb = align_up(2 * nbc * 9 * 8 + 2 * nbc * 4 + 2 * (nt / 64) + 16, 16);
+        // ring of SWD_OSD_RING row operations (10 words each), hand-over block of one batch (9 x 64 words), pivoted-row mask, control words
+        const int sb = align_up(SWD_OSD_RING * 10 * 8 + 9 * 64 * 8 + 10 * 8 + 16 * 4, 16);
         if (sb <= npad * 4) L.off_oslot = npad * 8 - sb;
     }
     L.off_hs = align_up(L.off_aux + n * 2, 16); // behind the decided-0 list of the OSD ordering, used before the elimination sets up
@@ -93,7 +94,12 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     }
     // experiment (SWD_POST_RENUM=1, tuned osd_window kernels of up to 256 threads): renumber the shortened graph's message cells
     // one column per live variable node inside the scratch region; the old-slot -> cell table takes the staged column table's place
-    if (diet && getenv("SWD_POST_RENUM") && L.off_lslot == 0 && (g.D * new_n + 1 + 2 * (nt / 64)) * 8 <= L.off_rc) L.post_lds = 1;
+    // (round 5, SWD_POST_SORTED: the production form of the tuned kernels' post phase whenever the renumbered cells fit in front of the
+    // staged column table, which becomes the old-slot -> cell table; SWD_NO_POST_SORTED=1 in the environment keeps the round-4 form)
+    // (diet kernels keep cell BYTE offsets in 16 bits, the 1024-thread osd_window kernels cell numbers)
+    if (kind == 0 && !big && !getenv("SWD_NO_POST_SORTED") && L.off_lslot == 0 && (g.D * new_n + 1 + 2 * (nt / 64)) * 8 <= L.off_rc &&
+        g.D * new_n + 1 + 2 * (nt / 64) <= (diet ? 8191 : 65535) && (diet || nt >= 1024))
+        L.post_lds = 1;
     L.total = align_up(o, 16);
     return 0;
 }

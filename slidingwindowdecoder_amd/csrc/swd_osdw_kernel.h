@@ -37,6 +37,44 @@
 #ifndef SWD_POST_DEPTH2
 #define SWD_POST_DEPTH2 0
 #endif
+// Round-5 experiments on the iteration loop's dependent LDS round trips (bp_run):
+//   SWD_BP_XARG_TRACK        1: the sign of a check's first-minimum position comes out of the sign shift registers (one compare-select
+//                               more per position) instead of a re-read of the message before the write phase
+//   SWD_BP_FLAG_MERGE_MAXVF  the convergence flags of block_any are read together with the first node's messages in caches of at
+//                            most this depth (0: never; deep caches pay for the twelve registers held across the exit test with spills)
+// Both measured on the headline (gpurun_out/r05f: 10.08 ms per launch without, 10.14 with the merge, 10.20 with the tracking, 10.17 with
+// both) and left off: the loops are bound by the CU's LDS pipeline, not by these round trips.
+#ifndef SWD_BP_XARG_TRACK
+#define SWD_BP_XARG_TRACK 0
+#endif
+#ifndef SWD_BP_FLAG_MERGE_MAXVF
+#define SWD_BP_FLAG_MERGE_MAXVF 0
+#endif
+// SWD_POST_SORTED (tuned osd_window kernels, round 5): the shortened graph's live nodes are listed by decreasing live degree, a node's
+// live edges are moved to the front of its cache, the message cells are renumbered one column per listed node (cell(k, i) = k x nlive + i)
+// and a wave's variable-node pass skips the positions beyond the largest live degree among its nodes (in steps of two) -- the
+// iterations are LDS-bound and the live degree averages 2.65 of 6 positions.
+#ifndef SWD_POST_SORTED
+#define SWD_POST_SORTED 3
+#endif
+// SWD_FULL_SORTED (osd_window kernels, round 5): the full-graph phase serves its nodes in the graph's listed order (SwdGraphDev::vperm:
+// degree tiers of two, heaviest first) and its variable-node pass is tiered like the shortened graph's.
+// Measured on the headline (gpurun_out/r05l): bit-exact, 30 % fewer message positions in the full-graph variable-node pass (7296 of
+// 10368 per iteration of the [[144,12,12]] mid window) -- and 10.01 ms per launch against 9.80: the three bodies per cache row, the row
+// caps and the node numbers cost the check pass six more instructions per group of four.  Off.
+#ifndef SWD_FULL_SORTED
+#define SWD_FULL_SORTED 0
+#endif
+// SWD_CN_HALF (round 5): the check pass of the SHORTENED graph walks its positions in groups of four whose second half is skipped when
+// no lane of the wave has a position there (cn_assign bounds a thread's walk by T = 3, 4, 6, 8, 12 ...: T = 6 costs 6 reads and writes
+// instead of 8).  Measured on the headline (gpurun_out/r05m): bit-exact and 10.45 ms per launch against 9.95 -- the scalar branch between
+// the two halves keeps the scheduler from issuing a group's four reads together; off.
+#ifndef SWD_CN_HALF
+#define SWD_CN_HALF 0
+#endif
+#ifndef SWD_TIER_STEP // positions per tier of the sorted form (tiers of one position -- six bodies of the pass per cache row, a second prefix sum for the order -- measured slower: 10.0 against 9.84 ms per headline launch)
+#define SWD_TIER_STEP(DM) 2
+#endif
 #ifndef SWD_POST_KGP // groups of four check positions in the shortened graph's register cache (0: as many as for the full graph)
 #define SWD_POST_KGP 0
 #endif
@@ -258,6 +296,12 @@ __device__ __forceinline__ uint64_t f2key(double x) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+__device__ __forceinline__ int wave_max(int x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x = max(x, __shfl_xor(x, d, 64));
+    return x;
+}
+
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -305,6 +349,9 @@ template <int VF, int DM, int SH = 0, bool PB = true>
 struct VnCacheP {
     static_assert(DM % 2 == 0, "edge offsets are packed in pairs");
     static constexpr bool par_bytes = PB;
+    // the halves of par[][] hold the check's lane number, or -- byte-offset caches with parity words (SH == 0, !PB: round 5) -- the
+    // byte offset of its parity word (lane << 2): the flip's address is then one add, like a message address
+    static constexpr int par_shift = (SH == 0 && !PB) ? 2 : 0;
     double llr[VF];
     uint32_t edp[VF][DM / 2];
     __device__ __forceinline__ void set_ed(int i, int k, uint32_t v) { v >>= SH; edp[i][k >> 1] = (k & 1) ? ((edp[i][k >> 1] & 0xFFFFu) | (v << 16)) : ((edp[i][k >> 1] & 0xFFFF0000u) | v); }
@@ -332,16 +379,30 @@ __device__ __forceinline__ int swd_slot_zero(const SwdGraphDev &g) { return g.E 
 // whatever the caller does in between runs while the loads are in flight.
 template <int NT, int VF, int DM>
 struct VnRaw { uint32_t ev[VF][DM]; double llr[VF]; };
-template <int NT, int VF, int DM>
+template <int NT, int VF, int DM, bool SORTED = false> // SORTED: entry idx = the idx-th node of the graph's listed order (vperm)
 __device__ __forceinline__ void vn_cache_issue(const SwdGraphDev &g, const Lds &s, VnRaw<NT, VF, DM> &r) {
     const int n = g.n, D = g.D;
+    const uint32_t *et = SORTED ? g.vn_edge_s : g.vn_edge;
+    const double *lt = SORTED ? g.llr_s : g.llr;
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         const int idx = s.vtid + i * NT;
         const int v = (idx < n) ? idx : 0;
-        r.llr[i] = (n > 0) ? g.llr[v] : 0.0;
+        r.llr[i] = (n > 0) ? lt[v] : 0.0;
 #pragma unroll
-        for (int k = 0; k < DM; ++k) r.ev[i][k] = (n > 0) ? g.vn_edge[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
+        for (int k = 0; k < DM; ++k) r.ev[i][k] = (n > 0) ? et[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
+    }
+}
+// largest degree among the nodes this wave serves in cache row i (wave-uniform), from the raw edge words of the row
+template <int NT, int VF, int DM>
+__device__ __forceinline__ void vn_row_caps(const SwdGraphDev &g, const Lds &s, const uint32_t (&ev)[VF][DM], int (&kc)[VF]) {
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const bool valid = s.vtid + i * NT < g.n;
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) d += (valid && k < g.D && ev[i][k] != SWD_PAD_EDGE) ? 1 : 0;
+        kc[i] = __builtin_amdgcn_readfirstlane(wave_max(d));
     }
 }
 template <int NT, int VF, int DM, int SH, bool PB>
@@ -355,35 +416,41 @@ __device__ __forceinline__ void vn_cache_pack(const SwdGraphDev &g, const Lds &s
         c.llr[i] = valid ? r.llr[i] : 0.0;
 #pragma unroll
         for (int k = 0; k < DM; ++k) c.set_ed(i, k, dead);
+        constexpr int PS = VnCacheP<VF, DM, SH, PB>::par_shift;
 #pragma unroll
-        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
+        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = ((uint32_t)g.m << PS) * 0x10001u;
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
             const uint32_t e = r.ev[i][k];
             if (valid && k < D && e != SWD_PAD_EDGE) {
                 c.set_ed(i, k, swd_edge_slot(e) << 3);
-                c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
-                                           : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
+                c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | ((swd_edge_lane(e) << PS) << 16))
+                                           : ((c.par[i][k >> 1] & 0xFFFF0000u) | (swd_edge_lane(e) << PS));
             }
         }
     }
 }
 
 // ALLEDGES (with !FULL): the listed nodes with every edge of theirs, whatever the state of the checks.
-template <int NT, int VF, int DM, bool FULL, bool ALLEDGES = false, int SH, bool PB>
-__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr) {
+// SORTED (with FULL): entry idx = the idx-th node of the graph's listed order (vperm); kc (optional): the rows' degree caps (vn_row_caps)
+template <int NT, int VF, int DM, bool FULL, bool ALLEDGES = false, bool SORTED = false, int SH, bool PB>
+__device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr, int (*kc)[VF] = nullptr) {
+    static_assert(!SORTED || FULL, "the listed order belongs to the full graph");
     const int n = g.n, cnt = FULL ? n : nlive;
     const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
     const int D = g.D;
+    const uint32_t *et = SORTED ? g.vn_edge_s : g.vn_edge;
+    const double *lt = SORTED ? g.llr_s : g.llr;
     uint32_t ev[VF][DM];
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         const int idx = s.vtid + i * NT;
         const int v = (idx < cnt) ? (FULL ? idx : (int)s.lv[idx]) : 0;
-        c.llr[i] = (n > 0) ? g.llr[v] : 0.0; // (n, D: uniform)
+        c.llr[i] = (n > 0) ? lt[v] : 0.0; // (n, D: uniform)
 #pragma unroll
-        for (int k = 0; k < DM; ++k) ev[i][k] = (n > 0) ? g.vn_edge[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
+        for (int k = 0; k < DM; ++k) ev[i][k] = (n > 0) ? et[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
     }
+    if constexpr (SORTED) { if (kc) vn_row_caps<NT, VF, DM>(g, s, ev, *kc); }
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         const int idx = s.vtid + i * NT;
@@ -391,8 +458,9 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
         if (!valid) c.llr[i] = 0.0;
 #pragma unroll
         for (int k = 0; k < DM; ++k) c.set_ed(i, k, dead);
+        constexpr int PS = VnCacheP<VF, DM, SH, PB>::par_shift;
 #pragma unroll
-        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = (uint32_t)g.m * 0x10001u;
+        for (int k = 0; k < (DM + 1) / 2; ++k) c.par[i][k] = ((uint32_t)g.m << PS) * 0x10001u;
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
             const uint32_t e = ev[i][k];
@@ -401,11 +469,60 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
                     uint32_t slot = swd_edge_slot(e);
                     if (!FULL && remap) { const uint32_t cell = (uint32_t)(k * nlive + idx); remap[slot] = (uint16_t)cell; slot = cell; }
                     c.set_ed(i, k, slot << 3);
-                    c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (swd_edge_lane(e) << 16))
-                                               : ((c.par[i][k >> 1] & 0xFFFF0000u) | swd_edge_lane(e));
+                    c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | ((swd_edge_lane(e) << PS) << 16))
+                                               : ((c.par[i][k >> 1] & 0xFFFF0000u) | (swd_edge_lane(e) << PS));
                 }
             }
         }
+    }
+}
+
+
+// Shortened graph, sorted form (SWD_POST_SORTED): the listed nodes' LIVE edges at the front of the cache in their row order (the
+// prefix / suffix sums of a node run over its live edges in that order either way; a dead position contributed + 0.0), cells
+// renumbered cell(kk, i) = kk x nlive + i for the kk-th live edge of the i-th listed node, remap[old slot] = cell for the check side.
+// kc[i]: the largest number of live edges among the nodes this wave serves in cache row i (wave-uniform).
+template <int NT, int VF, int DM, int SH, bool PB>
+__device__ __forceinline__ void vn_cache_load_compact(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap, int (&kc)[VF]) {
+    const int n = g.n, D = g.D;
+    constexpr int PS = VnCacheP<VF, DM, SH, PB>::par_shift;
+    const uint32_t dead = (uint32_t)swd_slot_zero<NT>(g) << 3;
+    uint32_t ev[VF][DM];
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        const int v = (idx < nlive) ? (int)s.lv[idx] : 0;
+        c.llr[i] = (n > 0) ? g.llr[v] : 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) ev[i][k] = (n > 0) ? g.vn_edge[max(min(k, D - 1), 0) * n + v] : SWD_PAD_EDGE;
+    }
+#pragma unroll
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        const bool valid = idx < nlive;
+        if (!valid) c.llr[i] = 0.0;
+        uint32_t edl[DM], pl[DM]; // cell byte offsets / parity halves of the live edges, front-compacted
+#pragma unroll
+        for (int q = 0; q < DM; ++q) { edl[q] = dead; pl[q] = (uint32_t)g.m << PS; }
+        int kk = 0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+            const uint32_t e = ev[i][k];
+            const bool live = valid && k < D && e != SWD_PAD_EDGE && s.cn_val[swd_edge_lane(e)] >= 0;
+            if (live) {
+                const uint32_t cell = (uint32_t)(kk * nlive + idx);
+                remap[swd_edge_slot(e)] = (uint16_t)cell;
+#pragma unroll
+                for (int q = 0; q <= k; ++q) // (kk <= k)
+                    if (q == kk) { edl[q] = cell << 3; pl[q] = swd_edge_lane(e) << PS; }
+                ++kk;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < DM; ++q) c.set_ed(i, q, edl[q]);
+#pragma unroll
+        for (int q = 0; q < (DM + 1) / 2; ++q) c.par[i][q] = pl[2 * q] | ((2 * q + 1 < DM ? pl[2 * q + 1] : ((uint32_t)g.m << PS)) << 16);
+        kc[i] = __builtin_amdgcn_readfirstlane(wave_max(kk));
     }
 }
 
@@ -423,11 +540,6 @@ __device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM, SH, PB> &
     }
 }
 
-__device__ __forceinline__ int wave_max(int x) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x = max(x, __shfl_xor(x, d, 64));
-    return x;
-}
 
 // Per-thread register cache of the check a lane owns during one BP phase: the LDS slots of its
 // edges (u16, two per register) in walk order; unused / dead positions hold the wave's far slot.
@@ -588,10 +700,13 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // tree walk instead of compacting the live nodes after every decimation), and the posterior history goes to registers of the
 // node's thread -- h4[i][slot] for its i-th node -- instead of the ring in HBM: the thread that runs a position's node is the one
 // that classifies the position afterwards, and without the stores the iteration barriers no longer wait for HBM.
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, int SH, bool PB>
+// TIER (sorted form of the shortened graph, vn_cache_load_compact): kcap[i] = largest number of live edges among the nodes the wave
+// serves in cache row i; the variable-node pass runs over the first 2, 4, ... DM positions only (a wave-uniform choice per row).
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
-                      double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr, bool rec_early = false) {
+                      double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr, bool rec_early = false,
+                      const int *kcap = nullptr) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
     const int vcnt = FULL ? n : nlive;
     // rec_early: the caller reads the history even when the run converges before its last four iterations (the threaded
@@ -605,6 +720,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #else
     const int wmax = __builtin_amdgcn_readfirstlane(wave_max(cnt)); // (scalar: the groups of four positions are skipped by scalar branches)
 #endif
+    // largest number of threads sharing a check in this wave (uniform): waves whose checks all have a thread of their own skip the merge
+    [[maybe_unused]] const int gmax = __builtin_amdgcn_readfirstlane(wave_max(cn.grp));
     const int farslot = swd_slot_far(g), zeroslot = swd_slot_zero<NT>(g);
     constexpr int K4 = KG * 4;
     constexpr int NR = (K4 + 31) / 32;       // sign shift registers
@@ -619,6 +736,14 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     s.msg[farslot] = 64.0;
     s.msg[zeroslot] = 0.0;
     char *const parb = (char *)s.par;
+    // (shortened graph) the node a list entry names does not change during the run: read once, not once per iteration
+    // (full graph in tiers: the listed order of the graph, SwdGraphDev::vperm)
+    constexpr bool kNodeList = !FULL || TIER;
+    [[maybe_unused]] int vnode[kNodeList ? VF : 1];
+    if constexpr (kNodeList) {
+#pragma unroll
+        for (int i = 0; i < VF; ++i) { const int idx = s.vtid + i * NT; vnode[i] = (idx < vcnt) ? (FULL ? (int)g.vperm[idx] : (int)s.lv[idx]) : n; }
+    }
 #ifdef SWD_BPPROF
     long long tc0, tc1, tc2, tc3;
     long long acc_cn = 0, acc_any = 0, acc_vn = 0, acc_bar = 0;
@@ -647,25 +772,40 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             // is slower with iterative-ilp, which overlaps the reads of the next group by itself.)
             double min1 = 1e308, min2 = 1e308;
             uint32_t argslot = (uint32_t)farslot << 3; // byte offset of the first position holding the minimum
+            uint32_t argk = 0;                          // ... and its position number: its sign comes out of the sign registers below
+                                                        // (round 4 re-read the message: one more dependent LDS round trip per iteration)
             uint32_t neg[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) neg[r] = 0;
+            constexpr bool kHalf = SWD_CN_HALF != 0 && !FULL;
 #pragma unroll
             for (int gq = 0; gq < KG; ++gq) {
                 if (gq * 4 < wmax) { // wave-uniform
                     double xs[4];
                     uint32_t ad[4];
                     cn.group(gq, ad);
+                    const bool hi = !kHalf || gq * 4 + 2 < wmax; // (wave-uniform) does any lane walk the group's second half?
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xs[u] = swd_msg_at(s, ad[u]);
+                    for (int u = 0; u < 2; ++u) xs[u] = swd_msg_at(s, ad[u]);
+                    if (hi) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                        for (int u = 2; u < 4; ++u) xs[u] = swd_msg_at(s, ad[u]);
+                    }
+                    auto one = [&](auto u_tag) {
+                        constexpr int u = decltype(u_tag)::value;
                         const int k = gq * 4 + u;
                         const double ax = vminabs64(xs[u], 50.0);
+                        if constexpr (SWD_BP_XARG_TRACK) argk = (ax < min1) ? (uint32_t)k : argk;
                         argslot = (ax < min1) ? ad[u] : argslot; // (as sign-of-difference mask + v_bfi instead of v_cmp + v_cndmask: 10.1 against 10.0 ms, round 4)
                         min2 = vmin64(min2, vmax64(min1, ax));
                         min1 = vmin64(min1, ax);
                         neg_shift_in(neg[k >> 5], xs[u]);
+                    };
+                    one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+                    if (hi) { one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{}); }
+                    else {
+#pragma unroll
+                        for (int u = 2; u < 4; ++u) neg[(gq * 4 + u) >> 5] <<= 1;
                     }
                 } else {
 #pragma unroll
@@ -677,25 +817,38 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             int npar = (cn.sub == 0) ? cv : 0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) npar += __popc(neg[r]);
+            // "is negative" bit of the first-minimum position (position k sits at bit 31 - k % 32 of neg[k / 32]; no live position:
+            // position 0 = the far slot, positive)
+            uint32_t argneg = 0;
+            if constexpr (SWD_BP_XARG_TRACK) {
+                uint32_t wsel = neg[0];
+#pragma unroll
+                for (int r = 1; r < NR; ++r) wsel = ((argk >> 5) == (uint32_t)r) ? neg[r] : wsel;
+                argneg = (wsel << (argk & 31u)) >> 31;
+            }
             if constexpr (!FULL || SF) {
                 // merge the partial results of the check's threads (butterfly inside the quad).  On a tie
                 // of the minima the second minimum equals the first, so which side's position is kept
                 // as "first minimum" does not change any value written below.
-                {
+                if (gmax >= 2) { // (scalar branch)
                     const double o1 = quad_xor<1>(min1), o2 = quad_xor<1>(min2);
                     const uint32_t oa = (uint32_t)quad_xor<1>((int)argslot); const int op = quad_xor<1>(npar);
+                    const uint32_t on = (uint32_t)quad_xor<1>((int)argneg);
                     if (cn.grp >= 2) {
                         npar += op;
+                        argneg = (o1 < min1) ? on : argneg;
                         argslot = (o1 < min1) ? oa : argslot;
                         min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
                         min1 = vmin64(min1, o1);
                     }
                 }
-                {
+                if (gmax == 4) {
                     const double o1 = quad_xor<2>(min1), o2 = quad_xor<2>(min2);
                     const uint32_t oa = (uint32_t)quad_xor<2>((int)argslot); const int op = quad_xor<2>(npar);
+                    const uint32_t on = (uint32_t)quad_xor<2>((int)argneg);
                     if (cn.grp == 4) {
                         npar += op;
+                        argneg = (o1 < min1) ? on : argneg;
                         argslot = (o1 < min1) ? oa : argslot;
                         min2 = vmin64(vmax64(min1, o1), vmin64(min2, o2));
                         min1 = vmin64(min1, o1);
@@ -703,9 +856,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 }
             }
             const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
-            // the first position holding the minimum gets the second minimum (ties: both equal).
-            // Its own sign is re-read before the slots are overwritten.
-            const double xarg = swd_msg_at(s, argslot);
+            // the first position holding the minimum gets the second minimum (ties: both equal); its own sign: argneg
+            if constexpr (!SWD_BP_XARG_TRACK) argneg = (swd_msg_at(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
             if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
             const double p1 = min1 * alpha, p2 = min2 * alpha;
             const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
@@ -714,24 +866,53 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 if (gq * 4 < wmax) {
                     uint32_t ad[4];
                     cn.group(gq, ad);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    auto put = [&](auto u_tag) {
+                        constexpr int u = decltype(u_tag)::value;
                         const int k = gq * 4 + u;
                         const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
                         const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
                         swd_msg_at(s, ad[u]) = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
-                    }
+                    };
+                    put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{});
+                    if (!kHalf || gq * 4 + 2 < wmax) { put(std::integral_constant<int, 2>{}); put(std::integral_constant<int, 3>{}); }
                 }
             }
             {
-                const uint32_t sb = (((xarg <= 0) ? 0xFFFFFFFFu : 0u) ^ flip) & 0x80000000u;
+                const uint32_t sb = ((0u - argneg) ^ flip) & 0x80000000u;
                 const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
                 swd_msg_at(s, argslot) = __longlong_as_double((long long)b2);
                 s.msg[farslot] = 64.0; // re-arm
             }
         }
         BPT(tc1);
-        const bool any = block_any<NT>(unsat, s);
+        // block_any, cut in two: the per-wave flags go out before the barrier; behind it they are read TOGETHER with the first
+        // node's messages -- one LDS round trip instead of two in front of the variable-node pass (a converged run has loaded
+        // those messages for nothing)
+        int anyr = 0;
+        {
+            constexpr int NW = NT / 64;
+            const int fp_ = (s.fpar++) & 1;
+            const unsigned long long bu = __ballot(unsat);
+            if ((tid & 63) == 0) s.flags[fp_ * 16 + (tid >> 6)] = (bu != 0ull);
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) anyr |= s.flags[fp_ * 16 + w];
+        }
+        constexpr bool kFlagMerge = VF <= SWD_BP_FLAG_MERGE_MAXVF;
+        [[maybe_unused]] double cc0[DM];
+        [[maybe_unused]] uint32_t ad0[DM];
+        if (kFlagMerge && nch > 0) { // (wave-uniform)
+            c.get_ed(0, ad0);
+#pragma unroll
+            for (int k = 0; k < DM; ++k) cc0[k] = swd_msg_at(s, ad0[k]);
+#pragma unroll
+            for (int k = 0; k < DM; ++k) asm volatile("" : "+v"(cc0[k])); // (loaded here, in front of the exit test)
+        }
+#ifdef SWD_NO_SCALAR_ANY
+        const bool any = anyr != 0;
+#else
+        const bool any = __builtin_amdgcn_readfirstlane(anyr) != 0; // the same on every lane: a scalar branch
+#endif
         BPT(tc2);
 #ifdef SWD_BPPROF
         acc_cn += tc1 - tc0; acc_any += tc2 - tc1;
@@ -743,21 +924,28 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         const bool record = record_all || it >= max_iter - 4;
         // VN pass (osd_window.pyx:442-471).  (Reading the next VN's messages before this one's are written
         // was tried and is slower.)
-#pragma unroll
-        for (int i = 0; i < VF; ++i) {
-            if (i < nch) { // wave-uniform
+        static_assert(!(TIER && kFlagMerge), "the tiered pass reads its own messages");
+        // one node of the pass over its first KD positions (KD = DM unless TIER)
+        auto vn_one = [&](auto kd_tag, auto i_tag) {
+                constexpr int KD = decltype(kd_tag)::value, i = decltype(i_tag)::value;
                 const int idx = s.vtid + i * NT;
                 bool valid = idx < vcnt;
-                const int v = valid ? (FULL ? idx : (int)s.lv[idx]) : n;
+                int v;
+                if constexpr (!kNodeList) v = valid ? idx : n; else v = vnode[i];
                 if constexpr (SPARSE) valid = v < n;
-                double cc[DM], pre[DM];
+                double cc[KD], pre[KD];
                 uint32_t ad[DM];
-                c.get_ed(i, ad);
+                if (kFlagMerge && i == 0) {
 #pragma unroll
-                for (int k = 0; k < DM; ++k) cc[k] = swd_msg_at(s, ad[k]);
+                    for (int k = 0; k < KD; ++k) { ad[k] = ad0[k]; cc[k] = cc0[k]; }
+                } else {
+                    c.get_ed(i, ad);
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) cc[k] = swd_msg_at(s, ad[k]);
+                }
                 double temp = c.llr[i];
 #pragma unroll
-                for (int k = 0; k < DM; ++k) { pre[k] = temp; temp = temp + cc[k]; }
+                for (int k = 0; k < KD; ++k) { pre[k] = temp; temp = temp + cc[k]; }
                 if constexpr (ACC) {
                     if (it >= max_iter - 4) hs[i] = (it == max_iter - 4) ? temp : hs[i] + temp; // wave-uniform conditions
                 } else if constexpr (SPARSE) {
@@ -771,27 +959,63 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
                 double suf = 0.0;
 #pragma unroll
-                for (int k = DM - 1; k >= 0; --k) {
+                for (int k = KD - 1; k >= 0; --k) {
                     swd_msg_at(s, ad[k]) = pre[k] + suf;
                     suf = suf + cc[k];
                 }
                 s.msg[zeroslot] = 0.0; // re-arm
+#ifdef SWD_EXP_EXTRA_LDS // experiment: N more LDS reads per node and iteration (is the LDS pipeline what the iterations queue for?)
+                {
+                    double dx_[SWD_EXP_EXTRA_LDS];
+#pragma unroll
+                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) dx_[e_] = *(volatile double *)&s.msg[farslot];
+#pragma unroll
+                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) asm volatile("" :: "v"(dx_[e_]));
+                }
+#endif
+#ifdef SWD_EXP_EXTRA_VALU // experiment: N more vector instructions per node and iteration
+                {
+                    uint32_t vx_ = (uint32_t)v;
+#pragma unroll
+                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_VALU; ++e_) asm volatile("v_add_u32 %0, %0, %0" : "+v"(vx_));
+                }
+#endif
                 if (hd) {
 #pragma unroll
-                    for (int k2 = 0; k2 < (DM + 1) / 2; ++k2) {
+                    for (int k2 = 0; k2 < (KD + 1) / 2; ++k2) {
                         uint32_t pw = c.par[i][k2];
                         asm volatile("" : "+v"(pw));
                         if constexpr (PB) {
                             atomicXor((uint32_t *)(parb + (pw & 0xFFFCu)), 1u << ((pw & 3u) << 3));
-                            if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
+                            if (2 * k2 + 1 < KD) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
                         } else {
-                            atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << 2)), 1u);
-                            if (2 * k2 + 1 < DM) atomicXor((uint32_t *)(parb + ((pw >> 16) << 2)), 1u);
+                            constexpr int PS2 = 2 - VnCacheP<VF, DM, SH, PB>::par_shift; // (0: the halves are byte offsets already)
+                            atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << PS2)), 1u);
+                            if (2 * k2 + 1 < KD) atomicXor((uint32_t *)(parb + ((pw >> 16) << PS2)), 1u);
                         }
                     }
                 }
+        };
+        // TIER: the smallest multiple KD of the tier step >= the wave's largest live degree in this cache row (scalar branches)
+        auto vn_tier = [&](auto self, auto kd_tag, auto i_tag, int kcv) -> void {
+            constexpr int KD = decltype(kd_tag)::value;
+            if constexpr (KD >= DM) vn_one(std::integral_constant<int, DM>{}, i_tag);
+            else {
+                if (kcv <= KD) vn_one(kd_tag, i_tag);
+                else self(self, std::integral_constant<int, KD + SWD_TIER_STEP(DM)>{}, i_tag, kcv);
             }
-        }
+        };
+        auto vn_rows = [&](auto self, auto i_tag) -> void {
+            constexpr int i = decltype(i_tag)::value;
+            if constexpr (i < VF) {
+                if (i < nch) { // wave-uniform
+                    if constexpr (TIER) vn_tier(vn_tier, std::integral_constant<int, SWD_TIER_STEP(DM)>{}, i_tag, kcap[i]);
+                    else vn_one(std::integral_constant<int, DM>{}, i_tag);
+                }
+                self(self, std::integral_constant<int, i + 1>{});
+            }
+        };
+        vn_rows(vn_rows, std::integral_constant<int, 0>{});
         BPT(tc3);
         __syncthreads();
 #ifdef SWD_BPPROF
@@ -1228,6 +1452,9 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 // instructions per pivot -- overlaps the 9 x 40 of the update.  (osd0_block below: 3.4k cycles per pivot, wave 0
 // evaluating against T in LDS while 15 waves wait, then all threads rewriting T in LDS, two barriers per pivot.)
 #define SWD_LDS_AS __attribute__((address_space(3)))
+#ifndef SWD_OSD_RING
+#define SWD_OSD_RING 128 // row operations the column-form elimination can publish per round (ring entries in the exchange region)
+#endif
 // bit `rbit` of word `rw` (both wave-uniform) of a register-resident bit vector: a scalar branch per word instead of a select chain
 template <int WMC>
 __device__ __forceinline__ uint32_t osd_vec_bit(const uint64_t (&v)[WMC], int rw, int rbit) {
@@ -1253,6 +1480,7 @@ __device__ __forceinline__ void osd_vec_setbit(uint64_t (&v)[WMC], int rw, int r
     }
 }
 
+#ifdef SWD_OSD_COLS_V1 // round 2-4 form (one batch of 64 sorted columns per pair of barriers), kept for A/B builds
 template <int NT, int DM, int WMC>
 __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
                                          uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
@@ -1454,6 +1682,279 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
     *npiv_out = npiv;
     return ctl[4];
 }
+
+#else
+// Round 5: ROUNDS of up to four batches per pair of barriers.  What the instrumented build showed for the form above on the [[288,12,18]]
+// windows: of ~1.0 M cycles per elimination the resolver spends ~0.4 M evaluating its batches (54 LDS reads per lane whose
+// latencies the 128-VGPR allocation serialises) and another share in 47 x 2 workgroup barriers -- the scan walks ~3000 sorted columns
+// for its 576 pivots, and the ~2400 columns behind the first ~600 hold two or three pivots per batch.  Now three HELPER waves
+// (13, 14, 15: one on each SIMD the resolver does not use) evaluate the next three batches against the same mirror while the
+// resolver works on the first, follow the ring like the column waves do (a candidate column takes a row operation exactly like a
+// column of T: y ^= S if y[r]), and hand their reduced vectors over through LDS when the resolver reaches their batch: the
+// resolver evaluates only the first batch of a round, and the mirror refresh + two barriers come once per round.  A round ends
+// after four batches, when the ring (RING operations) could overflow in the next batch, or with the elimination.
+template <int NT, int DM, int WMC>
+__device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
+                                         uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
+                                         int *npiv_out, char *slotmem) {
+    constexpr int NBC = 64;      // columns per batch
+    constexpr int RING = SWD_OSD_RING; // row operations a round can publish (make_layout sizes the exchange region with the same constant)
+    constexpr int NHELP = 3;     // helper waves
+    static_assert(NT >= 1024 && WMC <= 16, "wave 0 resolves, nine of the waves 1..11 hold the columns, waves 13..15 help");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
+    constexpr int ES = (WMC + 2) & ~1; // words per ring entry: S, then pivot row | column within the round << 16 (16-byte multiples)
+    SWD_LDS_AS uint64_t *ringS = (SWD_LDS_AS uint64_t *)slotmem;                  // [RING][ES] the round's row operations
+    SWD_LDS_AS uint64_t *hbuf = ringS + RING * ES;                                // [WMC][64] hand-over of a helper's reduced vectors (word-major)
+    SWD_LDS_AS uint64_t *Pl = hbuf + WMC * NBC;                                   // [WMC] pivoted rows
+    // 0: published, 1: round closed, 2: elimination finished, 3: pivots so far, 4: row additions, 5: batch the resolver works on,
+    // 6: batch whose vectors lie in hbuf, 7: batches of the round, 8..11: operations published when batch b began
+    SWD_LDS_AS int *ctl = (SWD_LDS_AS int *)(Pl + WMC + 1);
+    volatile SWD_LDS_AS int *vctl = ctl;
+    const bool colwave = (wave & 3) != 0 && wave < 12;
+    const int helper = (wave >= 13 && wave <= 15) ? wave - 12 : 0; // helper h evaluates batch h of a round
+    const int jc = colwave ? (wave - 1 - (wave >> 2)) * 64 + lane : m; // the column of T this thread keeps
+    uint64_t col[WMC];
+#pragma unroll
+    for (int x = 0; x < WMC; ++x) col[x] = (jc < m && x == (jc >> 6)) ? (1ull << (jc & 63)) : 0ull;
+    if (tid < 16) ctl[tid] = 0;
+    if (tid < WMC) Pl[tid] = 0ull;
+    __syncthreads();
+    // the reduced vector of sorted column pc against the mirror (resolver: first batch of a round; helpers: the next ones)
+    auto evaluate = [&](int pb, uint64_t (&red)[WMC]) {
+        const int pc = pb + lane;
+        const bool cval = pc < n;
+        int rows[DM];
+        if (pb + NBC <= nst) { // uniform: whole batch inside the staged prefix
+#pragma unroll
+            for (int kk = 0; kk < DM; ++kk) rows[kk] = crows[pc * DM + kk];
+        } else {
+            const int v = cval ? (int)order[pc] : 0;
+            const int deg = cval ? (int)g.col_deg[v] : 0;
+#pragma unroll
+            for (int kk = 0; kk < DM; ++kk) rows[kk] = (kk < deg) ? (int)g.vn_row[kk * n + v] : 0xFFFF;
+        }
+#pragma unroll
+        for (int x = 0; x < WMC; ++x) {
+            red[x] = 0ull;
+            if (x < wm) { // uniform
+#pragma unroll
+                for (int kk = 0; kk < DM; ++kk) red[x] ^= (rows[kk] == 0xFFFF) ? 0ull : Tw[osd_tidx(rows[kk] == 0xFFFF ? 0 : rows[kk], x, m)];
+            }
+        }
+    };
+    // resolver state: lane x < WMC keeps word x of the pivoted-row mask and counts the unpivoted ones of the pivot columns there
+    // (a single wave issues one instruction of any kind per four cycles: the pivot search runs word-per-lane, not as scalar code)
+    uint64_t Pmine = 0;
+    int racc = 0;
+    int npiv = 0, p = 0;
+#ifdef SWD_OSDPROF // diagnostic build: cycles of the resolver (evaluation, hand-over waits, pivots), of a column wave (applying, waiting) and between the barriers
+    long long q_eval = 0, q_res = 0, q_app = 0, q_wait = 0, q_sync = 0, q_hand = 0, q0_;
+    int q_rounds = 0, q_batches = 0;
+#endif
+    for (;;) {
+        const int npiv0 = npiv, p0 = p;
+#ifdef SWD_OSDPROF
+        q0_ = clock64(); ++q_rounds;
+#endif
+        if (wave == 0) {
+            int used = 0, nbatch = 0; // operations published this round, batches begun
+            bool fin = false;
+            for (;;) {
+                uint64_t red[WMC];
+                if (nbatch == 0) evaluate(p, red);
+                else { // the helper's vectors, every operation of the round so far applied
+                    if (lane == 0) { ctl[8 + nbatch] = used; }
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) ctl[5] = nbatch;
+                    while (vctl[6] != nbatch) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) red[x] = (x < wm) ? hbuf[x * NBC + lane] : 0ull;
+                }
+                bool alive = p + lane < n;
+#ifdef SWD_OSDPROF
+                if (nbatch == 0) q_eval += clock64() - q0_; else q_hand += clock64() - q0_;
+                q0_ = clock64(); ++q_batches;
+#endif
+                uint64_t pb[WMC]; // the pivoted-row mask, every word in every lane (read back after each pivot, ahead of its use)
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) pb[x] = Pl[x];
+                while (npiv < rank) {
+                    uint32_t nz = 0;
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) {
+                        nz |= (uint32_t)red[x] & ~(uint32_t)pb[x];
+                        nz |= (uint32_t)(red[x] >> 32) & ~(uint32_t)(pb[x] >> 32);
+                    }
+                    const unsigned long long bal = __ballot(alive && nz != 0u);
+                    if (bal == 0ull) break; // every remaining column of the batch is dependent
+                    const int cs = __ffsll((long long)bal) - 1;
+                    uint32_t lz = 0;
+                    asm volatile("" : "+v"(lz)); // the lane number, recomputed here: kept across the loop it is spilled and reloaded per pivot
+                    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, lz));
+                    SWD_LDS_AS uint64_t *ent = ringS + used * ES;
+                    if (ln == cs) { // the pivot column's lane publishes its reduced vector (LDS operations of a wave execute in order)
+#pragma unroll
+                        for (int x = 0; x < WMC; ++x) ent[x] = red[x];
+                    }
+                    asm volatile("" ::: "memory");
+                    // one round trip: the vector a word per lane (pivot search) and every word in every lane (the update below)
+                    const uint64_t wv = ent[ln < WMC ? ln : 0];
+                    uint64_t S[WMC];
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) S[x] = ent[x];
+                    const uint64_t c = (ln < WMC) ? (wv & ~Pmine) : 0ull; // its ones in unpivoted rows
+                    const unsigned long long balc = __ballot(c != 0ull);
+                    const int fx = __ffsll((long long)balc) - 1;
+                    const int bit = __builtin_amdgcn_readlane(__ffsll((long long)c) - 1, fx);
+                    racc += __popcll(c); // row additions the reference's LU would apply: unpivoted rows with a one in this column (the pivot itself is taken off at the end)
+                    if (ln == fx) {
+                        __hip_atomic_fetch_and(&ent[fx], ~(1ull << bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(&Pl[fx], 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        Pmine |= 1ull << bit;
+                    }
+                    if (ln == 0) ent[WMC] = (uint64_t)(uint32_t)((fx * 64 + bit) | ((nbatch * NBC + cs) << 16));
+                    asm volatile("" ::: "memory"); // a wave's LDS operations execute in order: the count follows the entry
+                    if (ln == 0) ctl[0] = used + 1;
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) pb[x] = Pl[x]; // for the next pivot
+                    // the batch's later columns under the same row operation: y ^= S if y[r]; S here still has bit r, which y keeps
+                    const uint32_t ybit = osd_vec_bit<WMC>(red, fx, bit);
+                    if (ln <= cs) alive = false;
+                    else if (alive && ybit) {
+#pragma unroll
+                        for (int x = 0; x < WMC; ++x) red[x] ^= S[x];
+                        osd_vec_setbit<WMC>(red, fx, bit);
+                    }
+                    ++npiv; ++used;
+                }
+                p += NBC; ++nbatch;
+#ifdef SWD_OSDPROF
+                q_res += clock64() - q0_; q0_ = clock64();
+#endif
+                fin = !(p < n && npiv < rank);
+                if (fin || nbatch > NHELP || used + NBC > RING) break;
+            }
+            int rsum = racc;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) rsum += __shfl_xor(rsum, d, 64);
+            if (lane == 0) {
+                ctl[3] = npiv; ctl[4] = rsum - npiv; ctl[7] = nbatch;
+                ctl[2] = fin ? 1 : 0;
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) ctl[1] = 1;
+        } else if (colwave) {
+            int done_ops = 0;
+            for (;;) {
+                const int closed = vctl[1]; // read before the count: a closed round's count is final
+                const int avail = vctl[0];
+#ifdef SWD_OSDPROF
+                q_wait += clock64() - q0_; q0_ = clock64();
+#endif
+                while (done_ops < avail) {
+                    SWD_LDS_AS const uint64_t *ent = ringS + done_ops * ES;
+                    uint64_t S[WMC];
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) S[x] = ent[x];
+                    const int r = __builtin_amdgcn_readfirstlane((int)(uint32_t)ent[WMC]) & 0xFFFF;
+                    const int rw = r >> 6, rbit = r & 63;
+                    if (osd_vec_bit<WMC>(col, rw, rbit)) {
+#pragma unroll
+                        for (int x = 0; x < WMC; ++x) col[x] ^= S[x];
+                    }
+                    ++done_ops;
+                }
+#ifdef SWD_OSDPROF
+                q_app += clock64() - q0_; q0_ = clock64();
+#endif
+                if (closed) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else if (helper && p + helper * NBC < n) {
+            // batch `helper` of this round: evaluated against the mirror of the round's start, then every operation the resolver
+            // publishes before it reaches this batch; handed over when it does; dropped when the round ends first
+            uint64_t red[WMC];
+            evaluate(p + helper * NBC, red);
+            int done_ops = 0;
+            for (;;) {
+                const int closed = vctl[1];
+                const int cur = vctl[5];     // (read before the bound: bst is written first)
+                const int target = (cur >= helper) ? vctl[8 + helper] : vctl[0];
+                asm volatile("" ::: "memory");
+                while (done_ops < target) {
+                    SWD_LDS_AS const uint64_t *ent = ringS + done_ops * ES;
+                    uint64_t S[WMC];
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) S[x] = ent[x];
+                    const int r = __builtin_amdgcn_readfirstlane((int)(uint32_t)ent[WMC]) & 0xFFFF;
+                    const int rw = r >> 6, rbit = r & 63;
+                    if (osd_vec_bit<WMC>(red, rw, rbit)) {
+#pragma unroll
+                        for (int x = 0; x < WMC; ++x) red[x] ^= S[x];
+                    }
+                    ++done_ops;
+                }
+                if (cur >= helper) { // (cur >= helper implies target = the operations of the batches before this one, all applied now)
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x)
+                        if (x < wm) hbuf[x * NBC + lane] = red[x];
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) ctl[6] = helper; // (a wave's LDS operations execute in order)
+                    break;
+                }
+                if (closed) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads(); // the round's row operations are in every column; ctl[] is final
+        const int fin = ctl[2];
+        npiv = ctl[3];
+        p = p0 + NBC * ctl[7];
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[5] = 0; ctl[6] = 0; } // nobody reads these four between the barriers
+        if (tid >= 64 && tid - 64 < npiv - npiv0) { // the round's pivots (another wave than the resolver looks the columns up)
+            const int e = (int)(uint32_t)ringS[(tid - 64) * ES + WMC];
+            piv_col[npiv0 + tid - 64] = order[p0 + (int)((uint32_t)e >> 16)];
+            piv_row[npiv0 + tid - 64] = (uint16_t)(e & 0xFFFF);
+        }
+        if (jc < m) {
+#pragma unroll
+            for (int x = 0; x < WMC; ++x)
+                if (x < wm) Tw[osd_tidx(jc, x, m)] = col[x]; // the mirror (after the last round: what the higher-order sweep reads)
+        }
+        if (tid < wm) Sbuf[tid] = 0ull; // (used after the last round)
+        __syncthreads();
+#ifdef SWD_OSDPROF
+        q_sync += clock64() - q0_;
+        if (fin && (tid == 0 || tid == 64 || tid == 13 * 64) && (blockIdx.x & 63) == 0)
+            printf("osdprof cols2 thread %d: rounds %d batches %d pivots %d | resolver: evaluation %lld hand-over %lld resolve %lld | column wave: apply %lld wait %lld | rest of the round %lld cycles\n",
+                   tid, q_rounds, q_batches, npiv, q_eval, q_hand, q_res, q_app, q_wait, q_sync);
+#endif
+        if (fin) break;
+    }
+    // y = T * s (s in original row order)
+    const bool on = jc < m && synd_b[jc < m ? jc : 0] != 0;
+    if (colwave) {
+#pragma unroll
+        for (int x = 0; x < WMC; ++x) {
+            if (x < wm) { // uniform
+                uint64_t acc = on ? col[x] : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+                if (lane == 0 && acc) atomicXor((unsigned long long *)&Sbuf[x], (unsigned long long)acc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npiv; i += NT) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+    }
+    *npiv_out = npiv;
+    return ctl[4];
+}
+#endif // SWD_OSD_COLS_V1
 
 // osd0_wave for m <= 256 (wm <= 4): the transform matrix lives in registers -- lane l owns columns
 // l, l+64, l+128, l+192 of T, four words each -- and LDS only holds a mirror that the column
@@ -1957,6 +2458,11 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
                               const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map) {
     constexpr bool DIET = SWD_P16(NT); // the tuned kernels' LDS forms (decided-node bits, 48-bit live masks, no copy of the check degrees)
     if constexpr (DIET) s.lm_m = (L.off_par - L.off_livemask < 8 * g.m) ? g.m : 0; // m if the masks are stored in the 48-bit form
+    // Tuned kernels: the parity WORDS of the iterations lie over the live masks, which nothing reads while bp_run is running (the full-
+    // graph caches never look at them, the shortening step rebuilds them from scratch, the shortened graph's caches are loaded before
+    // its iterations start and the OSD does not use them): (m + 1) x 4 <= m x 6 bytes.  Round 4 kept one parity BYTE per check to fit
+    // three workgroups per CU, which cost ~5 address / mask instructions per flip in the hottest loop (a flip is now one add + ds_xor).
+    if constexpr (DIET) s.par = (uint32_t *)s.livemask;
     const int tid = threadIdx.x;
     const int m = g.m, n = g.n;
 #pragma unroll
@@ -1966,8 +2472,10 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // kernels of up to 256 threads: the cache's loads are in flight during the reset loops (headline 9.95 -> 9.84 ms per launch at
     // order 0; the 1024-thread kernels lose by it -- [[288]] 63.2 -> 64.0 ms -- and load where they always did)
     constexpr bool kSplitLoad = NT <= SWD_TUNED_NT;
+    constexpr bool kFullSorted = SWD_FULL_SORTED != 0; // the full-graph phase in the graph's listed order, tiered variable-node pass
+    [[maybe_unused]] int kcf[VF];
     [[maybe_unused]] VnRaw<NT, kSplitLoad ? VF : 1, DM> vraw;
-    if constexpr (kSplitLoad) vn_cache_issue<NT, VF, DM>(g, s, vraw);
+    if constexpr (kSplitLoad) vn_cache_issue<NT, VF, DM, kFullSorted>(g, s, vraw);
     // reset (osd_window.pyx:288-303)
     for (int l = tid; l < m; l += NT) {
         const int d = g.row_deg[l];
@@ -1982,12 +2490,14 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
     // the tuned kernels use the packed caches and their overloads of the BP routines: byte offsets + parity bytes up to 256
     // threads, slot numbers + parity words in the 1024-thread kernels
-    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM>, VnCacheP<VF, DM, 3, false>> vc;
+    std::conditional_t<SWD_P16(NT), VnCacheP<VF, DM, 0, false>, VnCacheP<VF, DM, 3, false>> vc;
 #ifdef SWD_INITPROF
     const long long ip0 = wall_clock64();
 #endif
-    if constexpr (kSplitLoad) vn_cache_pack<NT, VF, DM>(g, s, vraw, vc);
-    else vn_cache_load<NT, VF, DM, true>(g, s, n, vc);
+    if constexpr (kSplitLoad) {
+        vn_cache_pack<NT, VF, DM>(g, s, vraw, vc);
+        if constexpr (kFullSorted) vn_row_caps<NT, VF, DM>(g, s, vraw.ev, kcf);
+    } else vn_cache_load<NT, VF, DM, true, false, kFullSorted>(g, s, n, vc, nullptr, kFullSorted ? &kcf : nullptr);
 #ifdef SWD_INITPROF
     asm volatile("" : "+v"(vc.edp[VF - 1][0]), "+v"(vc.llr[0]));
     const long long ip1 = wall_clock64();
@@ -2023,7 +2533,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     double hs[VF]; // HACC: summed posterior history of this thread's variable nodes
 #pragma unroll
     for (int i = 0; i < VF; ++i) hs[i] = 0.0;
-    R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs);
+    R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, kFullSorted>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs, nullptr, false,
+                                                                        kFullSorted ? kcf : nullptr);
     R.pre_it = it;
     R.t[2] = wall_clock64();
     if (R.conv) {
@@ -2040,8 +2551,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     if constexpr (HACC) {
 #pragma unroll
         for (int i = 0; i < VF; ++i) { // the keys come straight from the accumulators of the owning thread
-            const int v = s.vtid + i * NT;
-            if (v < n) { key[v] = f2key(hs[i]); idx[v] = (uint16_t)v; }
+            const int li = s.vtid + i * NT;
+            if (li < n) { const int v = kFullSorted ? (int)g.vperm[li] : li; key[v] = f2key(hs[i]); idx[v] = (uint16_t)v; }
         }
         for (int v = n + tid; v < L.npad; v += NT) { key[v] = ~0ull; idx[v] = 0xFFFF; }
     } else {
@@ -2184,15 +2695,22 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // CN pass costs its largest degree, and after shortening the degrees are very uneven
     int *dhist = (int *)(s.scratch + L.off_cord);      // [65]
     uint16_t *cord = (uint16_t *)(dhist + 66);          // [m]
+    // Sorted form of the shortened graph (tuned kernels, SWD_POST_SORTED): the live nodes are listed by decreasing live degree -- in
+    // tiers of two positions, index order inside a tier -- so that the nodes a wave serves in one cache row need about the same number
+    // of positions; the live degrees are counted from the check side (one LDS atomic per live edge) into a byte per node that lies
+    // over the dead backup of the peeling step.
+    // (SWD_POST_SORTED bit 0: the tuned kernels of up to 256 threads, bit 1: the LDS-resident 1024-thread kernels)
+    constexpr bool kSorted = (SWD_POST_SORTED & (SWD_P16(NT) ? 1 : (SWD_OSDW_TUNED && NT >= 1024 ? 2 : 0))) != 0 && !BIG && VF > 2;
+    bool sorted = false;
+    if constexpr (kSorted) sorted = L.post_lds != 0 && uselist && g.new_n <= 2 * NT;
+    uint32_t *deg32 = (uint32_t *)(s.scratch + L.off_bak); // [n] bytes, four per word
     for (int i = tid; i < 65; i += NT) dhist[i] = 0;
+    if constexpr (kSorted) {
+        if (sorted)
+            for (int i = tid; i < (n + 3) / 4; i += NT) deg32[i] = 0u;
+    }
+    __syncthreads(); // the histogram (and the degree bytes) are zero before the first atomic below
     {
-        const int ch = (n + NT - 1) / NT;
-        const int v0 = tid * ch, v1 = min(n, v0 + ch);
-        int cnt = 0;
-        for (int v = v0; v < v1; ++v) cnt += vn_decided<DIET>(s, v) ? 0 : 1;
-        int pos = block_exscan<NT>(cnt, s, nlive);
-        for (int v = v0; v < v1; ++v)
-            if (!vn_decided<DIET>(s, v)) s.lv[pos++] = (uint16_t)v;
         int lc = 0, le = 0;
         for (int l = tid; l < m; l += NT)
             if (s.cn_val[l] >= 0) {
@@ -2205,11 +2723,61 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
                 while (mk) {
                     const int j = __ffsll((long long)mk) - 1;
                     mk &= mk - 1;
-                    s.lslot[k * m + l] = (uint16_t)(s.jptr[j] + l);
+                    const int slot = s.jptr[j] + l;
+                    s.lslot[k * m + l] = (uint16_t)slot;
+                    if constexpr (kSorted) {
+                        if (sorted) { const int v = rc[slot]; atomicAdd(&deg32[v >> 2], 1u << (8 * (v & 3))); }
+                    }
                     ++k;
                 }
             }
         if (lc) { atomicAdd(&s.scal[2], lc); atomicAdd(&s.scal[3], le); }
+        const int ch = (n + NT - 1) / NT;
+        const int v0 = tid * ch, v1 = min(n, v0 + ch);
+        bool plain = true;
+        if constexpr (kSorted) {
+            if (sorted) {
+                plain = false;
+                __syncthreads(); // the degrees are complete
+                // tiers of SWD_TIER_STEP(DM) positions: tier t = 1 .. NTIER holds the nodes whose live degree rounds up to t x step; the tier
+                // counts share prefix sums, FB bits each (a tier holds at most new_n <= 2 NT nodes), FPI of them per int
+                constexpr int TS = SWD_TIER_STEP(DM), NTIER = (DM + TS - 1) / TS;
+                constexpr int FB = (2 * NT < 1024) ? 10 : 12, FPI = (2 * NT < 1024) ? 3 : 2, FM = (1 << FB) - 1, NI = (NTIER + FPI - 1) / FPI;
+                const uint8_t *deg8 = (const uint8_t *)deg32;
+                auto tier_q = [&](int v) { const int d = deg8[v]; const int t = min(max((d + TS - 1) / TS, 1), NTIER); return NTIER - t; }; // 0 = the heaviest tier
+                int cnt[NI], pos[NI], tot[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) cnt[j] = 0;
+                for (int v = v0; v < v1; ++v)
+                    if (!vn_decided<DIET>(s, v)) {
+                        const int q = tier_q(v);
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) cnt[j] += (q / FPI == j) ? (1 << (FB * (q % FPI))) : 0;
+                    }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) pos[j] = block_exscan<NT>(cnt[j], s, tot[j]);
+                int base[NTIER], run = 0;
+#pragma unroll
+                for (int q = 0; q < NTIER; ++q) { base[q] = run; run += (tot[q / FPI] >> (FB * (q % FPI))) & FM; }
+                nlive = run;
+                for (int v = v0; v < v1; ++v)
+                    if (!vn_decided<DIET>(s, v)) {
+                        const int q = tier_q(v);
+                        int p = 0;
+#pragma unroll
+                        for (int qq = 0; qq < NTIER; ++qq)
+                            if (qq == q) { p = base[qq] + ((pos[qq / FPI] >> (FB * (qq % FPI))) & FM); pos[qq / FPI] += 1 << (FB * (qq % FPI)); }
+                        s.lv[p] = (uint16_t)v;
+                    }
+            }
+        }
+        if (plain) {
+            int cnt = 0;
+            for (int v = v0; v < v1; ++v) cnt += vn_decided<DIET>(s, v) ? 0 : 1;
+            int pos = block_exscan<NT>(cnt, s, nlive);
+            for (int v = v0; v < v1; ++v)
+                if (!vn_decided<DIET>(s, v)) s.lv[pos++] = (uint16_t)v;
+        }
     }
     __syncthreads();
 #ifdef SWD_SHPROF
@@ -2229,8 +2797,27 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // the post phase proper, for a register cache of any depth: caches, (re)initialised messages, the iterations
     // (renum_tag: compile-time twin of `renum`, so that a BIG kernel's post-phase message pointer is an LDS pointer on every path
     // that reaches the iterations -- ds_read / ds_write instead of flat accesses)
-    auto run_post = [&](auto &vcx, auto &cnx, double *hsx, auto vfx, auto kgx, auto renum_tag) {
+    auto run_post = [&](auto &vcx, auto &cnx, double *hsx, auto vfx, auto kgx, auto renum_tag, auto sorted_tag) {
         constexpr int VFX = decltype(vfx)::value, KGX = decltype(kgx)::value;
+        if constexpr (decltype(sorted_tag)::value) { // sorted form: compacted caches, renumbered cells, tiered variable-node pass
+            int kc[VFX];
+            uint16_t *remap = rc;
+            gp.E = g.D * nlive;
+            vn_cache_load_compact<NT, VFX, DM>(gp, s, nlive, vcx, remap, kc);
+            __syncthreads();
+            for (int l = tid; l < m; l += NT)
+                if (s.cn_val[l] >= 0) {
+                    const int d = s.cn_deg[l];
+                    for (int k = 0; k < d; ++k) s.lslot[k * m + l] = remap[s.lslot[k * m + l]];
+                }
+            __syncthreads();
+            cn_cache_load<NT, KGX, false>(gp, s, uselist, clc, csub, cgrp, cnx);
+            __syncthreads(); // every lane has read its slot list before the messages are re-initialised
+            bp_init<VFX, DM>(s, vcx);
+            __syncthreads();
+            R.t[4] = wall_clock64();
+            return bp_run<NT, VFX, DM, KGX, false, false, HACC, false, true>(gp, P, s, P.post_iter, nlive, vcx, cnx, hist_b, it, P.alpha, false, hsx, nullptr, false, kc);
+        } else
         if constexpr (kRenum && decltype(renum_tag)::value) {
             {
                 uint16_t *remap = rc;
@@ -2259,32 +2846,43 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // 8 VF + 2 KG, its check pass is unrolled KGP times instead of KG times, and no reload sits in it.
     constexpr int KGP = (SWD_POST_KGP > 0 && SWD_POST_KGP < KG) ? SWD_POST_KGP : KG;
     const bool small_ok = g.new_n <= 2 * NT && (KGP == KG || s.iaux[0] <= 4 * KGP);
-    using VC2 = std::conditional_t<SWD_P16(NT), VnCacheP<2, DM>, VnCacheP<2, DM, 3, false>>;
+    using VC2 = std::conditional_t<SWD_P16(NT), VnCacheP<2, DM, 0, false>, VnCacheP<2, DM, 3, false>>;
     using CC2 = std::conditional_t<SWD_P16(NT), CnCacheP<KGP>, CnCacheP<KGP, 3>>;
     // (BIG kernels: the host sets post_lds only for new_n <= 2 NT, so the renumbered form always runs at depth 2)
     bool post_done = false;
+    if constexpr (kSorted) {
+        if (sorted && small_ok) {
+            VC2 vc2; CC2 cn2;
+            double hs2[2] = {0.0, 0.0};
+            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::false_type{}, std::true_type{});
+            hs[0] = hs2[0]; hs[1] = hs2[1];
+            post_done = true;
+        }
+    }
+    if (post_done) {
+    } else
     if constexpr (BIG && VF > 2) {
         if (renum && small_ok) {
             VC2 vc2; CC2 cn2;
             double hs2[2] = {0.0, 0.0};
-            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::true_type{});
+            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::true_type{}, std::false_type{});
             hs[0] = hs2[0]; hs[1] = hs2[1];
             post_done = true;
         }
     } else if constexpr (kRenum) {
-        if (renum) { R.conv = run_post(vc, cn, hs, std::integral_constant<int, VF>{}, std::integral_constant<int, KG>{}, std::true_type{}); post_done = true; }
+        if (renum) { R.conv = run_post(vc, cn, hs, std::integral_constant<int, VF>{}, std::integral_constant<int, KG>{}, std::true_type{}, std::false_type{}); post_done = true; }
     } else if constexpr ((SWD_POST_DEPTH2 & (NT >= 1024 ? 1 : 2)) != 0 && VF > 2) {
         // the LDS-resident kernels: bit 0 = the 1024-thread ones ([[288]] (4,1): 61.9 -> 60.5 ms per launch), bit 1 = those of up to
         // 256 threads (headline, order 0: 10.25 -> 9.7 ms per launch); both on in the production build
         if (small_ok) {
             VC2 vc2; CC2 cn2;
             double hs2[2] = {0.0, 0.0};
-            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::false_type{});
+            R.conv = run_post(vc2, cn2, hs2, std::integral_constant<int, 2>{}, std::integral_constant<int, KGP>{}, std::false_type{}, std::false_type{});
             hs[0] = hs2[0]; hs[1] = hs2[1];
             post_done = true;
         }
     }
-    if (!post_done) R.conv = run_post(vc, cn, hs, std::integral_constant<int, VF>{}, std::integral_constant<int, KG>{}, std::false_type{});
+    if (!post_done) R.conv = run_post(vc, cn, hs, std::integral_constant<int, VF>{}, std::integral_constant<int, KG>{}, std::false_type{}, std::false_type{});
 #ifdef SWD_SHPROF
     if (tid == 0) { s.scal[20] = (int)(sh0 - R.t[3]); s.scal[21] = (int)(sh1 - sh0); s.scal[22] = (int)(sh2 - sh1); s.scal[23] = (int)(R.t[4] - sh2); }
 #endif
