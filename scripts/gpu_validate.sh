@@ -11,6 +11,7 @@ mkdir -p gpurun_out/$TAG
 (timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15) > gpurun_out/$TAG/suite.log 2>&1
 (timeout 4000 bash scripts/fuzz_campaign.sh 7000 $ROUNDS) > gpurun_out/$TAG/fuzz_campaign.log 2>&1
 timeout 900 bash scripts/profile_all.sh $TAG headline > gpurun_out/$TAG/prof_headline.log 2>&1
+timeout 600 bash scripts/profile_stream.sh $TAG headline > gpurun_out/$TAG/prof_stream.log 2>&1
 timeout 900 bash scripts/profile_all.sh $TAG bb288 --steps 6 > gpurun_out/$TAG/prof_bb288.log 2>&1
 timeout 900 bash scripts/profile_all.sh $TAG gdg --steps 8 > gpurun_out/$TAG/prof_gdg.log 2>&1
 timeout 900 bash scripts/profile_all.sh $TAG gdg64 --steps 6 > gpurun_out/$TAG/prof_gdg64.log 2>&1

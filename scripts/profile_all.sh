@@ -7,7 +7,7 @@ TAG=${1:-r04}; WL=${2:-headline}; shift $(( $# < 2 ? $# : 2 ))
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${TAG}_${WL}
 cd /tmp && export TMPDIR=/tmp
-ARGS="--workload $WL --no-cpu-baseline --no-order0 --no-stream $*"  # (one launch at a time: the durations in the trace are those of single launches)
+ARGS="--workload $WL --no-cpu-baseline --no-order0 --no-stream --no-other-workloads $*"  # (one launch at a time: the durations in the trace are those of single launches)
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $ARGS > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 > $O/fetch.log 2>&1

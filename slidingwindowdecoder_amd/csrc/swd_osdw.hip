@@ -98,7 +98,7 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     // staged column table, which becomes the old-slot -> cell table; SWD_NO_POST_SORTED=1 in the environment keeps the round-4 form)
     // (diet kernels keep cell BYTE offsets in 16 bits, the 1024-thread osd_window kernels cell numbers)
     if (kind == 0 && !big && !getenv("SWD_NO_POST_SORTED") && L.off_lslot == 0 && (g.D * new_n + 1 + 2 * (nt / 64)) * 8 <= L.off_rc &&
-        g.D * new_n + 1 + 2 * (nt / 64) <= (diet ? 8191 : 65535) && (diet || nt >= 1024))
+        g.D * new_n + 1 + 2 * (nt / 64) <= (diet ? 8191 : 65535) && (diet || nt >= 512))
         L.post_lds = 1;
     L.total = align_up(o, 16);
     return 0;

@@ -54,6 +54,8 @@
 // live edges are moved to the front of its cache, the message cells are renumbered one column per listed node (cell(k, i) = k x nlive + i)
 // and a wave's variable-node pass skips the positions beyond the largest live degree among its nodes (in steps of two) -- the
 // iterations are LDS-bound and the live degree averages 2.65 of 6 positions.
+// (bit 2, the large-graph kernels: measured on the 936 x 8784 model, gpurun_out/r05q -- 3.54 against 3.67 us per iteration of the shortened
+// graph, paid for by 26 us more in the shortening step with its degree bytes and lists in HBM: no net gain, off)
 #ifndef SWD_POST_SORTED
 #define SWD_POST_SORTED 3
 #endif
@@ -62,6 +64,8 @@
 // Measured on the headline (gpurun_out/r05l): bit-exact, 30 % fewer message positions in the full-graph variable-node pass (7296 of
 // 10368 per iteration of the [[144,12,12]] mid window) -- and 10.01 ms per launch against 9.80: the three bodies per cache row, the row
 // caps and the node numbers cost the check pass six more instructions per group of four.  Off.
+// (bit 1, the large-graph kernels, whose full-graph messages live in HBM: 40.1 against 33.9 us per iteration of the 936 x 8784 model --
+// the listed order scatters what were neighbouring 8-byte accesses; off too)
 #ifndef SWD_FULL_SORTED
 #define SWD_FULL_SORTED 0
 #endif
@@ -658,6 +662,9 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 #pragma unroll 1
             for (int ci = 0; ci < 8; ++ci) {
                 const int Tc = cand[ci];
+#ifdef SWD_CN_MIN_T // experiment: no walk bound below this (fewer, fuller waves in the check pass of the shortened graph)
+                if (Tc < SWD_CN_MIN_T) continue;
+#endif
                 int need = c0 * (d <= Tc ? 1 : (d <= 2 * Tc ? 2 : 4));
                 int q = (d > 2 * Tc) ? c0 : 0, pr = (d > Tc && d <= 2 * Tc) ? c0 : 0;
 #pragma unroll
@@ -2472,7 +2479,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // kernels of up to 256 threads: the cache's loads are in flight during the reset loops (headline 9.95 -> 9.84 ms per launch at
     // order 0; the 1024-thread kernels lose by it -- [[288]] 63.2 -> 64.0 ms -- and load where they always did)
     constexpr bool kSplitLoad = NT <= SWD_TUNED_NT;
-    constexpr bool kFullSorted = SWD_FULL_SORTED != 0; // the full-graph phase in the graph's listed order, tiered variable-node pass
+    // the full-graph phase in the graph's listed order, tiered variable-node pass (bit 0: the LDS-resident kernels, bit 1: the large-graph ones)
+    constexpr bool kFullSorted = (SWD_FULL_SORTED & (BIG ? 2 : 1)) != 0;
     [[maybe_unused]] int kcf[VF];
     [[maybe_unused]] VnRaw<NT, kSplitLoad ? VF : 1, DM> vraw;
     if constexpr (kSplitLoad) vn_cache_issue<NT, VF, DM, kFullSorted>(g, s, vraw);
@@ -2699,8 +2707,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // tiers of two positions, index order inside a tier -- so that the nodes a wave serves in one cache row need about the same number
     // of positions; the live degrees are counted from the check side (one LDS atomic per live edge) into a byte per node that lies
     // over the dead backup of the peeling step.
-    // (SWD_POST_SORTED bit 0: the tuned kernels of up to 256 threads, bit 1: the LDS-resident 1024-thread kernels)
-    constexpr bool kSorted = (SWD_POST_SORTED & (SWD_P16(NT) ? 1 : (SWD_OSDW_TUNED && NT >= 1024 ? 2 : 0))) != 0 && !BIG && VF > 2;
+    // (SWD_POST_SORTED bit 0: the tuned kernels of up to 256 threads, bit 1: the LDS-resident 1024-thread kernels, bit 2: the large-graph
+    // kernels, whose shortened graph lives in the LDS region post_lds names)
+    constexpr bool kSorted = (SWD_POST_SORTED & (BIG ? 4 : (SWD_P16(NT) ? 1 : (SWD_OSDW_TUNED && NT >= 512 ? 2 : 0)))) != 0 && VF > 2;
     bool sorted = false;
     if constexpr (kSorted) sorted = L.post_lds != 0 && uselist && g.new_n <= 2 * NT;
     uint32_t *deg32 = (uint32_t *)(s.scratch + L.off_bak); // [n] bytes, four per word
@@ -2803,6 +2812,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
             int kc[VFX];
             uint16_t *remap = rc;
             gp.E = g.D * nlive;
+            if constexpr (BIG) s.msg = (double *)(s.hard - L.off_hard + L.off_pmsg); // the LDS block starts off_hard bytes below s.hard
             vn_cache_load_compact<NT, VFX, DM>(gp, s, nlive, vcx, remap, kc);
             __syncthreads();
             for (int l = tid; l < m; l += NT)
@@ -3048,7 +3058,7 @@ __global__ void __launch_bounds__(NT) shot_order_kernel(const uint32_t *wt, int 
 }
 
 template <int NT, int VF, int DM, int KG, int KIND, bool SF = false, bool BIG = false, int VFP = VF>
-__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : ((SWD_OSDW_TUNED && NT == 512 && SWD_TUNED_NT >= 512 && (KIND == 0 || KIND == 3)) ? 6 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2)))) pipeline_kernel(const SwdPipeArgs a) {
+__global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : (NT == 640 ? 3 : ((SWD_OSDW_TUNED && NT == 512 && SWD_TUNED_NT >= 512 && (KIND == 0 || KIND == 3)) ? 6 : ((SWD_OSDW_TUNED && NT == 256 && KG <= 12 && (KIND == 0 || KIND == 3)) ? 3 : 2))))) pipeline_kernel(const SwdPipeArgs a) {
     static_assert(!BIG || KIND == 0 || KIND == 3 || KIND == 1 || KIND == 7, "the HBM-resident scratch region exists for the osd_window kernels and for the guessing decoders' serial walk / ticket-scheduled ensemble");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;

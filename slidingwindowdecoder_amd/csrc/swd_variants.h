@@ -13,6 +13,8 @@
 #define SWD_VARIANTS(X) X(256, 7, 8, 16, 0, 1, 1, 0)
 #elif defined(SWD_EXP_288_512) // experiment (round 5): [[288,12,18]] windows of up to 512 checks ((3,1): 432 x 3456) on 512 threads / 256 VGPRs
 #define SWD_VARIANTS(X) X(512, 8, 6, 9, 0, 0, 0, 1) X(1024, 5, 6, 6, 1, 0, 0, 1) X(1024, 5, 6, 9, 0, 1, 0, 1)
+#elif defined(SWD_EXP_288_640) // experiment (round 5): the [[288,12,18]] (4,1) windows (576 checks) on 640 threads = ten waves, one check per thread, 168 VGPRs
+#define SWD_VARIANTS(X) X(640, 8, 6, 9, 0, 0, 0, 1) X(1024, 5, 6, 6, 1, 0, 0, 1) X(1024, 5, 6, 9, 0, 1, 0, 1)
 #elif defined(SWD_BB288_ONLY) // development builds: only the [[288,12,18]] kernels
 #define SWD_VARIANTS(X) X(1024, 5, 6, 6, 1, 0, 0, 1) X(1024, 5, 6, 9, 0, 1, 0, 1)
 #else
