@@ -19,6 +19,9 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     L.off_aux = align_up(npad * 10, 16);
     int osd_bytes = align_up(L.off_aux + m * wm * 8 + wm * 8 + g.rank * 4 + n * 2 + 16, 16);
     const int osd_bytes_at_aux = osd_bytes; // end of the arrays that start at off_aux (the higher-order sweep's may follow)
+    // ring of row operations of the four-wave elimination (osd0_quad: m <= 256, at least four waves, scratch region in LDS)
+    L.off_oring = -1;
+    if (wm <= 4 && nt >= 256 && !big) { L.off_oring = osd_bytes; osd_bytes += align_up(SWD_QUAD_RING_BYTES, 16); }
     // higher-order OSD arrays: over the dead sort keys when they fit there, else after the OSD-0 arrays
     // candidates evaluated concurrently: as many threads as still let the sweep's arrays lie over the dead sort keys (at least 256):
     // [[288]] (4,1) windows, OSD-CS 10: 621 candidates in one round of 640 threads instead of three rounds of 256

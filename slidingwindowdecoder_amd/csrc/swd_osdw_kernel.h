@@ -97,6 +97,7 @@ struct SwdLdsLayout {
     int32_t off_bak;   // inside scratch: state backup of the parallel peel (10 m + 2 n bytes)
     int32_t off_hs;    // inside scratch: f64 hs[n], summed posterior history of the live VNs after a failed post phase (HACC kernels)
     int32_t off_oslot; // inside scratch (tail of the sort keys): exchange slots of the column-form elimination (osd0_cols), -1 if unused
+    int32_t off_oring; // inside scratch (behind the OSD-0 arrays): ring of row operations of the four-wave elimination (osd0_quad), -1 if unused
     // Large graphs (kernels instantiated with BIG, swd_kernels_k5.hip): the scratch region -- messages, sort keys, staged lists,
     // OSD arrays -- lives in HBM, big_scratch bytes per workgroup, and every other offset above (off_livemask ... off_misc, total)
     // is relative to the workgroup's LDS, which then only holds the per-check / per-variable-node state.  0: everything in LDS.
@@ -1459,6 +1460,12 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 // instructions per pivot -- overlaps the 9 x 40 of the update.  (osd0_block below: 3.4k cycles per pivot, wave 0
 // evaluating against T in LDS while 15 waves wait, then all threads rewriting T in LDS, two barriers per pivot.)
 #define SWD_LDS_AS __attribute__((address_space(3)))
+#ifndef SWD_OSD_QUAD
+#define SWD_OSD_QUAD 1 // m <= 256 on at least four waves: the elimination with the transform matrix on the other waves (osd0_quad)
+#endif
+#ifndef SWD_SERIAL_PRIO
+#define SWD_SERIAL_PRIO 0 // s_setprio of a wave the rest of its workgroup waits for (single-wave eliminations, the column form's resolver)
+#endif
 #ifndef SWD_OSD_RING
 #define SWD_OSD_RING 128 // row operations the column-form elimination can publish per round (ring entries in the exchange region)
 #endif
@@ -1765,6 +1772,9 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
         q0_ = clock64(); ++q_rounds;
 #endif
         if (wave == 0) {
+#if SWD_SERIAL_PRIO
+            __builtin_amdgcn_s_setprio(SWD_SERIAL_PRIO);
+#endif
             int used = 0, nbatch = 0; // operations published this round, batches begun
             bool fin = false;
             for (;;) {
@@ -1852,6 +1862,9 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
             }
             asm volatile("" ::: "memory");
             if (lane == 0) ctl[1] = 1;
+#if SWD_SERIAL_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         } else if (colwave) {
             int done_ops = 0;
             for (;;) {
@@ -2016,6 +2029,9 @@ __device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const
         for (int x = 0; x < 4; ++x) t[q][x] = (x == q && q * 64 + lane < m) ? (1ull << lane) : 0ull;
     uint64_t Pw = 0;                    // word w of the pivoted-row mask (replicated per column group)
     int npiv = 0, rowadds = 0, p = 0;
+#if SWD_SERIAL_PRIO
+    __builtin_amdgcn_s_setprio(SWD_SERIAL_PRIO); // the workgroup's other waves wait for this one: ahead of the other workgroups' waves on its SIMD
+#endif
 #ifdef SWD_BPPROF
     long long acc_scan = 0, acc_upd = 0, acc_f1 = 0; int nscan = 0;
 #endif
@@ -2096,6 +2112,9 @@ __device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const
 #ifdef SWD_BPPROF
     if (lane == 0) { s.scal[20] = nscan; s.scal[21] = (int)(acc_scan >> 4); s.scal[22] = (int)(acc_upd >> 4); s.scal[23] = (int)(acc_f1 >> 4); }
 #endif
+#if SWD_SERIAL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) rowadds += __shfl_xor(rowadds, d, 64);
     // y = T * s  (s in original row order): XOR of the owned columns the syndrome selects, reduced over the wave
@@ -2121,6 +2140,216 @@ __device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const
     wave_fence();
     *npiv_out = npiv;
     return rowadds;
+}
+
+// Round 5, m <= 256 on workgroups of at least four waves: the same elimination with the transform matrix OFF the resolving wave.
+// What osd0_wave_reg costs per pivot is its own instruction stream -- ~130 instructions, 40 of them the update of the lane's four
+// columns of T, 1500 cycles whatever else runs on the CU (raising the wave's priority changes nothing) -- while the three other
+// waves of the workgroup wait at a barrier.  Here wave 0 (the resolver) keeps only what the pivot search needs: the step's 16
+// reduced columns, one word per lane, and the mask of unpivoted rows.  Per pivot it publishes (S, r) -- the pivot column's reduced
+// vector without bit r -- into a ring in LDS and applies the row operation to the step's later columns; the other waves (the
+// followers) hold the columns of T, one or two per lane, and apply the ring's operations at their own pace: col ^= S if col[r].
+// An entry is valid when its tag carries the generation of the current step (a wave's LDS operations execute in order: S first,
+// then the tag); a step that found pivots ends with a CLOSE entry, one barrier, the followers' refresh of the mirror in LDS that
+// the next evaluation reads, and a second barrier; steps without a pivot cost the resolver its evaluation only.
+#define SWD_QUAD_RING 20     // entries: up to 16 operations of a step + the CLOSE entry
+#define SWD_QUAD_RING_BYTES (SWD_QUAD_RING * 48 + 32)
+typedef uint32_t swd_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t swd_u32x8 __attribute__((ext_vector_type(8)));
+struct __attribute__((aligned(16))) QuadEnt { uint64_t S[4]; uint32_t tag; uint32_t pad[3]; };
+
+template <int NT, int DM>
+__device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
+                                         uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
+                                         int *npiv_out, char *ringmem) {
+    static_assert(NT >= 256 && NT % 64 == 0, "wave 0 resolves, the other waves hold the columns of T");
+    constexpr int NB = 16;                 // columns per step, four lanes (words) each
+    constexpr int NF = NT / 64 - 1;        // followers
+    constexpr int CPL = (NF * 64 >= 256) ? 1 : 2; // columns of T per follower lane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
+    SWD_LDS_AS QuadEnt *ring = (SWD_LDS_AS QuadEnt *)ringmem;
+    SWD_LDS_AS int *ctl = (SWD_LDS_AS int *)(ring + SWD_QUAD_RING); // 0: operations of the step, 1: finished, 2: first sorted column of the step, 3: pivots so far, 4: row additions
+    // follower state: the columns jc (and jc2) of T as eight 32-bit words
+    const int jc = wave > 0 ? (wave - 1) * 64 + lane : m;
+    const int jc2 = (CPL == 2 && wave > 0) ? NF * 64 + jc : m;
+    const bool has2 = CPL == 2 && __builtin_amdgcn_readfirstlane((wave > 0 && NF * 64 + (wave - 1) * 64 < m) ? 1 : 0) != 0;
+    swd_u32x8 ca, cb;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        ca[d] = (jc < m && d == (jc >> 5)) ? (1u << (jc & 31)) : 0u;
+        cb[d] = (jc2 < m && d == (jc2 >> 5)) ? (1u << (jc2 & 31)) : 0u;
+    }
+    // resolver state
+    const int c = lane >> 2, w = lane & 3;
+    const bool wact = w < wm;
+    const int wl = wact ? w : 0;
+    uint64_t U = ~0ull;  // word w of the unpivoted-row mask (replicated per column group)
+    int racc = 0;        // ones of the pivot columns in unpivoted rows, pivot included
+    int npiv = 0, p = 0;
+    if (tid < SWD_QUAD_RING) ring[tid].tag = 0u;
+    __syncthreads();
+#ifdef SWD_BPPROF
+    long long q_eval = 0, q_chain = 0, q_sync = 0, q0_ = clock64(); int q_steps = 0, q_closed = 0;
+#endif
+    for (int gen = 1;; ++gen) {
+#ifdef SWD_BPPROF
+        if (gen > 1) q_sync += clock64() - q0_;
+        ++q_closed;
+#endif
+        if (wave == 0) {
+            int used = 0;
+            bool fin = false;
+            int pbase = p;
+            for (;;) {
+                pbase = p;
+#ifdef SWD_BPPROF
+                q0_ = clock64(); ++q_steps;
+#endif
+                const int pc = p + c;
+                const bool cval = wact && pc < n;
+                int rows[DM];
+                if (p + NB <= nst) { // wave-uniform: whole step inside the staged prefix
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) rows[k] = crows[pc * DM + k];
+                } else {             // beyond the staged prefix (rare): straight from the graph
+                    const int v = cval ? (int)order[pc] : 0;
+                    const int deg = cval ? (int)g.col_deg[v] : 0;
+#pragma unroll
+                    for (int k = 0; k < DM; ++k) rows[k] = (k < deg) ? (int)g.vn_row[k * n + v] : 0xFFFF;
+                }
+                uint64_t tw[DM];
+#pragma unroll
+                for (int k = 0; k < DM; ++k) tw[k] = Tw[osd_tidx(rows[k] == 0xFFFF ? 0 : rows[k], wl, m)];
+                uint64_t red = 0;
+#pragma unroll
+                for (int k = 0; k < DM; ++k) red ^= (rows[k] == 0xFFFF) ? 0ull : tw[k];
+                if (!cval) red = 0ull;
+                uint64_t cand = red & U;
+#ifdef SWD_BPPROF
+                q_eval += clock64() - q0_; q0_ = clock64();
+#endif
+                for (;;) {
+                    const unsigned long long bal = __ballot(cand != 0ull);
+                    if (bal == 0ull) break;
+                    const int fl = __ffsll((long long)bal) - 1; // first column with a usable 1, its lowest word
+                    const int cs = fl >> 2, ws = fl & 3;
+                    const int bit = __ffsll((long long)wave_read64(cand, fl)) - 1;
+                    const bool mine = c == cs;
+                    if (mine) racc += __popcll(cand);
+                    if (lane == fl) red &= ~(1ull << bit);
+                    SWD_LDS_AS QuadEnt *ent = ring + used;
+                    if (mine) ent->S[w] = red;
+                    asm volatile("" ::: "memory"); // (a wave's LDS operations execute in order: the tag follows the vector)
+                    if (mine) ent->tag = (uint32_t)(ws * 64 + bit) | ((uint32_t)cs << 8) | (1u << 12) | ((uint32_t)gen << 16);
+                    // bit r of this lane's column: the quad's lane ws has it
+                    const uint32_t half = (bit < 32) ? (uint32_t)red : (uint32_t)(red >> 32);
+                    uint32_t yb = (w == ws) ? ((half >> (bit & 31)) & 1u) : 0u;
+                    yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+                    yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+                    // word w of S from the pivot column's quad
+                    const int src = (cs * 4 + w) << 2;
+                    const uint32_t slo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)red);
+                    const uint32_t shi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(red >> 32));
+                    const bool later = c > cs;
+                    if (later && yb) red ^= ((uint64_t)shi << 32) | slo; // rows i != r with u[i] = 1 get row r added: y ^= S if y[r]
+                    if (w == ws) U &= ~(1ull << bit);
+                    ++npiv; ++used;
+                    if (npiv >= rank) break;
+                    cand = later ? (red & U) : 0ull;
+                }
+                p += NB;
+#ifdef SWD_BPPROF
+                q_chain += clock64() - q0_;
+#endif
+                fin = !(p < n && npiv < rank);
+                if (used || fin) break;
+            }
+#ifdef SWD_BPPROF
+            q0_ = clock64();
+#endif
+            int rsum = 0;
+            if (fin) {
+                rsum = racc;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) rsum += __shfl_xor(rsum, d, 64);
+            }
+            if (lane == 0) { ctl[0] = used; ctl[1] = fin ? 1 : 0; ctl[2] = pbase; ctl[3] = npiv; ctl[4] = rsum - npiv; }
+            asm volatile("" ::: "memory");
+            if (lane == 0) ring[used].tag = (2u << 12) | ((uint32_t)gen << 16); // CLOSE
+        } else {
+            int pos = 0;
+            for (;;) {
+                SWD_LDS_AS QuadEnt *ent = ring + pos;
+                const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile SWD_LDS_AS uint32_t *)&ent->tag);
+                asm volatile("" ::: "memory");
+                const swd_u32x4 s01 = *(SWD_LDS_AS const swd_u32x4 *)&ent->S[0];
+                const swd_u32x4 s23 = *(SWD_LDS_AS const swd_u32x4 *)&ent->S[2];
+                asm volatile("" ::: "memory");
+                if ((int)(tag >> 16) != gen) { __builtin_amdgcn_s_sleep(1); continue; }
+                if (((tag >> 12) & 3u) != 1u) break; // CLOSE
+                const int r = (int)(tag & 0xFFu), d = r >> 5, b = r & 31;
+                const uint32_t S[8] = {s01[0], s01[1], s01[2], s01[3], s23[0], s23[1], s23[2], s23[3]};
+                {
+                    const uint32_t msk = (uint32_t)__builtin_amdgcn_sbfe((int)ca[d], (uint32_t)b, 1u);
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) ca[x] ^= S[x] & msk;
+                }
+                if (has2) {
+                    const uint32_t msk = (uint32_t)__builtin_amdgcn_sbfe((int)cb[d], (uint32_t)b, 1u);
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) cb[x] ^= S[x] & msk;
+                }
+                ++pos;
+            }
+        }
+        __syncthreads(); // the step's row operations are in every column; ctl[] is final
+        const int nops = ctl[0], fin = ctl[1], pbase = ctl[2], npiv0 = ctl[3] - nops;
+        npiv = ctl[3];
+        if (tid >= 64 && tid - 64 < nops) { // the step's pivots (another wave than the resolver looks the columns up)
+            const uint32_t e = ring[tid - 64].tag;
+            piv_col[npiv0 + tid - 64] = order[pbase + (int)((e >> 8) & 15u)];
+            piv_row[npiv0 + tid - 64] = (uint16_t)(e & 0xFFu);
+        }
+        if (nops) { // the mirror (after the last step: what the higher-order sweep reads)
+            if (jc < m) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (x < wm) Tw[osd_tidx(jc, x, m)] = ((uint64_t)ca[2 * x + 1] << 32) | ca[2 * x];
+            }
+            if (jc2 < m) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (x < wm) Tw[osd_tidx(jc2, x, m)] = ((uint64_t)cb[2 * x + 1] << 32) | cb[2 * x];
+            }
+        }
+        if (tid < wm) Sbuf[tid] = 0ull; // (used after the last step)
+        __syncthreads();
+        if (fin) break;
+    }
+#ifdef SWD_BPPROF // steps, cycles / 16 of the evaluations, of the pivot loops, of the closes (CLOSE entry to the second barrier) + closed steps << 20
+    if (tid == 0) { q_sync += clock64() - q0_; s.scal[20] = q_steps; s.scal[21] = (int)(q_eval >> 4); s.scal[22] = (int)(q_chain >> 4); s.scal[23] = (int)(q_sync >> 4); s.scal[28] = q_closed; }
+#endif
+    // y = T * s (s in original row order)
+    if (wave > 0) {
+        const bool ona = jc < m && synd_b[jc < m ? jc : 0] != 0, onb = jc2 < m && synd_b[jc2 < m ? jc2 : 0] != 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (x < wm) { // uniform
+                uint64_t acc = (ona ? (((uint64_t)ca[2 * x + 1] << 32) | ca[2 * x]) : 0ull) ^ (onb ? (((uint64_t)cb[2 * x + 1] << 32) | cb[2 * x]) : 0ull);
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+                if (lane == 0 && acc) atomicXor((unsigned long long *)&Sbuf[x], (unsigned long long)acc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npiv; i += NT) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+    }
+    *npiv_out = npiv;
+    return ctl[4];
 }
 
 // Higher-order OSD sweep (osd_window.pyx:242-284): after OSD-0, try the osd_cs candidates (every
@@ -2367,7 +2596,8 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
 // sort keys (key[v], idx[v] = v, padding ~0 / 0xFFFF) at the start of the scratch region.  Sorts, runs the
 // OSD-0 elimination on wave 0, then the higher-order sweep.  On return s.hard[0..n) holds the OSD
 // solution; the return value is its path metric (sum of g.llr over the solution in column order).
-template <int NT, int DM, bool COLFORM = false> // COLFORM: the caller's kernel can afford osd0_cols (osd_window kernels of 1024 threads)
+// QUAD: the scratch region is LDS (osd0_quad addresses its ring there)
+template <int NT, int DM, bool COLFORM = false, bool QUAD = COLFORM> // COLFORM: the caller's kernel can afford osd0_cols (osd_window kernels of 1024 threads)
 __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                           const uint8_t *synd, uint8_t *osd0_b, int &rowadds, long long &t_sorted,
                                           long long &t_elim, bool presorted = false) {
@@ -2401,7 +2631,16 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
         for (int k = 0; k < DM; ++k) crows[p * DM + k] = (k < deg) ? g.vn_row[k * n + v] : (uint16_t)0xFFFF;
     }
     __syncthreads();
-    if (g.wm <= 4) {
+    constexpr bool kQuad = QUAD && NT >= 256 && SWD_OSD_QUAD;
+    bool quad = false;
+    if constexpr (kQuad) quad = g.wm <= 4 && L.off_oring >= 0;
+    if (quad) {
+        if constexpr (kQuad) {
+            int npiv = 0;
+            const int ra = osd0_quad<NT, DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv, s.scratch + L.off_oring);
+            if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
+        }
+    } else if (g.wm <= 4) {
         if (tid < 64) {
             int npiv;
             const int ra = osd0_wave_reg<DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
