@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(NT) bp4_osd_kernel(const SwdBp4Args a) {
             __syncthreads();
             int ra;
             uint8_t *o0 = a.osd0 ? a.osd0 + (int64_t)b * 2 * n + (basis == 0 ? n : 0) : nullptr;
-            osd_run<NT, DM>(g, L, P, s, basis == 0 ? sxo : szo, o0, ra, t0, t1);
+            osd_run<NT, DM, false, true>(g, L, P, s, basis == 0 ? sxo : szo, o0, ra, t0, t1); // (the scratch region is LDS: check matrices of up to 256 rows take the four-wave elimination)
             rowadds += ra;
             uint8_t *dst = out_b + (basis == 0 ? n : 0);
             for (int v = tid; v < n; v += NT) dst[v] = s.hard[v];

@@ -1463,6 +1463,11 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 #ifndef SWD_OSD_QUAD
 #define SWD_OSD_QUAD 1 // m <= 256 on at least four waves: the elimination with the transform matrix on the other waves (osd0_quad)
 #endif
+#ifndef SWD_SPEC_LOAD
+#define SWD_SPEC_LOAD 0 // experiment (round 5): the tuned osd_window kernels ask for the next unit's variable-node cache before they draw the
+                        // ticket -- the loads are in flight during the three round trips of ticket, counter and state record: 9.37 -> 9.44 ms per
+                        // launch, no gain (two other workgroups on the CU already run during a workgroup's waits)
+#endif
 #ifndef SWD_SERIAL_PRIO
 #define SWD_SERIAL_PRIO 0 // s_setprio of a wave the rest of its workgroup waits for (single-wave eliminations, the column form's resolver)
 #endif
@@ -2149,27 +2154,34 @@ __device__ __forceinline__ int osd0_wave_reg(const SwdGraphDev &g, Lds &s, const
 // reduced columns, one word per lane, and the mask of unpivoted rows.  Per pivot it publishes (S, r) -- the pivot column's reduced
 // vector without bit r -- into a ring in LDS and applies the row operation to the step's later columns; the other waves (the
 // followers) hold the columns of T, one or two per lane, and apply the ring's operations at their own pace: col ^= S if col[r].
-// An entry is valid when its tag carries the generation of the current step (a wave's LDS operations execute in order: S first,
-// then the tag); a step that found pivots ends with a CLOSE entry, one barrier, the followers' refresh of the mirror in LDS that
-// the next evaluation reads, and a second barrier; steps without a pivot cost the resolver its evaluation only.
-#define SWD_QUAD_RING 20     // entries: up to 16 operations of a step + the CLOSE entry
+// An entry is valid when its tag carries the current generation (a wave's LDS operations execute in order: S first, then the
+// tag).  A generation ends -- CLOSE entry, the followers' refresh of the mirror in LDS that the evaluations read, one barrier --
+// with every step that found a pivot (SWD_QUAD_LAZY = 0) or when SWD_QUAD_LAZY operations are pending: until then the resolver
+// evaluates its next 16 columns against the mirror as it stands and applies the pending operations to them itself (y ^= S if
+// y[r], ~25 instructions each; no gain measured, see SWD_QUAD_LAZY).
+#ifndef SWD_QUAD_LAZY
+#define SWD_QUAD_LAZY 0 // (measured on the [[144,12,12]] windows: 8 moves 41 k cycles per elimination out of the closes and 48 k into the evaluations)
+#endif
+#define SWD_QUAD_RING (SWD_QUAD_LAZY + 18) // entries: pending operations + the up to 16 of a step + the CLOSE entry
 #define SWD_QUAD_RING_BYTES (SWD_QUAD_RING * 48 + 32)
 typedef uint32_t swd_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t swd_u32x8 __attribute__((ext_vector_type(8)));
-struct __attribute__((aligned(16))) QuadEnt { uint64_t S[4]; uint32_t tag; uint32_t pad[3]; };
+// tagpos: pivot row | kind << 8 (1: operation, 2: CLOSE) | generation << 10, sorted position of the pivot column << 32
+struct __attribute__((aligned(16))) QuadEnt { uint64_t S[4]; uint64_t tagpos; uint64_t pad; };
 
 template <int NT, int DM>
 __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
                                          uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
                                          int *npiv_out, char *ringmem) {
     static_assert(NT >= 256 && NT % 64 == 0, "wave 0 resolves, the other waves hold the columns of T");
+    static_assert(SWD_QUAD_RING <= 64, "the pending pivot rows are kept one per lane");
     constexpr int NB = 16;                 // columns per step, four lanes (words) each
     constexpr int NF = NT / 64 - 1;        // followers
     constexpr int CPL = (NF * 64 >= 256) ? 1 : 2; // columns of T per follower lane
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
     SWD_LDS_AS QuadEnt *ring = (SWD_LDS_AS QuadEnt *)ringmem;
-    SWD_LDS_AS int *ctl = (SWD_LDS_AS int *)(ring + SWD_QUAD_RING); // 0: operations of the step, 1: finished, 2: first sorted column of the step, 3: pivots so far, 4: row additions
+    SWD_LDS_AS int *ctl = (SWD_LDS_AS int *)(ring + SWD_QUAD_RING); // 0: operations of the generation, 1: finished, 3: pivots so far, 4: row additions
     // follower state: the columns jc (and jc2) of T as eight 32-bit words
     const int jc = wave > 0 ? (wave - 1) * 64 + lane : m;
     const int jc2 = (CPL == 2 && wave > 0) ? NF * 64 + jc : m;
@@ -2186,23 +2198,21 @@ __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uin
     const int wl = wact ? w : 0;
     uint64_t U = ~0ull;  // word w of the unpivoted-row mask (replicated per column group)
     int racc = 0;        // ones of the pivot columns in unpivoted rows, pivot included
+    int rv = 0;          // lane e: pivot row of the generation's e-th operation
     int npiv = 0, p = 0;
-    if (tid < SWD_QUAD_RING) ring[tid].tag = 0u;
+    if (tid < SWD_QUAD_RING) ring[tid].tagpos = 0ull;
     __syncthreads();
 #ifdef SWD_BPPROF
-    long long q_eval = 0, q_chain = 0, q_sync = 0, q0_ = clock64(); int q_steps = 0, q_closed = 0;
+    long long q_eval = 0, q_chain = 0, q_sync = 0, q0_ = clock64(); int q_steps = 0;
 #endif
     for (int gen = 1;; ++gen) {
 #ifdef SWD_BPPROF
         if (gen > 1) q_sync += clock64() - q0_;
-        ++q_closed;
 #endif
         if (wave == 0) {
             int used = 0;
             bool fin = false;
-            int pbase = p;
             for (;;) {
-                pbase = p;
 #ifdef SWD_BPPROF
                 q0_ = clock64(); ++q_steps;
 #endif
@@ -2225,6 +2235,20 @@ __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uin
 #pragma unroll
                 for (int k = 0; k < DM; ++k) red ^= (rows[k] == 0xFFFF) ? 0ull : tw[k];
                 if (!cval) red = 0ull;
+                // the generation's operations so far, which the mirror does not have yet: y ^= S if y[r]
+                if (used > 0) {
+                    uint64_t Sn = ring[0].S[w];
+                    for (int e = 0; e < used; ++e) {
+                        const uint64_t Sw = Sn;
+                        if (e + 1 < used) Sn = ring[e + 1].S[w];
+                        const int r = __builtin_amdgcn_readlane(rv, e), ws = r >> 6, bit = r & 63;
+                        const uint32_t half = (bit < 32) ? (uint32_t)red : (uint32_t)(red >> 32);
+                        uint32_t yb = (w == ws) ? ((half >> (bit & 31)) & 1u) : 0u;
+                        yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+                        yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+                        if (yb) red ^= Sw;
+                    }
+                }
                 uint64_t cand = red & U;
 #ifdef SWD_BPPROF
                 q_eval += clock64() - q0_; q0_ = clock64();
@@ -2234,26 +2258,30 @@ __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uin
                     if (bal == 0ull) break;
                     const int fl = __ffsll((long long)bal) - 1; // first column with a usable 1, its lowest word
                     const int cs = fl >> 2, ws = fl & 3;
-                    const int bit = __ffsll((long long)wave_read64(cand, fl)) - 1;
-                    const bool mine = c == cs;
-                    if (mine) racc += __popcll(cand);
-                    if (lane == fl) red &= ~(1ull << bit);
-                    SWD_LDS_AS QuadEnt *ent = ring + used;
-                    if (mine) ent->S[w] = red;
-                    asm volatile("" ::: "memory"); // (a wave's LDS operations execute in order: the tag follows the vector)
-                    if (mine) ent->tag = (uint32_t)(ws * 64 + bit) | ((uint32_t)cs << 8) | (1u << 12) | ((uint32_t)gen << 16);
-                    // bit r of this lane's column: the quad's lane ws has it
-                    const uint32_t half = (bit < 32) ? (uint32_t)red : (uint32_t)(red >> 32);
-                    uint32_t yb = (w == ws) ? ((half >> (bit & 31)) & 1u) : 0u;
-                    yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
-                    yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
-                    // word w of S from the pivot column's quad
+                    // word w of the pivot column's vector from its quad (asked for first: the answer takes ~100 cycles)
                     const int src = (cs * 4 + w) << 2;
                     const uint32_t slo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)red);
                     const uint32_t shi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(red >> 32));
+                    const int bit = __ffsll((long long)wave_read64(cand, fl)) - 1;
+                    const int r = ws * 64 + bit;
+                    const uint64_t mask = (w == ws) ? (1ull << bit) : 0ull; // bit r in the lanes that hold word ws
+                    if (c == cs) { // the pivot column's quad publishes S = its vector without bit r
+                        racc += __popcll(cand);
+                        SWD_LDS_AS QuadEnt *ent = ring + used;
+                        ent->S[w] = red & ~mask;
+                        asm volatile("" ::: "memory"); // (a wave's LDS operations execute in order: the tag follows the vector)
+                        ent->tagpos = (uint64_t)((uint32_t)r | (1u << 8) | ((uint32_t)gen << 10)) | ((uint64_t)(uint32_t)(p + cs) << 32);
+                    }
+                    rv = (lane == used) ? r : rv;
+                    // bit r of this lane's column: the quad's lane ws has it
+                    const uint32_t half = (bit < 32) ? (uint32_t)red : (uint32_t)(red >> 32);
+                    uint32_t yb = (w == ws) ? ((half >> (bit & 31)) & 1u) : 0u;
+                    yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xB1, 0xF, 0xF, true);
+                    yb |= (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0x4E, 0xF, 0xF, true);
                     const bool later = c > cs;
-                    if (later && yb) red ^= ((uint64_t)shi << 32) | slo; // rows i != r with u[i] = 1 get row r added: y ^= S if y[r]
-                    if (w == ws) U &= ~(1ull << bit);
+                    // rows i != r with u[i] = 1 get row r added: y ^= S if y[r] (y keeps its bit r)
+                    if (later && yb) red ^= (((uint64_t)shi << 32) | slo) & ~mask;
+                    U &= ~mask;
                     ++npiv; ++used;
                     if (npiv >= rank) break;
                     cand = later ? (red & U) : 0ull;
@@ -2263,7 +2291,7 @@ __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uin
                 q_chain += clock64() - q0_;
 #endif
                 fin = !(p < n && npiv < rank);
-                if (used || fin) break;
+                if (used >= (SWD_QUAD_LAZY > 0 ? SWD_QUAD_LAZY : 1) || fin) break;
             }
 #ifdef SWD_BPPROF
             q0_ = clock64();
@@ -2274,20 +2302,22 @@ __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uin
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) rsum += __shfl_xor(rsum, d, 64);
             }
-            if (lane == 0) { ctl[0] = used; ctl[1] = fin ? 1 : 0; ctl[2] = pbase; ctl[3] = npiv; ctl[4] = rsum - npiv; }
-            asm volatile("" ::: "memory");
-            if (lane == 0) ring[used].tag = (2u << 12) | ((uint32_t)gen << 16); // CLOSE
+            if (lane == 0) {
+                ctl[0] = used; ctl[1] = fin ? 1 : 0; ctl[3] = npiv; ctl[4] = rsum - npiv;
+                asm volatile("" ::: "memory");
+                ring[used].tagpos = (uint64_t)((2u << 8) | ((uint32_t)gen << 10)); // CLOSE
+            }
         } else {
             int pos = 0;
             for (;;) {
                 SWD_LDS_AS QuadEnt *ent = ring + pos;
-                const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile SWD_LDS_AS uint32_t *)&ent->tag);
+                const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile SWD_LDS_AS uint32_t *)&ent->tagpos);
                 asm volatile("" ::: "memory");
                 const swd_u32x4 s01 = *(SWD_LDS_AS const swd_u32x4 *)&ent->S[0];
                 const swd_u32x4 s23 = *(SWD_LDS_AS const swd_u32x4 *)&ent->S[2];
                 asm volatile("" ::: "memory");
-                if ((int)(tag >> 16) != gen) { __builtin_amdgcn_s_sleep(1); continue; }
-                if (((tag >> 12) & 3u) != 1u) break; // CLOSE
+                if ((int)(tag >> 10) != gen) { __builtin_amdgcn_s_sleep(1); continue; }
+                if (((tag >> 8) & 3u) != 1u) break; // CLOSE
                 const int r = (int)(tag & 0xFFu), d = r >> 5, b = r & 31;
                 const uint32_t S[8] = {s01[0], s01[1], s01[2], s01[3], s23[0], s23[1], s23[2], s23[3]};
                 {
@@ -2303,32 +2333,39 @@ __device__ __forceinline__ int osd0_quad(const SwdGraphDev &g, Lds &s, const uin
                 ++pos;
             }
         }
-        __syncthreads(); // the step's row operations are in every column; ctl[] is final
-        const int nops = ctl[0], fin = ctl[1], pbase = ctl[2], npiv0 = ctl[3] - nops;
-        npiv = ctl[3];
-        if (tid >= 64 && tid - 64 < nops) { // the step's pivots (another wave than the resolver looks the columns up)
-            const uint32_t e = ring[tid - 64].tag;
-            piv_col[npiv0 + tid - 64] = order[pbase + (int)((e >> 8) & 15u)];
-            piv_row[npiv0 + tid - 64] = (uint16_t)(e & 0xFFu);
-        }
-        if (nops) { // the mirror (after the last step: what the higher-order sweep reads)
-            if (jc < m) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    if (x < wm) Tw[osd_tidx(jc, x, m)] = ((uint64_t)ca[2 * x + 1] << 32) | ca[2 * x];
+        // A follower that has seen the CLOSE entry has every operation of the generation in its columns and finds ctl[] final
+        // (written before the entry); nobody reads the mirror until the resolver's next evaluation, behind the barrier.
+        int fin;
+        if (wave == 0) {
+            fin = ctl[1];
+            if (tid < wm) Sbuf[tid] = 0ull; // (used after the last generation)
+        } else {
+            const int nops = ctl[0], npiv0 = ctl[3] - nops;
+            fin = ctl[1];
+            npiv = ctl[3];
+            if (tid - 64 < nops) { // the generation's pivots (another wave than the resolver looks the columns up)
+                const uint64_t e = ring[tid - 64].tagpos;
+                piv_col[npiv0 + tid - 64] = order[(int)(e >> 32)];
+                piv_row[npiv0 + tid - 64] = (uint16_t)((uint32_t)e & 0xFFu);
             }
-            if (jc2 < m) {
+            if (nops) { // the mirror (after the last generation: what the higher-order sweep reads)
+                if (jc < m) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    if (x < wm) Tw[osd_tidx(jc2, x, m)] = ((uint64_t)cb[2 * x + 1] << 32) | cb[2 * x];
+                    for (int x = 0; x < 4; ++x)
+                        if (x < wm) Tw[osd_tidx(jc, x, m)] = ((uint64_t)ca[2 * x + 1] << 32) | ca[2 * x];
+                }
+                if (jc2 < m) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (x < wm) Tw[osd_tidx(jc2, x, m)] = ((uint64_t)cb[2 * x + 1] << 32) | cb[2 * x];
+                }
             }
         }
-        if (tid < wm) Sbuf[tid] = 0ull; // (used after the last step)
         __syncthreads();
         if (fin) break;
     }
-#ifdef SWD_BPPROF // steps, cycles / 16 of the evaluations, of the pivot loops, of the closes (CLOSE entry to the second barrier) + closed steps << 20
-    if (tid == 0) { q_sync += clock64() - q0_; s.scal[20] = q_steps; s.scal[21] = (int)(q_eval >> 4); s.scal[22] = (int)(q_chain >> 4); s.scal[23] = (int)(q_sync >> 4); s.scal[28] = q_closed; }
+#ifdef SWD_BPPROF // steps, cycles / 16 of the evaluations (pending operations included), of the pivot loops, of the closes (CLOSE entry to the second barrier)
+    if (tid == 0) { q_sync += clock64() - q0_; s.scal[20] = q_steps; s.scal[21] = (int)(q_eval >> 4); s.scal[22] = (int)(q_chain >> 4); s.scal[23] = (int)(q_sync >> 4); }
 #endif
     // y = T * s (s in original row order)
     if (wave > 0) {
@@ -2699,9 +2736,12 @@ __device__ __forceinline__ void lds_bind(Lds &s, char *smem, const SwdLdsLayout 
 
 // osd_window.decode (osd_window.pyx:158-199) for one syndrome `synd` (LDS bytes, original check
 // order).  On return s.hard[0..n) is the vector decode() returns.
+// vraw (kernels that split the cache load): where the raw edge words and priors of the variable nodes go; pre_valid: the caller has
+// issued the loads for this graph already
 template <int NT, int VF, int DM, int KG, bool SF, bool HACC, bool BIG = false>
 __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
-                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map) {
+                              const uint8_t *synd, double *hist_b, uint8_t *osd0_b, uint8_t *bpdec_b, WinResult &R, const uint32_t *cn_map,
+                              VnRaw<NT, (NT <= SWD_TUNED_NT) ? VF : 1, DM> &vraw, bool pre_valid = false) {
     constexpr bool DIET = SWD_P16(NT); // the tuned kernels' LDS forms (decided-node bits, 48-bit live masks, no copy of the check degrees)
     if constexpr (DIET) s.lm_m = (L.off_par - L.off_livemask < 8 * g.m) ? g.m : 0; // m if the masks are stored in the 48-bit form
     // Tuned kernels: the parity WORDS of the iterations lie over the live masks, which nothing reads while bp_run is running (the full-
@@ -2721,18 +2761,25 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // the full-graph phase in the graph's listed order, tiered variable-node pass (bit 0: the LDS-resident kernels, bit 1: the large-graph ones)
     constexpr bool kFullSorted = (SWD_FULL_SORTED & (BIG ? 2 : 1)) != 0;
     [[maybe_unused]] int kcf[VF];
-    [[maybe_unused]] VnRaw<NT, kSplitLoad ? VF : 1, DM> vraw;
-    if constexpr (kSplitLoad) vn_cache_issue<NT, VF, DM, kFullSorted>(g, s, vraw);
+    // (memory loads return in order: what the reset loops need from the graph is asked for BEFORE the cache's 7 x DM + 7 loads, so
+    // that the loops run while those are in flight instead of behind them)
+    [[maybe_unused]] int d_first = 0, p_first = 0, j_first = 0;
+    if constexpr (kSplitLoad) {
+        if (tid < m) { d_first = g.row_deg[tid]; p_first = g.perm[tid]; }
+        if (tid <= g.K) j_first = g.jptr[tid];
+        __builtin_amdgcn_sched_barrier(0); // (issued here)
+        if (!pre_valid) vn_cache_issue<NT, VF, DM, kFullSorted>(g, s, vraw); // (uniform)
+    }
     // reset (osd_window.pyx:288-303)
     for (int l = tid; l < m; l += NT) {
-        const int d = g.row_deg[l];
-        s.cn_val[l] = (int8_t)(synd[g.perm[l]] ? 1 : 0);
+        const int d = (kSplitLoad && l == tid) ? d_first : (int)g.row_deg[l];
+        s.cn_val[l] = (int8_t)(synd[(kSplitLoad && l == tid) ? p_first : (int)g.perm[l]] ? 1 : 0);
         s.cn_deg[l] = (uint8_t)d;
         if constexpr (!DIET) s.cn_deg0[l] = (uint8_t)d;
         lm_set<DIET>(s, l, (d >= 64) ? ~0ull : ((1ull << d) - 1ull));
     }
     vn_reset<NT, DIET>(s, n);
-    for (int j = tid; j <= g.K; j += NT) s.jptr[j] = g.jptr[j];
+    for (int j = tid; j <= g.K; j += NT) s.jptr[j] = (kSplitLoad && j == tid) ? (uint16_t)j_first : g.jptr[j];
     if (P.zero_hist)
         for (int i = tid; i < 4 * n; i += NT) hist_b[i] = 0.0;
     // the tuned kernels use the packed caches and their overloads of the BP routines: byte offsets + parity bytes up to 256
@@ -3325,9 +3372,23 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : (NT == 640 ? 3 : ((SWD_O
     // parallel form: every shot is admitted through the counter a.sched[0] -- by a workgroup that finds nothing unclaimed in the
     // ring, or by the one that finishes a shot -- so progress never depends on a workgroup that is not resident yet
     constexpr uint32_t shots0 = 0;
+    // The tuned osd_window kernels ask for the next unit's variable-node cache (7 x DM edge words + the priors per thread, from the
+    // graph's tables in L2) BEFORE they draw the ticket: consecutive tickets name the same window -- or a window that shares its
+    // graph -- nearly always, and the ticket, the predecessor's counter and the state record are three more dependent round trips to
+    // memory during which those loads can be in flight.  A unit of another graph asks again (decode_window).
+    constexpr bool kSpecLoad = SWD_SPEC_LOAD && (KIND == 0 || KIND == 3) && !BIG && NT <= SWD_TUNED_NT && !((SWD_FULL_SORTED & 1) != 0);
+    [[maybe_unused]] VnRaw<NT, kSpecLoad ? VF : 1, DM> vspec;
+    [[maybe_unused]] int wi_spec = 0;
+    [[maybe_unused]] const uint32_t *spec_tab = nullptr;
     for (;;) {
     const long long t_unit0 = wall_clock64();
     int wi, b, final_ctx = -1;
+    if constexpr (kSpecLoad) {
+        const SwdGraphDev &gs = a.wins[wi_spec].g;
+        vn_cache_issue<NT, VF, DM, false>(gs, s, vspec);
+        spec_tab = gs.vn_edge;
+        __builtin_amdgcn_sched_barrier(0);
+    }
     [[maybe_unused]] bool ens_task = false;      // kind 7: this turn runs a tree thread of a parked ensemble, not a unit
     [[maybe_unused]] uint32_t ens_item = 0;
 #ifdef SWD_GDG_DEBUG
@@ -3473,8 +3534,18 @@ __global__ void __launch_bounds__(NT, (NT >= 1024 ? 4 : (NT == 640 ? 3 : ((SWD_O
             R = WinResult{};
             R.exit_class = SWD_EXIT_SCHED_FAULT;
         } else if constexpr (KIND == 0 || KIND == 3) // 3: osd_window with the posterior history accumulated in registers (bp_run, ACC)
-            decode_window<NT, VF, DM, KG, SF, KIND == 3, BIG>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
-                                                         a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map);
+        {
+            if constexpr (kSpecLoad) {
+                const bool hit = g.vn_edge == spec_tab && g.llr == a.wins[wi_spec].g.llr && g.n == a.wins[wi_spec].g.n;
+                wi_spec = wi;
+                decode_window<NT, VF, DM, KG, SF, KIND == 3, BIG>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
+                                                             a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map, vspec, hit);
+            } else {
+                VnRaw<NT, (NT <= SWD_TUNED_NT) ? VF : 1, DM> vraw;
+                decode_window<NT, VF, DM, KG, SF, KIND == 3, BIG>(g, L, a.P, s, sdet + (w.row0 - dbase), hist_b, a.osd0 ? a.osd0 + (int64_t)b * g.n : nullptr,
+                                                             a.bp_dec ? a.bp_dec + (int64_t)b * g.n : nullptr, R, w.cn_map, vraw);
+            }
+        }
         else {
             uint8_t *snap_b = a.snap + (int64_t)sidx * a.snap_stride;
             bool redo = false;
