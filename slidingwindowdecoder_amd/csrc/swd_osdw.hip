@@ -95,6 +95,14 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
             o += L.pmsg_bytes;
         }
     }
+    // large graphs, 256 < m <= 960: ring (64 or 32 entries of 16 words), pivoted-row mask and control words of osd0_colsw
+    L.off_owide = -1; L.owide_ring = 0;
+    if (big && kind == 0 && nt == 1024 && wm > 4 && wm <= 15 && !getenv("SWD_NO_OSD_WIDE")) {
+        for (int ring = 64; ring >= 32; ring >>= 1) {
+            const int bytes = align_up(ring * 16 * 8 + 16 * 8 + 64, 16);
+            if (o + bytes <= lds_budget) { L.off_owide = o; L.owide_ring = ring; o += bytes; break; }
+        }
+    }
     // experiment (SWD_POST_RENUM=1, tuned osd_window kernels of up to 256 threads): renumber the shortened graph's message cells
     // one column per live variable node inside the scratch region; the old-slot -> cell table takes the staged column table's place
     // (round 5, SWD_POST_SORTED: the production form of the tuned kernels' post phase whenever the renumbered cells fit in front of the

@@ -98,6 +98,7 @@ struct SwdLdsLayout {
     int32_t off_hs;    // inside scratch: f64 hs[n], summed posterior history of the live VNs after a failed post phase (HACC kernels)
     int32_t off_oslot; // inside scratch (tail of the sort keys): exchange slots of the column-form elimination (osd0_cols), -1 if unused
     int32_t off_oring; // inside scratch (behind the OSD-0 arrays): ring of row operations of the four-wave elimination (osd0_quad), -1 if unused
+    int32_t off_owide, owide_ring; // large-graph kernels: LDS offset of the ring / masks / control words of osd0_colsw and its entries, -1 if unused
     // Large graphs (kernels instantiated with BIG, swd_kernels_k5.hip): the scratch region -- messages, sort keys, staged lists,
     // OSD arrays -- lives in HBM, big_scratch bytes per workgroup, and every other offset above (off_livemask ... off_misc, total)
     // is relative to the workgroup's LDS, which then only holds the per-check / per-variable-node state.  0: everything in LDS.
@@ -1463,6 +1464,12 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 #ifndef SWD_OSD_QUAD
 #define SWD_OSD_QUAD 1 // m <= 256 on at least four waves: the elimination with the transform matrix on the other waves (osd0_quad)
 #endif
+#ifndef SWD_WIDE_EVAL_DS
+#define SWD_WIDE_EVAL_DS 0
+#endif
+#ifndef SWD_OSD_WIDE
+#define SWD_OSD_WIDE 1 // large-graph kernels: the column-form elimination on fifteen column waves (osd0_colsw) instead of osd0_block
+#endif
 #ifndef SWD_SPEC_LOAD
 #define SWD_SPEC_LOAD 0 // experiment (round 5): the tuned osd_window kernels ask for the next unit's variable-node cache before they draw the
                         // ticket -- the loads are in flight during the three round trips of ticket, counter and state record: 9.37 -> 9.44 ms per
@@ -1980,6 +1987,233 @@ __device__ __forceinline__ int osd0_cols(const SwdGraphDev &g, Lds &s, const uin
     return ctl[4];
 }
 #endif // SWD_OSD_COLS_V1
+
+// Large-graph kernels (scratch region in HBM), 256 < m <= 960: the column form on ALL fifteen waves behind the resolver -- wave w holds
+// columns 64 (w - 1) .. 64 w - 1 of the transform matrix, one per lane, fifteen words each.  One batch of 64 sorted columns per pair
+// of barriers (the round-2 protocol: the resolver publishes (S, r) into a ring, the column waves follow it at their own pace,
+// col ^= S if col[r]; the barriers bracket the refresh of the mirror the evaluations read); the ring, the pivoted-row mask and the
+// control words are LDS (`ringmem`: the layout's off_owide, `ring` entries -- a batch that fills the ring closes early and the next
+// one starts behind its last pivot column); the mirror is wherever the OSD arrays are (LDS when the layout says osd_lds, else HBM).
+// Replaces osd0_block for these graphs: 6500 cycles per pivot there -- wave 0 evaluating against T in memory, every thread
+// rewriting T, two barriers per PIVOT -- on the 936-check model of IBM.ipynb:119.
+template <int NT, int DM, int WMC>
+__device__ __forceinline__ int osd0_colsw(const SwdGraphDev &g, Lds &s, const uint16_t *order, uint64_t *Tw, uint64_t *Sbuf,
+                                          uint16_t *piv_col, uint16_t *piv_row, const uint8_t *synd_b, const uint16_t *crows, int nst,
+                                          int *npiv_out, char *ringmem, int ring, bool lds_mirror) {
+    constexpr int NBC = 64;
+    static_assert(NT == 1024 && WMC <= 15, "wave 0 resolves, waves 1..15 hold the columns");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = g.m, n = g.n, wm = g.wm, rank = g.rank;
+    constexpr int ES = 16; // words per ring entry: S, then pivot row | column within the batch << 16
+    SWD_LDS_AS uint64_t *ringS = (SWD_LDS_AS uint64_t *)ringmem;                  // [ring][ES] the batch's row operations
+    SWD_LDS_AS uint64_t *Pl = ringS + ring * ES;                                  // [16] pivoted rows
+    SWD_LDS_AS int *ctl = (SWD_LDS_AS int *)(Pl + 16); // 0: published, 1: batch closed, 2: elimination finished, 3: pivots so far, 4: row additions, 5: first column of the next batch, 6: of the closing one
+    volatile SWD_LDS_AS int *vctl = ctl;
+    const bool colwave = wave != 0;
+    const int jc = colwave ? (wave - 1) * 64 + lane : m; // the column of T this thread keeps
+    uint64_t col[WMC];
+#pragma unroll
+    for (int x = 0; x < WMC; ++x) col[x] = (jc < m && x == (jc >> 6)) ? (1ull << (jc & 63)) : 0ull;
+    if (tid < 8) ctl[tid] = 0;
+    if (tid < 16) Pl[tid] = 0ull;
+    __syncthreads();
+    // resolver state: lane x < WMC keeps word x of the pivoted-row mask and counts the unpivoted ones of the pivot columns there
+    uint64_t Pmine = 0;
+    int racc = 0;
+    int npiv = 0, p = 0;
+#ifdef SWD_OSDPROF
+    long long q_eval = 0, q_res = 0, q_app = 0, q_wait = 0, q_sync = 0, q0_;
+    int q_batches = 0;
+#endif
+    for (;;) {
+        const int npiv0 = npiv;
+        int p0 = p;
+#ifdef SWD_OSDPROF
+        q0_ = clock64(); ++q_batches;
+#endif
+        if (wave == 0) {
+          for (;;) { // batches, until one finds a pivot (the others change nothing anybody else would have to see)
+            p0 = p;
+#ifdef SWD_OSDPROF
+            q0_ = clock64();
+#endif
+            const int pc = p + lane;
+            const bool cval = pc < n;
+            int rows[DM];
+            if (p + NBC <= nst) { // uniform: whole batch inside the staged prefix
+#pragma unroll
+                for (int kk = 0; kk < DM; ++kk) rows[kk] = crows[pc * DM + kk];
+            } else {
+                const int v = cval ? (int)order[pc] : 0;
+                const int deg = cval ? (int)g.col_deg[v] : 0;
+#pragma unroll
+                for (int kk = 0; kk < DM; ++kk) rows[kk] = (kk < deg) ? (int)g.vn_row[kk * n + v] : 0xFFFF;
+            }
+            uint64_t (&red)[WMC] = col; // (the resolver keeps no column of T: its batch vectors take those registers -- a second array of
+                                        //  thirty does not fit this kernel's 128 and sent both to scratch)
+            if (SWD_WIDE_EVAL_DS && lds_mirror) { // (uniform) ds_read instead of flat loads
+                SWD_LDS_AS const uint64_t *TwL = (SWD_LDS_AS const uint64_t *)Tw;
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) {
+                    red[x] = 0ull;
+                    if (x < wm) { // uniform
+#pragma unroll
+                        for (int kk = 0; kk < DM; ++kk) red[x] ^= (rows[kk] == 0xFFFF) ? 0ull : TwL[osd_tidx(rows[kk] == 0xFFFF ? 0 : rows[kk], x, m)];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) {
+                    red[x] = 0ull;
+                    if (x < wm) { // uniform
+#pragma unroll
+                        for (int kk = 0; kk < DM; ++kk) red[x] ^= (rows[kk] == 0xFFFF) ? 0ull : Tw[osd_tidx(rows[kk] == 0xFFFF ? 0 : rows[kk], x, m)];
+                    }
+                }
+            }
+            bool alive = cval;
+            int nb = 0, last_cs = NBC - 1; // pivots of this batch, its last pivot column
+#ifdef SWD_OSDPROF
+            q_eval += clock64() - q0_; q0_ = clock64();
+#endif
+            while (npiv < rank && nb < ring) {
+                uint32_t nz = 0; // (the pivoted-row mask is read where it is used: fifteen more registers do not fit the 128 of this kernel)
+#pragma unroll
+                for (int x = 0; x < WMC; ++x) {
+                    const uint64_t pbx = Pl[x];
+                    nz |= (uint32_t)red[x] & ~(uint32_t)pbx;
+                    nz |= (uint32_t)(red[x] >> 32) & ~(uint32_t)(pbx >> 32);
+                }
+                const unsigned long long bal = __ballot(alive && nz != 0u);
+                if (bal == 0ull) break; // every remaining column of the batch is dependent
+                const int cs = __ffsll((long long)bal) - 1;
+                last_cs = cs;
+                uint32_t lz = 0;
+                asm volatile("" : "+v"(lz)); // the lane number, recomputed here: kept across the loop it is spilled and reloaded per pivot
+                const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, lz));
+                SWD_LDS_AS uint64_t *ent = ringS + nb * ES;
+                if (ln == cs) { // the pivot column's lane publishes its reduced vector (LDS operations of a wave execute in order)
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) ent[x] = red[x];
+                }
+                asm volatile("" ::: "memory");
+                const uint64_t wv = ent[ln < WMC ? ln : 0]; // the vector a word per lane: pivot search
+                const uint64_t c = (ln < WMC) ? (wv & ~Pmine) : 0ull; // its ones in unpivoted rows
+                const unsigned long long balc = __ballot(c != 0ull);
+                const int fx = __ffsll((long long)balc) - 1;
+                const int bit = __builtin_amdgcn_readlane(__ffsll((long long)c) - 1, fx);
+                racc += __popcll(c); // row additions the reference's LU would apply: unpivoted rows with a one in this column (the pivot itself is taken off at the end)
+                if (ln == fx) {
+                    __hip_atomic_fetch_and(&ent[fx], ~(1ull << bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(&Pl[fx], 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    Pmine |= 1ull << bit;
+                }
+                if (ln == 0) ent[WMC] = (uint64_t)(uint32_t)((fx * 64 + bit) | (cs << 16));
+                asm volatile("" ::: "memory"); // a wave's LDS operations execute in order: the count follows the entry
+                if (ln == 0) ctl[0] = nb + 1;
+                // the batch's later columns under the same row operation: y ^= S if y[r] (S without bit r by now: y keeps its own)
+                const uint32_t ybit = osd_vec_bit<WMC>(red, fx, bit);
+                if (ln <= cs) alive = false;
+                else if (alive && ybit) {
+#pragma unroll
+                    for (int x = 0; x < WMC; ++x) red[x] ^= ent[x];
+                }
+                ++npiv; ++nb;
+            }
+            p = (nb >= ring && npiv < rank) ? p0 + last_cs + 1 : p0 + NBC; // (ring full: the columns behind the last pivot are evaluated again)
+#ifdef SWD_OSDPROF
+            q_res += clock64() - q0_; q0_ = clock64();
+#endif
+            if (nb > 0 || !(p < n && npiv < rank)) break;
+          }
+            int rsum = racc;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) rsum += __shfl_xor(rsum, d, 64);
+            if (lane == 0) {
+                ctl[3] = npiv; ctl[4] = rsum - npiv; ctl[5] = p; ctl[6] = p0;
+                ctl[2] = (p < n && npiv < rank) ? 0 : 1;
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) ctl[1] = 1;
+        } else {
+            int done_ops = 0;
+            for (;;) {
+                const int closed = vctl[1]; // read before the count: a closed batch's count is final
+                const int avail = vctl[0];
+#ifdef SWD_OSDPROF
+                q_wait += clock64() - q0_; q0_ = clock64();
+#endif
+                while (done_ops < avail) {
+                    SWD_LDS_AS const uint64_t *ent = ringS + done_ops * ES;
+                    const int r = __builtin_amdgcn_readfirstlane((int)(uint32_t)ent[WMC]) & 0xFFFF;
+                    const int rw = r >> 6, rbit = r & 63;
+                    if (osd_vec_bit<WMC>(col, rw, rbit)) {
+#pragma unroll
+                        for (int x = 0; x < WMC; ++x) col[x] ^= ent[x];
+                    }
+                    ++done_ops;
+                }
+#ifdef SWD_OSDPROF
+                q_app += clock64() - q0_; q0_ = clock64();
+#endif
+                if (closed) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads(); // the batch's row operations are in every column; ctl[] is final
+        const int fin = ctl[2];
+        npiv = ctl[3];
+        p = ctl[5];
+        p0 = ctl[6];
+        if (tid >= 64 && tid - 64 < npiv - npiv0) { // the batch's pivots (another wave than the resolver looks the columns up)
+            const int e = (int)(uint32_t)ringS[(tid - 64) * ES + WMC];
+            piv_col[npiv0 + tid - 64] = order[p0 + (e >> 16)];
+            piv_row[npiv0 + tid - 64] = (uint16_t)(e & 0xFFFF);
+        }
+        if (jc < m && npiv != npiv0) { // the mirror (after the last batch: what the higher-order sweep reads)
+            if (lds_mirror) {
+                SWD_LDS_AS uint64_t *TwL = (SWD_LDS_AS uint64_t *)Tw;
+#pragma unroll
+                for (int x = 0; x < WMC; ++x)
+                    if (x < wm) TwL[osd_tidx(jc, x, m)] = col[x];
+            } else {
+#pragma unroll
+                for (int x = 0; x < WMC; ++x)
+                    if (x < wm) Tw[osd_tidx(jc, x, m)] = col[x];
+            }
+        }
+        if (tid < wm) Sbuf[tid] = 0ull; // (used after the last batch)
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; } // nobody reads these two between the barriers
+        __syncthreads();
+#ifdef SWD_OSDPROF
+        q_sync += clock64() - q0_;
+        if (fin && (tid == 0 || tid == 64) && (blockIdx.x & 63) == 0)
+            printf("osdprof colsw thread %d: batches %d pivots %d | resolver: evaluation %lld resolve %lld | column wave: apply %lld wait %lld | rest of the batch %lld cycles\n",
+                   tid, q_batches, npiv, q_eval, q_res, q_app, q_wait, q_sync);
+#endif
+        if (fin) break;
+    }
+    // y = T * s (s in original row order)
+    const bool on = jc < m && synd_b[jc < m ? jc : 0] != 0;
+    if (colwave) {
+#pragma unroll
+        for (int x = 0; x < WMC; ++x) {
+            if (x < wm) { // uniform
+                uint64_t acc = on ? col[x] : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+                if (lane == 0 && acc) atomicXor((unsigned long long *)&Sbuf[x], (unsigned long long)acc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npiv; i += NT) {
+        const int r = piv_row[i];
+        s.hard[piv_col[i]] = (uint8_t)((Sbuf[r >> 6] >> (r & 63)) & 1ull);
+    }
+    *npiv_out = npiv;
+    return ctl[4];
+}
 
 // osd0_wave for m <= 256 (wm <= 4): the transform matrix lives in registers -- lane l owns columns
 // l, l+64, l+128, l+192 of T, four words each -- and LDS only holds a mirror that the column
@@ -2634,7 +2868,8 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
 // OSD-0 elimination on wave 0, then the higher-order sweep.  On return s.hard[0..n) holds the OSD
 // solution; the return value is its path metric (sum of g.llr over the solution in column order).
 // QUAD: the scratch region is LDS (osd0_quad addresses its ring there)
-template <int NT, int DM, bool COLFORM = false, bool QUAD = COLFORM> // COLFORM: the caller's kernel can afford osd0_cols (osd_window kernels of 1024 threads)
+// WIDE: large-graph kernel (osd0_colsw when the layout has its LDS block)
+template <int NT, int DM, bool COLFORM = false, bool QUAD = COLFORM, bool WIDE = false> // COLFORM: the caller's kernel can afford osd0_cols (osd_window kernels of 1024 threads)
 __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                           const uint8_t *synd, uint8_t *osd0_b, int &rowadds, long long &t_sorted,
                                           long long &t_elim, bool presorted = false) {
@@ -2688,6 +2923,12 @@ __device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayo
         bool done = false;
         if constexpr (kColForm) {
             if (cols) { ra = osd0_cols<NT, DM, 9>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv, s.scratch + L.off_oslot); done = true; }
+        }
+        if constexpr (WIDE && NT == 1024 && DM <= 8 && SWD_OSD_WIDE) {
+            if (g.wm <= 15 && L.off_owide >= 0) {
+                ra = osd0_colsw<NT, DM, 15>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv, (char *)s.hard - L.off_hard + L.off_owide, L.owide_ring, L.osd_lds != 0);
+                done = true;
+            }
         }
         if (!done) ra = osd0_block<NT, DM>(g, s, idx, Tc, Sbuf, piv_col, piv_row, synd, crows, nst, &npiv);
         if (tid == 0) { s.scal[2] = ra; s.scal[3] = npiv; }
@@ -3269,7 +3510,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         }
         __syncthreads();
     }
-    R.pm = osd_run<NT, DM, !BIG>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted); // (the column-form elimination addresses LDS explicitly;
+    R.pm = osd_run<NT, DM, !BIG, !BIG, BIG>(g, L, P, s, synd, osd0_b, R.osd_rowadds, R.t[6], R.t[7], presorted); // (the column-form elimination addresses LDS explicitly;
     // behind a function boundary -- its own register allocation -- the headline launch took 12.3 instead of 10.5 ms: round 4)
     R.exit_class = SWD_EXIT_OSD;
 }
