@@ -205,7 +205,9 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     Bp4::LaunchSlot *sl = nullptr;
     if (d->take_slot(st, &sl)) return -1;
     if (!lpr) {
-        if (sl->lpr.reserve((size_t)B * 3 * d->n * 8)) return -1;
+        // every slot's buffer at the first launch of this size, not one per launch: the allocations (226 MB each for 65 536 decodes of
+        // a 144-qubit code) would otherwise fall into the first kSlots launches one by one -- 5-7 ms of host time each, behind a warm-up
+        for (auto &s2 : d->slot) if (s2.lpr.reserve((size_t)B * 3 * d->n * 8)) return -1;
         lpr = sl->lpr.as<double>();
     }
     SwdBp4Args a{};
@@ -213,7 +215,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
     a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.bp_dec = bp_dec; a.stats = stats; a.lpr = lpr;
-    if (sl->osd_q.reserve((size_t)B * 4 + 16)) return -1;
+    for (auto &s2 : d->slot) if (s2.osd_q.reserve((size_t)B * 4 + 16)) return -1;
     a.osd_count = sl->osd_q.as<uint32_t>(); a.osd_list = sl->osd_q.as<int32_t>() + 4;
     if (bp4_dispatch(d, a, st)) return -1;
     SWD_HIP(hipEventRecord(sl->done, st));

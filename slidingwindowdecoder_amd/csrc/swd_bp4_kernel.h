@@ -75,6 +75,40 @@ __device__ __forceinline__ bool bp4_block_any(bool p, Lds &s, int nwaves) {
     return __builtin_amdgcn_readfirstlane(r) != 0;
 }
 
+#ifndef SWD_BP4_OWN_CHECK
+#define SWD_BP4_OWN_CHECK 1
+#endif
+// one check of the plain min-sum CN pass (bp4_osd.pyx:483-529): true when its parity word was still set
+__device__ __forceinline__ bool bp4_cn_one(double *msg, const uint16_t *jptr, const int8_t *cn, uint32_t *par, int l, int deg, int it, double alpha) {
+    bool unsat = false;
+    {
+        const int cv = cn[l];
+        if (it > 0 && par[l] != 0u) unsat = true;
+        par[l] = (uint32_t)cv;
+        double min1 = 1e308, min2 = 1e308;
+        int arg = -1;
+        uint64_t negm = 0;
+        for (int k = 0; k < deg; ++k) {
+            double x = msg[jptr[k] + l];
+            // (clip and comparisons as in bp4_cn_pass below; asking for every message before the first is used -- a fixed unroll of
+            // eight predicated positions -- made the pass 1.5x slower)
+            x = (x > 50.0) ? 50.0 : ((x < -50.0) ? -50.0 : x);
+            const double ax = (x != x) ? 1e308 : fabs(x);
+            arg = (ax < min1) ? k : arg;
+            min2 = fmin(min2, fmax(min1, ax));
+            min1 = fmin(min1, ax);
+            negm |= (x <= 0) ? (1ull << k) : 0ull;
+        }
+        const int sg = (cv ^ __popcll(negm)) & 1;
+        for (int k = 0; k < deg; ++k) {
+            const double mag = (k == arg) ? min2 : min1;
+            const int sgn = sg ^ (int)((negm >> k) & 1ull);
+            msg[jptr[k] + l] = mag * (sgn ? -alpha : alpha);
+        }
+    }
+    return unsat;
+}
+
 // plain min-sum CN pass over one graph: lanes [lane0, lane0 + g.m) of the block own its checks
 __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, double *msg, const uint16_t *jptr, const int8_t *cn,
                                             uint32_t *par, int lane0, int it, double alpha) {
@@ -164,6 +198,35 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         c_mx = bp4_log1pexp(-1. * c_lx) - bp4_logaddexp(-1. * c_ly, -1. * c_lz);
         c_mz = bp4_log1pexp(-1. * c_lz) - bp4_logaddexp(-1. * c_ly, -1. * c_lz); // sic (bp4_osd.pyx:438)
     }
+    // Round 5: when every check of both graphs has a thread (mx + mz <= NT: the notebooks' codes), a thread keeps ONE check for the
+    // whole launch -- the checks of Hx, then those of Hz, dealt to the waves in equal shares -- with its degree, its syndrome index
+    // and its arrays in registers: the check pass is one walk per wave instead of two half-empty ones (the wave that held the end
+    // of Hx and the start of Hz walked both: 2x the others, which waited for it at the barrier), and neither the pass nor the
+    // reset waits for a load of the graph's tables any more.
+    const int mtot = mx + mz;
+    const bool own = SWD_BP4_OWN_CHECK && mtot <= NT;
+    int o_l = -1, o_deg = 0, o_perm = 0;
+    bool o_z = false;
+    if (own) {
+        const int nw = NT >> 6, q = (mtot + nw - 1) / nw, c = (tid >> 6) * q + (tid & 63);
+        if ((tid & 63) < q && c < mtot) {
+            o_z = c >= mx;
+            o_l = o_z ? c - mx : c;
+            o_deg = o_z ? (int)gz.row_deg[o_l] : (int)gx.row_deg[o_l];
+            o_perm = o_z ? (int)gz.perm[o_l] : (int)gx.perm[o_l];
+        }
+    }
+    double *const o_msg = o_z ? msgz : msgx;
+    const uint16_t *const o_jp = o_z ? jpz : jpx;
+    int8_t *const o_cn = o_z ? cnz : cnx;
+    uint32_t *const o_par = o_z ? parz : parx;
+#ifdef SWD_BP4PROF // diagnostic build: cycles (s_memtime) per region of a decode, summed over the units of this workgroup
+    long long q_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q0_ = clock64();
+    long long q_iters = 0, q_units = 0;
+#define BP4T(i) { const long long t_ = clock64(); q_[i] += t_ - q0_; q0_ = t_; }
+#else
+#define BP4T(i)
+#endif
     for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const int b = a.camel ? unit >> 2 : unit;
     s.fpar = 0;
@@ -174,8 +237,12 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
     __syncthreads(); // the previous unit is done with LDS
 
     // reset + bp_init (bp4_osd.pyx:371-386, 425-442)
-    for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
-    for (int l = tid; l < mz; l += NT) cnz[l] = (int8_t)(sz_b[gz.perm[l]] ? 1 : 0);
+    if (own) {
+        if (o_l >= 0) o_cn[o_l] = (int8_t)((o_z ? sz_b : sx_b)[o_perm] ? 1 : 0);
+    } else {
+        for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
+        for (int l = tid; l < mz; l += NT) cnz[l] = (int8_t)(sz_b[gz.perm[l]] ? 1 : 0);
+    }
     for (int v = tid; v < n; v += NT) {
         decx[v] = 0; decz[v] = 0;
         double m_x = c_mx, m_z = c_mz;
@@ -202,13 +269,21 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         __syncthreads();
     }
 
+    BP4T(0) // reset + bp_init
     // bp4_decode_llr (bp4_osd.pyx:444-481)
     int conv = 0, iters = 0;
     const int lane0z = (mx + mz <= NT) ? mx : 0; // Hz checks on the lanes after the Hx ones when both fit
     for (int it = 0; it < a.max_iter; ++it) {
-        bool unsat = bp4_cn_pass(NT, gx, msgx, jpx, cnx, parx, 0, it, a.alpha);
-        unsat |= bp4_cn_pass(NT, gz, msgz, jpz, cnz, parz, lane0z, it, a.alpha);
+        bool unsat = false;
+        if (own) {
+            if (o_l >= 0) unsat = bp4_cn_one(o_msg, o_jp, o_cn, o_par, o_l, o_deg, it, a.alpha);
+        } else {
+            unsat = bp4_cn_pass(NT, gx, msgx, jpx, cnx, parx, 0, it, a.alpha);
+            unsat |= bp4_cn_pass(NT, gz, msgz, jpz, cnz, parz, lane0z, it, a.alpha);
+        }
+        BP4T(1) // check passes
         const bool any = bp4_block_any(unsat, s, NT >> 6);
+        BP4T(2) // flags + barrier
         if (it > 0 && !any) { conv = 1; iters = it; break; }
         for (int v = tid; v < n; v += NT) { // vn_update (bp4_osd.pyx:533-589)
             if (v == fixed) { // decided (bp4_osd.pyx:456-458): its bit-to-check messages stay the priors of bp_init; the
@@ -248,7 +323,9 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
             else idx = 3;
             const int bx = idx & 1, bz = idx >> 1;
             decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz;
+            BP4T(3) // node: message loads, sums, posteriors, decision
             const double num_hx = bp4_log1pexp(-1. * llrx_hx);
+            BP4T(4) // log1pexp
 #if SWD_BP4_ROLLED // one body of the helper per basis instead of DM: the edge word is picked by a select chain, the message re-read from LDS
             auto pick = [&](const uint32_t (&ev)[DM], int k) { uint32_t e = ev[0];
 #pragma unroll
@@ -262,7 +339,9 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
                 msgx[swd_edge_slot(e)] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb);
                 if (bz) atomicXor(&parx[swd_edge_lane(e)], 1u); // Hx * z-string
             }
+            BP4T(5) // Hx edges: logaddexp + store + parity flip each
             const double num_hz = bp4_log1pexp(-1. * llrz_hz);
+            BP4T(4)
 #pragma unroll 1
             for (int k = 0; k < dz; ++k) {
                 const uint32_t e = pick(ez, k);
@@ -271,6 +350,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
                 msgz[swd_edge_slot(e)] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb);
                 if (bx) atomicXor(&parz[swd_edge_lane(e)], 1u); // Hz * x-string
             }
+            BP4T(6) // Hz edges
 #else
 #pragma unroll
             for (int k = 0; k < DM; ++k)
@@ -290,6 +370,10 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
 #endif
         }
         __syncthreads();
+        BP4T(7) // barrier behind the node pass
+#ifdef SWD_BP4PROF
+        ++q_iters;
+#endif
     }
     if (p_set) { lpr_b[tid] = p_x; lpr_b[n + tid] = p_y; lpr_b[2 * n + tid] = p_z; } // (read back below by this thread only)
     if (!conv) {
@@ -336,7 +420,16 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         st[0] = exit_class | (conv ? SWD_STATUS_CONVERGE : 0);
         st[1] = iters; st[2] = iters; st[3] = 0; st[4] = n; st[5] = mx + mz; st[6] = gx.E + gz.E; st[7] = 0;
     }
+    BP4T(8) // exit test, result stores
+#ifdef SWD_BP4PROF
+    ++q_units;
+#endif
     } // next unit
+#ifdef SWD_BP4PROF
+    if ((tid & 63) == 0 && (blockIdx.x % 97) == 0)
+        printf("bp4prof block %d wave %d: units %lld node passes %lld | reset+init %lld | check passes %lld | flags+barrier %lld | node head %lld | log1pexp x2 %lld | Hx edges %lld | Hz edges %lld | end barrier %lld | tail %lld cycles\n",
+               (int)blockIdx.x, tid >> 6, q_units, q_iters, q_[0], q_[1], q_[2], q_[3], q_[4], q_[5], q_[6], q_[7], q_[8]);
+#endif
 }
 
 // The decodes the BP kernel queued (bp4_osd.pyx:212-219: osd('x') and osd('z') when BP did not converge), one per workgroup at a time:

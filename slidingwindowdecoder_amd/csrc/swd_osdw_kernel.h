@@ -220,6 +220,10 @@ struct Lds {
     double *dbl;        // [24]
     int *iaux;          // [32]
     int fpar;
+    // large-graph kernels, full-graph phase (SWD_BIG_HYBRID): message cells at byte offsets >= msg_lo live in LDS -- at msg_alt +
+    // (offset - msg_lo) -- the others in the HBM scratch region as ever
+    char *msg_alt;
+    uint32_t msg_lo;
     // work assignment ids (== threadIdx.x up to a permutation of the waves, see swd_wave_roles): ctid picks
     // the check a thread serves, vtid its variable nodes
     int ctid, vtid;
@@ -533,16 +537,24 @@ __device__ __forceinline__ void vn_cache_load_compact(const SwdGraphDev &g, Lds 
 }
 
 __device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
+template <bool HYB>
+__device__ __forceinline__ double &swd_msg_h(Lds &s, uint32_t ed) {
+    if constexpr (HYB) { // (no pre-subtracted base: arithmetic that leaves the LDS block is folded into its 32-bit offset and wraps)
+        const bool up = ed >= s.msg_lo;
+        return *(double *)((up ? s.msg_alt : (char *)s.msg) + (up ? ed - s.msg_lo : ed));
+    }
+    else return *(double *)((char *)s.msg + ed);
+}
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
-template <int VF, int DM, int SH, bool PB>
+template <int VF, int DM, bool HYB = false, int SH, bool PB>
 __device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM, SH, PB> &c) {
 #pragma unroll
     for (int i = 0; i < VF; ++i) {
         uint32_t ad[DM];
         c.get_ed(i, ad);
 #pragma unroll
-        for (int k = 0; k < DM; ++k) swd_msg_at(s, ad[k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
+        for (int k = 0; k < DM; ++k) swd_msg_h<HYB>(s, ad[k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
     }
 }
 
@@ -711,7 +723,7 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // that classifies the position afterwards, and without the stores the iteration barriers no longer wait for HBM.
 // TIER (sorted form of the shortened graph, vn_cache_load_compact): kcap[i] = largest number of live edges among the nodes the wave
 // serves in cache row i; the variable-node pass runs over the first 2, 4, ... DM positions only (a wave-uniform choice per row).
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, int SH, bool PB>
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, bool HYB = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr, bool rec_early = false,
@@ -742,8 +754,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #ifdef SWD_BPPROF
     if (!FULL && (tid & 63) == 0) ((uint8_t *)&s.scal[28])[tid >> 6] = (uint8_t)wmax;
 #endif
-    s.msg[farslot] = 64.0;
-    s.msg[zeroslot] = 0.0;
+    swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0;
+    swd_msg_h<HYB>(s, (uint32_t)zeroslot << 3) = 0.0;
     char *const parb = (char *)s.par;
     // (shortened graph) the node a list entry names does not change during the run: read once, not once per iteration
     // (full graph in tiers: the listed order of the graph, SwdGraphDev::vperm)
@@ -795,10 +807,10 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     cn.group(gq, ad);
                     const bool hi = !kHalf || gq * 4 + 2 < wmax; // (wave-uniform) does any lane walk the group's second half?
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) xs[u] = swd_msg_at(s, ad[u]);
+                    for (int u = 0; u < 2; ++u) xs[u] = swd_msg_h<HYB>(s, ad[u]);
                     if (hi) {
 #pragma unroll
-                        for (int u = 2; u < 4; ++u) xs[u] = swd_msg_at(s, ad[u]);
+                        for (int u = 2; u < 4; ++u) xs[u] = swd_msg_h<HYB>(s, ad[u]);
                     }
                     auto one = [&](auto u_tag) {
                         constexpr int u = decltype(u_tag)::value;
@@ -866,7 +878,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             }
             const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
             // the first position holding the minimum gets the second minimum (ties: both equal); its own sign: argneg
-            if constexpr (!SWD_BP_XARG_TRACK) argneg = (swd_msg_at(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
+            if constexpr (!SWD_BP_XARG_TRACK) argneg = (swd_msg_h<HYB>(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
             if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
             const double p1 = min1 * alpha, p2 = min2 * alpha;
             const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
@@ -880,7 +892,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                         const int k = gq * 4 + u;
                         const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
                         const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
-                        swd_msg_at(s, ad[u]) = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
+                        swd_msg_h<HYB>(s, ad[u]) = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
                     };
                     put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{});
                     if (!kHalf || gq * 4 + 2 < wmax) { put(std::integral_constant<int, 2>{}); put(std::integral_constant<int, 3>{}); }
@@ -889,8 +901,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             {
                 const uint32_t sb = ((0u - argneg) ^ flip) & 0x80000000u;
                 const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
-                swd_msg_at(s, argslot) = __longlong_as_double((long long)b2);
-                s.msg[farslot] = 64.0; // re-arm
+                swd_msg_h<HYB>(s, argslot) = __longlong_as_double((long long)b2);
+                swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0; // re-arm
             }
         }
         BPT(tc1);
@@ -913,7 +925,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         if (kFlagMerge && nch > 0) { // (wave-uniform)
             c.get_ed(0, ad0);
 #pragma unroll
-            for (int k = 0; k < DM; ++k) cc0[k] = swd_msg_at(s, ad0[k]);
+            for (int k = 0; k < DM; ++k) cc0[k] = swd_msg_h<HYB>(s, ad0[k]);
 #pragma unroll
             for (int k = 0; k < DM; ++k) asm volatile("" : "+v"(cc0[k])); // (loaded here, in front of the exit test)
         }
@@ -950,7 +962,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 } else {
                     c.get_ed(i, ad);
 #pragma unroll
-                    for (int k = 0; k < KD; ++k) cc[k] = swd_msg_at(s, ad[k]);
+                    for (int k = 0; k < KD; ++k) cc[k] = swd_msg_h<HYB>(s, ad[k]);
                 }
                 double temp = c.llr[i];
 #pragma unroll
@@ -969,15 +981,15 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 double suf = 0.0;
 #pragma unroll
                 for (int k = KD - 1; k >= 0; --k) {
-                    swd_msg_at(s, ad[k]) = pre[k] + suf;
+                    swd_msg_h<HYB>(s, ad[k]) = pre[k] + suf;
                     suf = suf + cc[k];
                 }
-                s.msg[zeroslot] = 0.0; // re-arm
+                swd_msg_h<HYB>(s, (uint32_t)zeroslot << 3) = 0.0; // re-arm
 #ifdef SWD_EXP_EXTRA_LDS // experiment: N more LDS reads per node and iteration (is the LDS pipeline what the iterations queue for?)
                 {
                     double dx_[SWD_EXP_EXTRA_LDS];
 #pragma unroll
-                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) dx_[e_] = *(volatile double *)&s.msg[farslot];
+                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) dx_[e_] = *(volatile double *)&swd_msg_h<HYB>(s, (uint32_t)farslot << 3);
 #pragma unroll
                     for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) asm volatile("" :: "v"(dx_[e_]));
                 }
@@ -1466,6 +1478,9 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 #endif
 #ifndef SWD_WIDE_EVAL_DS
 #define SWD_WIDE_EVAL_DS 0
+#endif
+#ifndef SWD_BIG_HYBRID
+#define SWD_BIG_HYBRID 1 // large-graph kernels: the top of the full graph's message array in the LDS region that idles during that phase
 #endif
 #ifndef SWD_OSD_WIDE
 #define SWD_OSD_WIDE 1 // large-graph kernels: the column-form elimination on fifteen column waves (osd0_colsw) instead of osd0_block
@@ -3043,7 +3058,17 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 #ifdef SWD_INITPROF
     const long long ip2 = wall_clock64();
 #endif
-    bp_init<VF, DM>(s, vc);
+    // large graphs: the LDS region that will hold the shortened graph's messages / the OSD arrays is idle in this phase -- the TOP of the
+    // message array (the far and zero slots included) lives there, one select per access (flat addresses reach both memories)
+    constexpr bool kHyb = BIG && SWD_BIG_HYBRID;
+    if constexpr (kHyb) {
+        const int cells = g.E + 1 + 2 * (NT / 64);
+        const int cap = (L.off_pmsg >= 0) ? L.pmsg_bytes / 8 : 0;
+        const int lo = max(cells - cap, 0);
+        s.msg_lo = (cap > 0) ? (uint32_t)lo << 3 : 0xFFFFFFFFu;
+        s.msg_alt = (char *)s.hard - L.off_hard + (L.off_pmsg >= 0 ? L.off_pmsg : 0);
+    }
+    bp_init<VF, DM, kHyb>(s, vc);
 #ifdef SWD_INITPROF
     const long long ip3 = wall_clock64();
 #endif
@@ -3068,7 +3093,7 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     double hs[VF]; // HACC: summed posterior history of this thread's variable nodes
 #pragma unroll
     for (int i = 0; i < VF; ++i) hs[i] = 0.0;
-    R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, kFullSorted>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs, nullptr, false,
+    R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, kFullSorted, kHyb>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs, nullptr, false,
                                                                         kFullSorted ? kcf : nullptr);
     R.pre_it = it;
     R.t[2] = wall_clock64();
