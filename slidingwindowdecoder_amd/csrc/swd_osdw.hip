@@ -98,7 +98,8 @@ int make_layout(const Graph &g, int new_n, int nt, int kind, SwdLdsLayout &L, bo
     // large graphs, 256 < m <= 960: ring (64 or 32 entries of 16 words), pivoted-row mask and control words of osd0_colsw
     L.off_owide = -1; L.owide_ring = 0;
     if (big && kind == 0 && nt == 1024 && wm > 4 && wm <= 15 && !getenv("SWD_NO_OSD_WIDE")) {
-        for (int ring = 64; ring >= 32; ring >>= 1) {
+        const char *rq = getenv("SWD_OWIDE_RING"); // (tests: a smaller ring, so that batches close early)
+        for (int ring = rq ? std::max(atoi(rq), 4) : 64; ring >= (rq ? 4 : 32); ring >>= 1) {
             const int bytes = align_up(ring * 16 * 8 + 16 * 8 + 64, 16);
             if (o + bytes <= lds_budget) { L.off_owide = o; L.owide_ring = ring; o += bytes; break; }
         }

@@ -73,6 +73,15 @@ def test_random_large_matrices_vs_oracle(m, n, colw, pre, post):
     assert np.array_equal(dev.last_status & 0xFF, res["exit_class"])
 
 
+@pytest.mark.parametrize("ring", ["8", "32"])
+def test_column_form_elimination_with_a_short_ring(ring, monkeypatch):
+    """osd0_colsw (large graphs, 256 < m <= 960) when a batch of 64 sorted columns holds more pivots than its ring has entries: the
+    batch closes early and the next one starts behind its last pivot column (SWD_OWIDE_RING is read when the layout is made)"""
+    monkeypatch.setenv("SWD_OWIDE_RING", ring)
+    test_random_large_matrices_vs_oracle(900, 8600, 4, 3, 5)
+    test_random_large_matrices_vs_oracle(512, 9000, 3, 8, 16)
+
+
 def test_bb288_wide_windows_pipeline_vs_oracle():
     """[[288,12,18]] with (W,F) = (5,1): 720 x 6336 window matrices, 173 KB of messages -- the sliding-window pipeline on the
     large-graph kernels against the oracle driven through the host window loop"""
