@@ -224,6 +224,10 @@ struct Lds {
     // (offset - msg_lo) -- the others in the HBM scratch region as ever
     char *msg_alt;
     uint32_t msg_lo;
+    // ... and (SWD_BIG_REC) the check-to-bit messages are not stored at all: a check leaves ONE record of 32 bytes in LDS -- the two
+    // magnitudes, the sign bits of its positions (flip applied), the position of the first minimum -- and a variable node rebuilds
+    // the message of an edge from the record of the edge's check; the message array only ever holds bit-to-check messages
+    char *rec;
     // work assignment ids (== threadIdx.x up to a permutation of the waves, see swd_wave_roles): ctid picks
     // the check a thread serves, vtid its variable nodes
     int ctid, vtid;
@@ -443,7 +447,8 @@ __device__ __forceinline__ void vn_cache_pack(const SwdGraphDev &g, const Lds &s
 
 // ALLEDGES (with !FULL): the listed nodes with every edge of theirs, whatever the state of the checks.
 // SORTED (with FULL): entry idx = the idx-th node of the graph's listed order (vperm); kc (optional): the rows' degree caps (vn_row_caps)
-template <int NT, int VF, int DM, bool FULL, bool ALLEDGES = false, bool SORTED = false, int SH, bool PB>
+// JPACK: the halves of par[][] carry the edge's position inside its check's row in bits 10..15 (lane numbers need ten: bp_run<..., REC>)
+template <int NT, int VF, int DM, bool FULL, bool ALLEDGES = false, bool SORTED = false, bool JPACK = false, int SH, bool PB>
 __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int nlive, VnCacheP<VF, DM, SH, PB> &c, uint16_t *remap = nullptr, int (*kc)[VF] = nullptr) {
     static_assert(!SORTED || FULL, "the listed order belongs to the full graph");
     const int n = g.n, cnt = FULL ? n : nlive;
@@ -479,8 +484,9 @@ __device__ __forceinline__ void vn_cache_load(const SwdGraphDev &g, Lds &s, int 
                     uint32_t slot = swd_edge_slot(e);
                     if (!FULL && remap) { const uint32_t cell = (uint32_t)(k * nlive + idx); remap[slot] = (uint16_t)cell; slot = cell; }
                     c.set_ed(i, k, slot << 3);
-                    c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | ((swd_edge_lane(e) << PS) << 16))
-                                               : ((c.par[i][k >> 1] & 0xFFFF0000u) | (swd_edge_lane(e) << PS));
+                    const uint32_t ph = (swd_edge_lane(e) << PS) | (JPACK ? (swd_edge_j(e) << 10) : 0u);
+                    c.par[i][k >> 1] = (k & 1) ? ((c.par[i][k >> 1] & 0xFFFFu) | (ph << 16))
+                                               : ((c.par[i][k >> 1] & 0xFFFF0000u) | ph);
                 }
             }
         }
@@ -537,6 +543,7 @@ __device__ __forceinline__ void vn_cache_load_compact(const SwdGraphDev &g, Lds 
 }
 
 __device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
+typedef uint32_t swd_u32x4r __attribute__((ext_vector_type(4)));
 template <bool HYB>
 __device__ __forceinline__ double &swd_msg_h(Lds &s, uint32_t ed) {
     if constexpr (HYB) { // (no pre-subtracted base: arithmetic that leaves the LDS block is folded into its 32-bit offset and wraps)
@@ -723,7 +730,7 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // that classifies the position afterwards, and without the stores the iteration barriers no longer wait for HBM.
 // TIER (sorted form of the shortened graph, vn_cache_load_compact): kcap[i] = largest number of live edges among the nodes the wave
 // serves in cache row i; the variable-node pass runs over the first 2, 4, ... DM positions only (a wave-uniform choice per row).
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, bool HYB = false, int SH, bool PB>
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, bool HYB = false, bool REC = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr, bool rec_early = false,
@@ -816,7 +823,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                         constexpr int u = decltype(u_tag)::value;
                         const int k = gq * 4 + u;
                         const double ax = vminabs64(xs[u], 50.0);
-                        if constexpr (SWD_BP_XARG_TRACK) argk = (ax < min1) ? (uint32_t)k : argk;
+                        if constexpr (SWD_BP_XARG_TRACK || REC) argk = (ax < min1) ? (uint32_t)k : argk;
                         argslot = (ax < min1) ? ad[u] : argslot; // (as sign-of-difference mask + v_bfi instead of v_cmp + v_cndmask: 10.1 against 10.0 ms, round 4)
                         min2 = vmin64(min2, vmax64(min1, ax));
                         min1 = vmin64(min1, ax);
@@ -878,10 +885,21 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             }
             const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
             // the first position holding the minimum gets the second minimum (ties: both equal); its own sign: argneg
-            if constexpr (!SWD_BP_XARG_TRACK) argneg = (swd_msg_h<HYB>(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
+            if constexpr (!SWD_BP_XARG_TRACK && !REC) argneg = (swd_msg_h<HYB>(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
             if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
             const double p1 = min1 * alpha, p2 = min2 * alpha;
             const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
+            if constexpr (REC) { // one record per check instead of a message per edge (position k's sign bit: bit 31 - k % 32 of word k / 32)
+                static_assert(FULL && !SF && NR <= 2, "records: one thread per check, at most 64 positions");
+                if (cn.l >= 0) {
+                    swd_u32x4r q0, q1;
+                    q0.x = p1lo; q0.y = p1hi; q0.z = (uint32_t)__double_as_longlong(p2); q0.w = (uint32_t)(__double_as_longlong(p2) >> 32);
+                    q1.x = neg[0] ^ flip; q1.y = (NR > 1 ? neg[NR - 1] : 0u) ^ flip; q1.z = argk; q1.w = 0u;
+                    *(swd_u32x4r *)(s.rec + (size_t)l * 32) = q0;
+                    *(swd_u32x4r *)(s.rec + (size_t)l * 32 + 16) = q1;
+                }
+                swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0; // (nothing overwrote it; kept for symmetry with the message form)
+            } else {
 #pragma unroll
             for (int gq = 0; gq < KG; ++gq) {
                 if (gq * 4 < wmax) {
@@ -904,6 +922,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 swd_msg_h<HYB>(s, argslot) = __longlong_as_double((long long)b2);
                 swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0; // re-arm
             }
+            } // (message form)
         }
         BPT(tc1);
         // block_any, cut in two: the per-wave flags go out before the barrier; behind it they are read TOGETHER with the first
@@ -961,8 +980,23 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     for (int k = 0; k < KD; ++k) { ad[k] = ad0[k]; cc[k] = cc0[k]; }
                 } else {
                     c.get_ed(i, ad);
+                    if constexpr (REC) { // the check-to-bit message of edge k from the record of its check (lane in bits 0..9, position in bits 10..15)
+#pragma unroll
+                        for (int k = 0; k < KD; ++k) {
+                            uint32_t pw = c.par[i][k >> 1];
+                            asm volatile("" : "+v"(pw));
+                            const uint32_t ph = (k & 1) ? (pw >> 16) : (pw & 0xFFFFu), ln_ = ph & 0x3FFu, j_ = ph >> 10;
+                            const swd_u32x4r q0 = *(const swd_u32x4r *)(s.rec + (size_t)ln_ * 32);
+                            const swd_u32x4r q1 = *(const swd_u32x4r *)(s.rec + (size_t)ln_ * 32 + 16);
+                            const bool isarg = j_ == q1.z;
+                            const uint32_t mlo = isarg ? q0.z : q0.x, mhi = isarg ? q0.w : q0.y;
+                            const uint32_t sb = (((j_ < 32u) ? q1.x : q1.y) << (j_ & 31u)) & 0x80000000u;
+                            cc[k] = __longlong_as_double((long long)(((uint64_t)(mhi | sb) << 32) | mlo));
+                        }
+                    } else {
 #pragma unroll
                     for (int k = 0; k < KD; ++k) cc[k] = swd_msg_h<HYB>(s, ad[k]);
+                    }
                 }
                 double temp = c.llr[i];
 #pragma unroll
@@ -1011,8 +1045,9 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                             if (2 * k2 + 1 < KD) atomicXor((uint32_t *)(parb + ((pw >> 16) & 0xFFFCu)), 1u << (((pw >> 16) & 3u) << 3));
                         } else {
                             constexpr int PS2 = 2 - VnCacheP<VF, DM, SH, PB>::par_shift; // (0: the halves are byte offsets already)
-                            atomicXor((uint32_t *)(parb + ((pw & 0xFFFFu) << PS2)), 1u);
-                            if (2 * k2 + 1 < KD) atomicXor((uint32_t *)(parb + ((pw >> 16) << PS2)), 1u);
+                            constexpr uint32_t LM = REC ? 0x3FFu : 0xFFFFu; // (REC: the halves carry the position above the lane number)
+                            atomicXor((uint32_t *)(parb + ((pw & LM) << PS2)), 1u);
+                            if (2 * k2 + 1 < KD) atomicXor((uint32_t *)(parb + (((pw >> 16) & LM) << PS2)), 1u);
                         }
                     }
                 }
@@ -1478,6 +1513,12 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 #endif
 #ifndef SWD_WIDE_EVAL_DS
 #define SWD_WIDE_EVAL_DS 0
+#endif
+#ifndef SWD_BIG_REC
+#define SWD_BIG_REC 0 // experiment (round 5, bit-exact): large-graph kernels, full-graph phase: one record per check in LDS instead of a check-to-bit
+                      // message per edge in HBM -- half the phase's traffic through L2 gone, 40.0 -> 38.8 us per iteration (the phase is bound by its
+                      // own instruction stream and its register spills, not by that traffic), and the shortened graph's iterations of the same
+                      // kernel 3.38 -> 3.78 us: 160 -> 156 k decodes/s, off
 #endif
 #ifndef SWD_BIG_HYBRID
 #define SWD_BIG_HYBRID 1 // large-graph kernels: the top of the full graph's message array in the LDS region that idles during that phase
@@ -3044,10 +3085,17 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
 #ifdef SWD_INITPROF
     const long long ip0 = wall_clock64();
 #endif
+    // large graphs: check-to-bit messages as one record per check in LDS (bp_run<..., REC>) when the layout's LDS block has room for them
+    constexpr bool kRec = BIG && SWD_BIG_REC && !kFullSorted && !kSplitLoad;
+    bool rec_on = false;
+    if constexpr (kRec) rec_on = L.off_pmsg >= 0 && m <= 1023 && L.pmsg_bytes >= (m + 1) * 32 + 4096;
     if constexpr (kSplitLoad) {
         vn_cache_pack<NT, VF, DM>(g, s, vraw, vc);
         if constexpr (kFullSorted) vn_row_caps<NT, VF, DM>(g, s, vraw.ev, kcf);
-    } else vn_cache_load<NT, VF, DM, true, false, kFullSorted>(g, s, n, vc, nullptr, kFullSorted ? &kcf : nullptr);
+    } else {
+        if (kRec && rec_on) { if constexpr (kRec) vn_cache_load<NT, VF, DM, true, false, false, true>(g, s, n, vc); }
+        else vn_cache_load<NT, VF, DM, true, false, kFullSorted>(g, s, n, vc, nullptr, kFullSorted ? &kcf : nullptr);
+    }
 #ifdef SWD_INITPROF
     asm volatile("" : "+v"(vc.edp[VF - 1][0]), "+v"(vc.llr[0]));
     const long long ip1 = wall_clock64();
@@ -3061,12 +3109,19 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     // large graphs: the LDS region that will hold the shortened graph's messages / the OSD arrays is idle in this phase -- the TOP of the
     // message array (the far and zero slots included) lives there, one select per access (flat addresses reach both memories)
     constexpr bool kHyb = BIG && SWD_BIG_HYBRID;
+    const int rec_b = (kRec && rec_on) ? (((m + 1) * 32 + 15) & ~15) : 0;
+    if constexpr (kRec) {
+        if (rec_on) {
+            s.rec = (char *)s.hard - L.off_hard + L.off_pmsg;
+            if (tid < 8) ((uint32_t *)(s.rec + (size_t)m * 32))[tid] = 0u; // the record dead positions point at: + 0.0
+        }
+    }
     if constexpr (kHyb) {
         const int cells = g.E + 1 + 2 * (NT / 64);
-        const int cap = (L.off_pmsg >= 0) ? L.pmsg_bytes / 8 : 0;
+        const int cap = (L.off_pmsg >= 0) ? (L.pmsg_bytes - rec_b) / 8 : 0;
         const int lo = max(cells - cap, 0);
         s.msg_lo = (cap > 0) ? (uint32_t)lo << 3 : 0xFFFFFFFFu;
-        s.msg_alt = (char *)s.hard - L.off_hard + (L.off_pmsg >= 0 ? L.off_pmsg : 0);
+        s.msg_alt = (char *)s.hard - L.off_hard + (L.off_pmsg >= 0 ? L.off_pmsg + rec_b : 0);
     }
     bp_init<VF, DM, kHyb>(s, vc);
 #ifdef SWD_INITPROF
@@ -3093,6 +3148,9 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     double hs[VF]; // HACC: summed posterior history of this thread's variable nodes
 #pragma unroll
     for (int i = 0; i < VF; ++i) hs[i] = 0.0;
+    if (kRec && rec_on) {
+        if constexpr (kRec) R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, false, kHyb, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs);
+    } else
     R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, kFullSorted, kHyb>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs, nullptr, false,
                                                                         kFullSorted ? kcf : nullptr);
     R.pre_it = it;
