@@ -227,7 +227,7 @@ struct Lds {
     // ... and (SWD_BIG_REC) the check-to-bit messages are not stored at all: a check leaves ONE record of 32 bytes in LDS -- the two
     // magnitudes, the sign bits of its positions (flip applied), the position of the first minimum -- and a variable node rebuilds
     // the message of an edge from the record of the edge's check; the message array only ever holds bit-to-check messages
-    char *rec;
+    __attribute__((address_space(3))) char *rec; // (an LDS pointer by type: ds_read / ds_write, not flat accesses)
     // work assignment ids (== threadIdx.x up to a permutation of the waves, see swd_wave_roles): ctid picks
     // the check a thread serves, vtid its variable nodes
     int ctid, vtid;
@@ -544,6 +544,36 @@ __device__ __forceinline__ void vn_cache_load_compact(const SwdGraphDev &g, Lds 
 
 __device__ __forceinline__ double &swd_msg_at(Lds &s, uint32_t ed) { return *(double *)((char *)s.msg + ed); }
 typedef uint32_t swd_u32x4r __attribute__((ext_vector_type(4)));
+// Hybrid store, explicit form: a FLAT access is worked through the texture addresser lane by lane whichever memory it ends in -- and the
+// scattered 8-byte accesses of the variable-node pass are bound by exactly that unit -- so the two memories get an instruction each
+// (ds_read / ds_write for the lanes in LDS, global_load / global_store for the rest, disjoint exec masks).
+#ifndef SWD_BIG_HYBRID_SPLIT
+#define SWD_BIG_HYBRID_SPLIT 1
+#endif
+#define SWD_AS3 __attribute__((address_space(3)))
+#define SWD_AS1 __attribute__((address_space(1)))
+template <bool HYB>
+__device__ __forceinline__ double swd_msg_ld(Lds &s, uint32_t ed) {
+    if constexpr (HYB && SWD_BIG_HYBRID_SPLIT) {
+        double v;
+        if (ed >= s.msg_lo) v = *(const SWD_AS3 double *)((SWD_AS3 char *)s.msg_alt + (ed - s.msg_lo));
+        else v = *(const SWD_AS1 double *)((SWD_AS1 char *)s.msg + ed);
+        return v;
+    } else if constexpr (HYB) {
+        const bool up = ed >= s.msg_lo;
+        return *(const double *)((up ? s.msg_alt : (char *)s.msg) + (up ? ed - s.msg_lo : ed));
+    } else return *(const double *)((char *)s.msg + ed);
+}
+template <bool HYB>
+__device__ __forceinline__ void swd_msg_st(Lds &s, uint32_t ed, double v) {
+    if constexpr (HYB && SWD_BIG_HYBRID_SPLIT) {
+        if (ed >= s.msg_lo) *(SWD_AS3 double *)((SWD_AS3 char *)s.msg_alt + (ed - s.msg_lo)) = v;
+        else *(SWD_AS1 double *)((SWD_AS1 char *)s.msg + ed) = v;
+    } else if constexpr (HYB) {
+        const bool up = ed >= s.msg_lo;
+        *(double *)((up ? s.msg_alt : (char *)s.msg) + (up ? ed - s.msg_lo : ed)) = v;
+    } else *(double *)((char *)s.msg + ed) = v;
+}
 template <bool HYB>
 __device__ __forceinline__ double &swd_msg_h(Lds &s, uint32_t ed) {
     if constexpr (HYB) { // (no pre-subtracted base: arithmetic that leaves the LDS block is folded into its 32-bit offset and wraps)
@@ -551,6 +581,23 @@ __device__ __forceinline__ double &swd_msg_h(Lds &s, uint32_t ed) {
         return *(double *)((up ? s.msg_alt : (char *)s.msg) + (up ? ed - s.msg_lo : ed));
     }
     else return *(double *)((char *)s.msg + ed);
+}
+
+// bp_init for the table form of the full graph (bp_run<..., TBL>)
+template <int NT, int VF, int DM, bool HYB>
+__device__ __forceinline__ void bp_init_tbl(const SwdGraphDev &g, Lds &s) {
+    const int n = g.n;
+#pragma unroll 1
+    for (int i = 0; i < VF; ++i) {
+        const int idx = s.vtid + i * NT;
+        if (idx < n) {
+            const double l = g.llr[idx];
+            for (int k = 0; k < g.D; ++k) {
+                const uint32_t e = g.vn_edge[k * n + idx];
+                if (e != SWD_PAD_EDGE) swd_msg_st<HYB>(s, swd_edge_slot(e) << 3, l);
+            }
+        }
+    }
 }
 
 // bp_init (osd_window.pyx:370-379): b2c <- prior on every live edge of every live VN
@@ -561,7 +608,7 @@ __device__ __forceinline__ void bp_init(Lds &s, const VnCacheP<VF, DM, SH, PB> &
         uint32_t ad[DM];
         c.get_ed(i, ad);
 #pragma unroll
-        for (int k = 0; k < DM; ++k) swd_msg_h<HYB>(s, ad[k]) = c.llr[i]; // dead positions land in Z_w (re-armed by bp_run)
+        for (int k = 0; k < DM; ++k) swd_msg_st<HYB>(s, ad[k], c.llr[i]); // dead positions land in Z_w (re-armed by bp_run)
     }
 }
 
@@ -730,7 +777,10 @@ __device__ __forceinline__ void cn_assign(const SwdGraphDev &g, Lds &s, int *dhi
 // that classifies the position afterwards, and without the stores the iteration barriers no longer wait for HBM.
 // TIER (sorted form of the shortened graph, vn_cache_load_compact): kcap[i] = largest number of live edges among the nodes the wave
 // serves in cache row i; the variable-node pass runs over the first 2, 4, ... DM positions only (a wave-uniform choice per row).
-template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, bool HYB = false, bool REC = false, int SH, bool PB>
+// TBL (large-graph kernels, full graph): no register cache of the variable nodes -- a row's edge words and prior come from the graph's
+// tables (coalesced, L2-resident, shared by every workgroup), asked for one row ahead; nine rows of cache do not fit that kernel's 128
+// registers beside the check cache and came back from scratch, row by row, inside the iterations.
+template <int NT, int VF, int DM, int KG, bool FULL, bool SF = false, bool ACC = false, bool SPARSE = false, bool TIER = false, bool HYB = false, bool REC = false, bool TBL = false, int SH, bool PB>
 __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParams &P, Lds &s, int max_iter, int nlive,
                       const VnCacheP<VF, DM, SH, PB> &c, const CnCacheP<KG, SH> &cn, double *hist_b, int &iters_done,
                       double alpha, bool force_unsat = false, double *hs = nullptr, double (*h4)[4] = nullptr, bool rec_early = false,
@@ -761,8 +811,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #ifdef SWD_BPPROF
     if (!FULL && (tid & 63) == 0) ((uint8_t *)&s.scal[28])[tid >> 6] = (uint8_t)wmax;
 #endif
-    swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0;
-    swd_msg_h<HYB>(s, (uint32_t)zeroslot << 3) = 0.0;
+    swd_msg_st<HYB>(s, (uint32_t)farslot << 3, 64.0);
+    swd_msg_st<HYB>(s, (uint32_t)zeroslot << 3, 0.0);
     char *const parb = (char *)s.par;
     // (shortened graph) the node a list entry names does not change during the run: read once, not once per iteration
     // (full graph in tiers: the listed order of the graph, SwdGraphDev::vperm)
@@ -779,6 +829,22 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #else
 #define BPT(x)
 #endif
+    static_assert(!TBL || (FULL && !TIER && !REC && !SPARSE && !PB), "table form: the full graph of the large-graph kernels");
+    [[maybe_unused]] uint32_t tbe[3][DM]; // edge words of rows i, i + 1, i + 2 (asked for two rows ahead)
+    [[maybe_unused]] double tbl[3];
+    [[maybe_unused]] auto tb_addr = [&](int row, const uint32_t (&e)[DM], uint32_t (&ad_)[DM]) {
+        const bool ok = s.vtid + row * NT < n;
+        const uint32_t dead_ = (uint32_t)zeroslot << 3;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) ad_[k] = (ok && k < g.D && e[k] != SWD_PAD_EDGE) ? (swd_edge_slot(e[k]) << 3) : dead_;
+    };
+    [[maybe_unused]] auto tb_load = [&](int row, uint32_t (&e)[DM], double &lv_) {
+        const int idx = s.vtid + row * NT;
+        const int v = (idx < n) ? idx : 0;
+        lv_ = g.llr[v];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) e[k] = g.vn_edge[max(min(k, g.D - 1), 0) * n + v];
+    };
     for (int it = 0; it < max_iter; ++it) {
         bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
         BPT(tc0);
@@ -814,10 +880,10 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     cn.group(gq, ad);
                     const bool hi = !kHalf || gq * 4 + 2 < wmax; // (wave-uniform) does any lane walk the group's second half?
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) xs[u] = swd_msg_h<HYB>(s, ad[u]);
+                    for (int u = 0; u < 2; ++u) xs[u] = swd_msg_ld<HYB>(s, ad[u]);
                     if (hi) {
 #pragma unroll
-                        for (int u = 2; u < 4; ++u) xs[u] = swd_msg_h<HYB>(s, ad[u]);
+                        for (int u = 2; u < 4; ++u) xs[u] = swd_msg_ld<HYB>(s, ad[u]);
                     }
                     auto one = [&](auto u_tag) {
                         constexpr int u = decltype(u_tag)::value;
@@ -885,7 +951,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             }
             const uint32_t flip = (npar & 1) ? 0xFFFFFFFFu : 0u;
             // the first position holding the minimum gets the second minimum (ties: both equal); its own sign: argneg
-            if constexpr (!SWD_BP_XARG_TRACK && !REC) argneg = (swd_msg_h<HYB>(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
+            if constexpr (!SWD_BP_XARG_TRACK && !REC) argneg = (swd_msg_ld<HYB>(s, argslot) <= 0) ? 1u : 0u; // (re-read before the slots are overwritten)
             if (cn.live == 1) min1 = min2 = 1e308; // minimum over no other edge (the far slot may have come first)
             const double p1 = min1 * alpha, p2 = min2 * alpha;
             const uint32_t p1lo = (uint32_t)__double_as_longlong(p1), p1hi = (uint32_t)(__double_as_longlong(p1) >> 32);
@@ -895,10 +961,10 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     swd_u32x4r q0, q1;
                     q0.x = p1lo; q0.y = p1hi; q0.z = (uint32_t)__double_as_longlong(p2); q0.w = (uint32_t)(__double_as_longlong(p2) >> 32);
                     q1.x = neg[0] ^ flip; q1.y = (NR > 1 ? neg[NR - 1] : 0u) ^ flip; q1.z = argk; q1.w = 0u;
-                    *(swd_u32x4r *)(s.rec + (size_t)l * 32) = q0;
-                    *(swd_u32x4r *)(s.rec + (size_t)l * 32 + 16) = q1;
+                    *(SWD_AS3 swd_u32x4r *)(s.rec + l * 32) = q0;
+                    *(SWD_AS3 swd_u32x4r *)(s.rec + l * 32 + 16) = q1;
                 }
-                swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0; // (nothing overwrote it; kept for symmetry with the message form)
+                swd_msg_st<HYB>(s, (uint32_t)farslot << 3, 64.0); // (nothing overwrote it; kept for symmetry with the message form)
             } else {
 #pragma unroll
             for (int gq = 0; gq < KG; ++gq) {
@@ -910,7 +976,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                         const int k = gq * 4 + u;
                         const uint32_t sb = ((neg[k >> 5] ^ flip) << (k & 31)) & 0x80000000u;
                         const uint32_t hi = sb | p1hi; // p1 >= +0: value * (+-alpha) is the magnitude with this sign
-                        swd_msg_h<HYB>(s, ad[u]) = __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo));
+                        swd_msg_st<HYB>(s, ad[u], __longlong_as_double((long long)(((uint64_t)hi << 32) | p1lo)));
                     };
                     put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{});
                     if (!kHalf || gq * 4 + 2 < wmax) { put(std::integral_constant<int, 2>{}); put(std::integral_constant<int, 3>{}); }
@@ -919,8 +985,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             {
                 const uint32_t sb = ((0u - argneg) ^ flip) & 0x80000000u;
                 const uint64_t b2 = (uint64_t)__double_as_longlong(p2) | ((uint64_t)sb << 32);
-                swd_msg_h<HYB>(s, argslot) = __longlong_as_double((long long)b2);
-                swd_msg_h<HYB>(s, (uint32_t)farslot << 3) = 64.0; // re-arm
+                swd_msg_st<HYB>(s, argslot, __longlong_as_double((long long)b2));
+                swd_msg_st<HYB>(s, (uint32_t)farslot << 3, 64.0); // re-arm
             }
             } // (message form)
         }
@@ -934,6 +1000,10 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             const int fp_ = (s.fpar++) & 1;
             const unsigned long long bu = __ballot(unsat);
             if ((tid & 63) == 0) s.flags[fp_ * 16 + (tid >> 6)] = (bu != 0ull);
+            if constexpr (TBL) { // (in flight across the barrier)
+                if (nch > 0) tb_load(0, tbe[0], tbl[0]);
+                if (nch > 1) tb_load(1, tbe[1], tbl[1]);
+            }
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < NW; ++w) anyr |= s.flags[fp_ * 16 + w];
@@ -944,7 +1014,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         if (kFlagMerge && nch > 0) { // (wave-uniform)
             c.get_ed(0, ad0);
 #pragma unroll
-            for (int k = 0; k < DM; ++k) cc0[k] = swd_msg_h<HYB>(s, ad0[k]);
+            for (int k = 0; k < DM; ++k) cc0[k] = swd_msg_ld<HYB>(s, ad0[k]);
 #pragma unroll
             for (int k = 0; k < DM; ++k) asm volatile("" : "+v"(cc0[k])); // (loaded here, in front of the exit test)
         }
@@ -978,6 +1048,13 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 if (kFlagMerge && i == 0) {
 #pragma unroll
                     for (int k = 0; k < KD; ++k) { ad[k] = ad0[k]; cc[k] = cc0[k]; }
+                } else if constexpr (TBL) {
+                    // (the messages of row i + 1 asked for here as well, one row ahead: 41.6 -> 51.0 us per iteration -- the pass is bound by the
+                    //  texture addresser's rate for scattered accesses, not by their latency)
+                    if (i + 2 < nch) tb_load(i + 2, tbe[(i + 2) % 3], tbl[(i + 2) % 3]);      // (uniform) edge words, two rows ahead
+                    tb_addr(i, tbe[i % 3], ad);
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) cc[k] = swd_msg_ld<HYB>(s, ad[k]);
                 } else {
                     c.get_ed(i, ad);
                     if constexpr (REC) { // the check-to-bit message of edge k from the record of its check (lane in bits 0..9, position in bits 10..15)
@@ -986,8 +1063,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                             uint32_t pw = c.par[i][k >> 1];
                             asm volatile("" : "+v"(pw));
                             const uint32_t ph = (k & 1) ? (pw >> 16) : (pw & 0xFFFFu), ln_ = ph & 0x3FFu, j_ = ph >> 10;
-                            const swd_u32x4r q0 = *(const swd_u32x4r *)(s.rec + (size_t)ln_ * 32);
-                            const swd_u32x4r q1 = *(const swd_u32x4r *)(s.rec + (size_t)ln_ * 32 + 16);
+                            const swd_u32x4r q0 = *(const SWD_AS3 swd_u32x4r *)(s.rec + ln_ * 32);
+                            const swd_u32x4r q1 = *(const SWD_AS3 swd_u32x4r *)(s.rec + ln_ * 32 + 16);
                             const bool isarg = j_ == q1.z;
                             const uint32_t mlo = isarg ? q0.z : q0.x, mhi = isarg ? q0.w : q0.y;
                             const uint32_t sb = (((j_ < 32u) ? q1.x : q1.y) << (j_ & 31u)) & 0x80000000u;
@@ -995,10 +1072,11 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                         }
                     } else {
 #pragma unroll
-                    for (int k = 0; k < KD; ++k) cc[k] = swd_msg_h<HYB>(s, ad[k]);
+                    for (int k = 0; k < KD; ++k) cc[k] = swd_msg_ld<HYB>(s, ad[k]);
                     }
                 }
-                double temp = c.llr[i];
+                double temp;
+                if constexpr (TBL) temp = valid ? tbl[i % 3] : 0.0; else temp = c.llr[i];
 #pragma unroll
                 for (int k = 0; k < KD; ++k) { pre[k] = temp; temp = temp + cc[k]; }
                 if constexpr (ACC) {
@@ -1015,15 +1093,15 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                 double suf = 0.0;
 #pragma unroll
                 for (int k = KD - 1; k >= 0; --k) {
-                    swd_msg_h<HYB>(s, ad[k]) = pre[k] + suf;
+                    swd_msg_st<HYB>(s, ad[k], pre[k] + suf);
                     suf = suf + cc[k];
                 }
-                swd_msg_h<HYB>(s, (uint32_t)zeroslot << 3) = 0.0; // re-arm
+                swd_msg_st<HYB>(s, (uint32_t)zeroslot << 3, 0.0); // re-arm
 #ifdef SWD_EXP_EXTRA_LDS // experiment: N more LDS reads per node and iteration (is the LDS pipeline what the iterations queue for?)
                 {
                     double dx_[SWD_EXP_EXTRA_LDS];
 #pragma unroll
-                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) dx_[e_] = *(volatile double *)&swd_msg_h<HYB>(s, (uint32_t)farslot << 3);
+                    for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) dx_[e_] = swd_msg_ld<HYB>(s, (uint32_t)farslot << 3);
 #pragma unroll
                     for (int e_ = 0; e_ < SWD_EXP_EXTRA_LDS; ++e_) asm volatile("" :: "v"(dx_[e_]));
                 }
@@ -1035,6 +1113,15 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     for (int e_ = 0; e_ < SWD_EXP_EXTRA_VALU; ++e_) asm volatile("v_add_u32 %0, %0, %0" : "+v"(vx_));
                 }
 #endif
+                if constexpr (TBL) {
+                    if (hd) {
+#pragma unroll
+                        for (int k = 0; k < KD; ++k) {
+                            const uint32_t e = tbe[i % 3][k];
+                            if (k < g.D && e != SWD_PAD_EDGE) atomicXor((uint32_t *)(parb + (swd_edge_lane(e) << 2)), 1u);
+                        }
+                    }
+                } else
                 if (hd) {
 #pragma unroll
                     for (int k2 = 0; k2 < (KD + 1) / 2; ++k2) {
@@ -1513,6 +1600,10 @@ __device__ __forceinline__ uint64_t wave_read64(uint64_t v, int srclane) { // sr
 #endif
 #ifndef SWD_WIDE_EVAL_DS
 #define SWD_WIDE_EVAL_DS 0
+#endif
+#ifndef SWD_BIG_TBL
+#define SWD_BIG_TBL 0 // experiment (round 5, bit-exact): large-graph kernels, full-graph phase: the variable-node pass reads the graph's tables (one row
+                      // ahead) instead of a register cache that does not fit: set-up 34 -> 24 us, 40.0 -> 41.6 us per iteration, 160 -> 163 k decodes/s: neutral, off
 #endif
 #ifndef SWD_BIG_REC
 #define SWD_BIG_REC 0 // experiment (round 5, bit-exact): large-graph kernels, full-graph phase: one record per check in LDS instead of a check-to-bit
@@ -3086,12 +3177,14 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     const long long ip0 = wall_clock64();
 #endif
     // large graphs: check-to-bit messages as one record per check in LDS (bp_run<..., REC>) when the layout's LDS block has room for them
-    constexpr bool kRec = BIG && SWD_BIG_REC && !kFullSorted && !kSplitLoad;
+    constexpr bool kTbl = BIG && SWD_BIG_TBL && !kFullSorted && !kSplitLoad; // the full graph's variable-node pass from the graph's tables (bp_run<..., TBL>)
+    constexpr bool kRec = BIG && SWD_BIG_REC && !kTbl && !kFullSorted && !kSplitLoad;
     bool rec_on = false;
     if constexpr (kRec) rec_on = L.off_pmsg >= 0 && m <= 1023 && L.pmsg_bytes >= (m + 1) * 32 + 4096;
     if constexpr (kSplitLoad) {
         vn_cache_pack<NT, VF, DM>(g, s, vraw, vc);
         if constexpr (kFullSorted) vn_row_caps<NT, VF, DM>(g, s, vraw.ev, kcf);
+    } else if constexpr (kTbl) { // (no cache)
     } else {
         if (kRec && rec_on) { if constexpr (kRec) vn_cache_load<NT, VF, DM, true, false, false, true>(g, s, n, vc); }
         else vn_cache_load<NT, VF, DM, true, false, kFullSorted>(g, s, n, vc, nullptr, kFullSorted ? &kcf : nullptr);
@@ -3112,8 +3205,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     const int rec_b = (kRec && rec_on) ? (((m + 1) * 32 + 15) & ~15) : 0;
     if constexpr (kRec) {
         if (rec_on) {
-            s.rec = (char *)s.hard - L.off_hard + L.off_pmsg;
-            if (tid < 8) ((uint32_t *)(s.rec + (size_t)m * 32))[tid] = 0u; // the record dead positions point at: + 0.0
+            s.rec = (SWD_AS3 char *)((char *)s.hard - L.off_hard + L.off_pmsg);
+            if (tid < 8) ((SWD_AS3 uint32_t *)(s.rec + m * 32))[tid] = 0u; // the record dead positions point at: + 0.0
         }
     }
     if constexpr (kHyb) {
@@ -3123,7 +3216,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
         s.msg_lo = (cap > 0) ? (uint32_t)lo << 3 : 0xFFFFFFFFu;
         s.msg_alt = (char *)s.hard - L.off_hard + (L.off_pmsg >= 0 ? L.off_pmsg + rec_b : 0);
     }
-    bp_init<VF, DM, kHyb>(s, vc);
+    if constexpr (kTbl) bp_init_tbl<NT, VF, DM, kHyb>(g, s);
+    else bp_init<VF, DM, kHyb>(s, vc);
 #ifdef SWD_INITPROF
     const long long ip3 = wall_clock64();
 #endif
@@ -3148,6 +3242,8 @@ __device__ __forceinline__ void decode_window(const SwdGraphDev &g, const SwdLds
     double hs[VF]; // HACC: summed posterior history of this thread's variable nodes
 #pragma unroll
     for (int i = 0; i < VF; ++i) hs[i] = 0.0;
+    if constexpr (kTbl) R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, false, kHyb, false, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs);
+    else
     if (kRec && rec_on) {
         if constexpr (kRec) R.conv = bp_run<NT, VF, DM, KG, true, SF, HACC, false, false, kHyb, true>(g, P, s, P.pre_iter, n, vc, cn, hist_b, it, P.alpha, false, hs);
     } else
