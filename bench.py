@@ -22,23 +22,22 @@ starts.  Shots are sharded over ranks with no data-path collective (weak: 4096 s
 total split contiguously); one RCCL all_gather of the per-shot decisions (observable flips + flagged bit,
 slidingwindowdecoder_amd.distributed.gather_decisions) closes the job inside the timed region.
 
-Rank 0 prints ONE JSON line.  `roofline`: the kernel keeps its messages in LDS, so HBM is not what bounds it;
-`frac` is the largest of the CAPACITY-BOUNDED utilisations, none of which can exceed 1:
-  lds   the CU's LDS pipeline: SQ_LDS_IDX_ACTIVE (array cycles incl. bank conflicts) + 2 cycles per store instruction (the
-        address / data transfer of a ds_write takes 2 cycles more than its array cycles: MI355X_MICROARCH.md, LDS table)
-        / (256 CUs x 2.4 GHz x t)
-  valu  VALU instructions priced by width: 4 cycles per wave64 instruction for the fp64-rate kinds (SQ_INSTS_VALU_ADD/MUL/FMA/
-        TRANS_F64 counted by the hardware + min / max / compare on doubles, which no counter separates: their static ratio to the
-        double adds in the kernel's ISA, profiles/<tag>_<workload>_isa_mix.json), 2 cycles for the rest / (1024 SIMDs x 2.4 GHz x t)
-  hbm   (2 x FETCH_SIZE + WRITE_SIZE) / 8 TB/s
-The counters come from the committed rocprofv3 profile of this same command (profiles/<tag>_<workload>_*), the time from HIP
-events measured live, and the line says `profile_stale` when the live kernel time has moved away from the profiled one.
-`lds_algorithmic_frac` = the LDS bytes the BP iterations must move (32 per live edge and iteration) over the ~79 TB/s a
-half-read / half-write 8-byte mix can move: the useful share of the busy time.  `lds_pipe` (wave time inside LDS
-instructions) is a diagnostic, not a capacity.  SURVEY 8(d)'s algorithmic-bytes figure is reported next to it as
-`achieved_algorithmic` (it exceeds the HBM peak: that is the traffic the LDS-resident design avoids, not a utilisation),
-and `lds_bytes_algorithmic` (32 E per executed BP iteration) against `lds_bytes_moved` (SQ_INSTS_LDS x 512) shows the
-padding of the LDS traffic.
+Rank 0 prints ONE JSON line.  `roofline.frac` = ALGORITHMIC bytes per launch / kernel time / peak of the memory that
+binds the kernel -- achieved / peak, nothing that grows with padding or bank conflicts:
+  LDS-resident kernels (headline, bb288, gdg, gdg64, bp4): the messages never leave LDS, so the binding memory is LDS;
+        achieved = 32 B per live edge and executed BP iteration (each of the two passes reads and writes the edge's 8-byte message
+        once; the counts come from the kernel's own statistics) / t; peak = 79 TB/s, what a half-read / half-write ds_*_b64 mix
+        can move with all 256 CUs streaming (MI355X_MICROARCH.md, LDS: ~150 TB/s reads, 38-51 TB/s writes); bound = "lds"
+  global144 (messages of the full graph in HBM): SURVEY 8(d)'s 40E+17n+2m bytes per executed iteration + sort + OSD + I/O / t
+        against the 8 TB/s HBM peak; bound = "hbm"
+`roofline.utilisation` keeps the BUSY fractions of rounds 3-5 (how occupied a unit is, padding and conflicts included -- not a
+score): lds = (SQ_LDS_IDX_ACTIVE + 2 x SQ_INSTS_LDS_STORE) / (256 CUs x 2.4 GHz x t); valu = (4 x fp64-rate + 2 x other VALU
+instructions) / (1024 SIMDs x 2.4 GHz x t); hbm = (2 x FETCH_SIZE + WRITE_SIZE) / (8 TB/s x t).  Counters: the committed
+rocprofv3 profile of this same command (profiles/<tag>_<workload>_*); time: HIP events measured live; `profile_stale` says when
+the live kernel time has moved away from the profiled one.  `traffic` = HBM bytes per launch from the PMC passes (gfx950 read-side
+correction applied); `lds_bytes_moved` (SQ_INSTS_LDS x 512) / `lds_bytes_algorithmic` = the padding of the LDS traffic;
+`achieved_algorithmic` = SURVEY 8(d)'s HBM-priced figure (exceeds the HBM peak for the LDS-resident kernels: the traffic the
+design avoids).
 `cpu_baseline`: the CPU oracle (bit-exact port of the reference's Cython path) timed on this box's host cores.
 """
 import argparse
@@ -160,6 +159,20 @@ def cpu_baseline_worker(args):
     return shots * len(plan.windows), time.perf_counter() - t0
 
 
+def reference_cpu_figure():
+    """The reference's OWN compiled Cython osd_window timed beside the port on one core of the build container
+    (tests/golden/time_reference.py -> profiles/r06_cpu_reference_vs_port.json; /root/reference does not exist on the GPU box, so
+    the figure travels as a committed measurement): the GPU / CPU ratio of this line is against the port -- scale it by
+    port_vs_reference to read it against the reference."""
+    j = load_profile("r06_cpu_reference_vs_port.json")
+    if not j:
+        return {"reference_cython_per_core": None}
+    return {"reference_cython_per_core": j["reference_cython_windows_per_s_per_core"],
+            "port_per_core_same_run": j["port_windows_per_s_per_core"], "port_vs_reference": j["port_vs_reference"],
+            "reference_figure_source": "profiles/r06_cpu_reference_vs_port.json (build container, " + str(j.get("cpu")) + ", 1 thread, "
+                                       "recorded 192-shot sliding run, one decode() per window; SURVEY.md section 6 probe: 500-510 / core)"}
+
+
 def cpu_baseline(order, shots_per_core=192):
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 32))
@@ -178,7 +191,7 @@ def cpu_baseline(order, shots_per_core=192):
             "sample": f"{shots_per_core} shots x 11 windows per core on {cores} processes (oracle/swd_oracle.c, "
                       f"bit-exact port of the reference's Cython osd_window; decode loop only, {busy:.1f} s; "
                       f"{wall:.1f} s incl. setup)",
-            "per_core": windows / busy / cores}
+            "per_core": windows / busy / cores, **reference_cpu_figure()}
 
 
 def parse_args(argv=None):
@@ -340,6 +353,7 @@ class Bp4Engine:
         self.dev = torch.device("cuda", local_rank)
         code, _, _ = bb_code(144)
         n, p = code.hx.shape[1], 0.02
+        self.edges = int(np.count_nonzero(code.hx)) + int(np.count_nonzero(code.hz))
         pr = np.full(n, p / 3)
         self.dec = bp4_osd(code.hx, code.hz, channel_probs_x=pr, channel_probs_y=pr, channel_probs_z=pr, max_iter=100,
                            ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10, device=local_rank)
@@ -443,13 +457,39 @@ def lds_algorithmic_bytes(plan, stats):
     return total
 
 
+def gdg_lds_algorithmic_bytes(plan, stats, new_n=None):
+    """Guessing decoders (statistics words of include/swd.h: [2] pre-processing iterations on the full graph, [3] iterations inside
+    decimation steps on the sub-graph of the new_n = min(n, 2m) least reliable columns, whose live edges shrink with every decimation and
+    are not reported): -> (lower, upper) bound of 32 B per live edge and iteration.  lower = the pre-processing iterations alone; upper
+    adds every decimation-step iteration at the edge count of the heaviest new_n columns of the window."""
+    lo = up = 0.0
+    for wi, w in enumerate(plan.windows):
+        st = stats[:, wi, :].astype(np.float64)
+        m, n = w.mat.shape
+        k = min(n, 2 * m)
+        deg = np.sort(np.asarray(w.mat.sum(axis=0)).ravel())[::-1]
+        e_sub = float(deg[:k].sum())
+        lo += (32.0 * w.mat.nnz * st[:, 2]).sum()
+        up += (32.0 * w.mat.nnz * st[:, 2] + 32.0 * e_sub * st[:, 3]).sum()
+    return lo, up
+
+
+def bp4_lds_algorithmic_bytes(dec_edges, stats):
+    """bp4_osd: both Tanner graphs' messages are read and written once by each of the two passes of every executed iteration
+    (statistics word [1] = bp_iteration): 32 B x (nnz(Hx) + nnz(Hz)) per iteration."""
+    return 32.0 * dec_edges * float(stats[:, 1].astype(np.float64).sum())
+
+
 LDS_MIX_PEAK_GBS = 79000.0  # what a half-read / half-write ds_*_b64 mix can move with every CU streaming (MI355X_MICROARCH.md, LDS: ~150 TB/s reads, 38-51 TB/s writes)
 
 
-def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducible, step_s=None, step_mode=None):
-    """Utilisation of the resources the kernel could be bound by.  Counters: the committed per-launch means of separate
-    rocprofv3 --pmc passes of this same command (profiles/); time: the kernel time measured live with HIP events.
-    `frac` is the largest of the capacity-bounded ones (each <= 1 by construction):
+def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducible, step_s=None, step_mode=None, lds_alg_note=None):
+    """`frac` = achieved / peak of the memory that binds the kernel, from ALGORITHMIC bytes and the kernel time measured live with
+    HIP events: LDS-resident kernels -> lds_alg_bytes / t / 79 TB/s (bound "lds"); a kernel whose messages live in HBM
+    (lds_alg_bytes None, alg_bytes given: global144) -> SURVEY 8(d)'s bytes / t / 8 TB/s (bound "hbm").
+    `utilisation` = the busy fractions of the units the kernel could saturate, from the committed per-launch means of separate
+    rocprofv3 --pmc passes of this same command (profiles/), each <= 1 by construction -- they rise with bank conflicts and
+    padding, so they describe how occupied a unit is, never how good the kernel is:
       lds   (SQ_LDS_IDX_ACTIVE + 2 x SQ_INSTS_LDS_STORE) / (256 CUs x 2.4 GHz x t): cycles the CU's LDS pipeline is occupied --
             array cycles incl. bank conflicts, plus the two cycles by which the address / data transfer of a store exceeds its
             array cycles (guide, LDS table: ds_write_b32 4 vs 2, ds_write_b64 6 vs 4)
@@ -537,33 +577,46 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
         out.update({"algorithmic_bytes_per_launch": alg_bytes, "achieved_algorithmic": alg_bytes / avg_kernel_s / 1e9,
                     "achieved_algorithmic_unit": "GB/s",
                     "achieved_algorithmic_over_hbm_peak": alg_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS})
-    out["fractions"] = fr
+    util = dict(fr)
+    if fr:
+        busiest = max(fr, key=lambda k: fr[k]["frac"])
+        util["busiest"] = busiest
+        util["max"] = fr[busiest]["frac"]
+        util["note"] = ("busy share of a unit's capacity at the 2.4 GHz peak clock (LDS pipeline cycles incl. bank conflicts and store "
+                        "transfers; VALU instructions priced by width; HBM bytes): occupancy, not achieved / peak")
+    out["utilisation"] = util
     out["diagnostics"] = diag
-    out["note"] = ("messages never leave LDS, so SURVEY 8(d)'s algorithmic bytes (40E+17n+2m per executed BP iteration + sort + OSD "
-                   "row adds + I/O) exceed what HBM could carry; frac = the highest capacity-bounded utilisation among the CU's LDS "
-                   "pipeline, the vector ALUs priced by instruction width, and HBM (counters from profiles/, time measured here with "
-                   "HIP events on single launches)")
     if fr and step_s:
         # The same counters priced at the STEP time of the timed region (this rank's shots per step): with the two-lane stream,
         # consecutive launches overlap -- a launch's grid fills the workgroup slots the previous launch's tail leaves empty -- so a step
         # takes less than one launch does alone (ms_per_step < avg_kernel_ms) and the device does one launch's work per step.
         sc = avg_kernel_s / step_s
         out["at_step_time"] = {"ms_per_step": step_s * 1e3, "avg_kernel_ms_single_launch": avg_kernel_s * 1e3, "step_mode": step_mode,
-                               "fractions": {k: v["frac"] * sc for k, v in fr.items()},
-                               "frac": max(v["frac"] for v in fr.values()) * sc,
-                               "note": "one launch's counters (profiles/, single launches) over the step time of the timed region; "
-                                       "`frac` above is priced at the single-launch kernel time that the committed kernel-trace describes"}
+                               "utilisation": {k: v["frac"] * sc for k, v in fr.items()},
+                               "note": "one launch's counters and algorithmic bytes over the step time of the timed region; `frac` above "
+                                       "is priced at the single-launch kernel time that the committed kernel-trace describes"}
         ss = find_stream_profile(workload)
         if ss:
             out["at_step_time"]["streamed_profile"] = ss
-    if fr:
-        bound = max(fr, key=lambda k: fr[k]["frac"])
-        out.update({"bound": bound, "frac": fr[bound]["frac"]})
-        if bound == "hbm":
-            out.update({"achieved": fr[bound]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"})
-        else:
-            out.update({"achieved": fr[bound]["busy_ms_at_peak_clock"], "peak": avg_kernel_s * 1e3,
-                        "unit": "ms busy at 2.4 GHz per launch (of the launch's duration)"})
+    # achieved / peak of the binding memory, from algorithmic bytes
+    if lds_alg_bytes is not None:
+        ach = lds_alg_bytes / avg_kernel_s / 1e9
+        out.update({"bound": "lds", "achieved": ach, "peak": LDS_MIX_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_MIX_PEAK_GBS,
+                    "achieved_is": "32 B per live edge and executed BP iteration (kernel statistics) / kernel time"
+                                   + (" -- " + lds_alg_note if lds_alg_note else ""),
+                    "peak_is": "LDS, half-read / half-write 8-byte mix with all 256 CUs streaming (MI355X_MICROARCH.md, LDS section)"})
+    elif alg_bytes is not None:
+        ach = alg_bytes / avg_kernel_s / 1e9
+        out.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "achieved_is": "SURVEY 8(d): 40E+17n+2m per executed BP iteration + sort + OSD row additions + I/O (kernel statistics) / kernel time",
+                    "peak_is": "HBM3E 8 TB/s (spec)"})
+    if out.get("frac") is not None and step_s:
+        out["at_step_time"] = dict(out.get("at_step_time") or {"ms_per_step": step_s * 1e3, "step_mode": step_mode},
+                                   frac=out["frac"] * avg_kernel_s / step_s)
+    out["note"] = ("frac = achieved / peak with ALGORITHMIC bytes: the messages of this kernel live in "
+                   + ("LDS, so the binding memory is LDS (SURVEY 8(d)'s HBM-priced figure is kept as achieved_algorithmic: it exceeds the "
+                      "HBM peak, which is the traffic the LDS-resident design avoids); " if lds_alg_bytes is not None else "HBM; ")
+                   + "utilisation = busy fractions from the committed counters (not a score); time measured here with HIP events on single launches")
     return out
 
 
@@ -596,19 +649,42 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5):
     ms, n, _ = eng.kernel_timing(1 + steps, 3)
     eng.check_status()
     avg_s = ms / max(n, 1) / 1e3
-    r = roofline(workload, "swd::bp4_kernel" if workload == "bp4" else "swd::pipeline_kernel", None, None, avg_s, None)
+    alg = lds_alg = None
+    note = None
+    extra = {}
+    if workload == "bp4":
+        lds_alg = bp4_lds_algorithmic_bytes(eng.edges, st)
+    elif workload == "global144":
+        alg = algorithmic_bytes(plan, st, None)
+    elif workload in ("gdg", "gdg64"):
+        lds_alg, up = gdg_lds_algorithmic_bytes(plan, st)
+        note = "LOWER bound: the pre-processing iterations only (the live edges of the decimation steps are not in the statistics)"
+        extra["roofline_frac_upper_bound"] = up / avg_s / 1e9 / LDS_MIX_PEAK_GBS
+    else:
+        lds_alg = lds_algorithmic_bytes(plan, st)
+    r = roofline(workload, "swd::bp4_kernel" if workload == "bp4" else "swd::pipeline_kernel", alg, lds_alg, avg_s, None, lds_alg_note=note)
     cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
-    return {"workload": workload, "metric": wl["metric"], "value": a.shots * eng.W * steps / el, "unit": wl.get("unit", "windows/s"),
-            "shots_per_step": a.shots, "steps": steps, "ms_per_step": el / steps * 1e3,
-            "step_mode": "two-lane stream" if streaming else "one launch at a time",
-            "ms_per_launch": avg_s * 1e3, "launches_timed": int(n), "exit_classes": [int(x) for x in cls[:7]],
-            "roofline_bound": r["bound"], "roofline_frac": r["frac"], "profile": (r.get("profile") or {}).get("counters"),
-            "profile_stale": r.get("profile_stale"), "setup_s": t_setup}
+    rec = {"workload": workload, "metric": wl["metric"], "value": a.shots * eng.W * steps / el, "unit": wl.get("unit", "windows/s"),
+           "shots_per_step": a.shots, "steps": steps, "ms_per_step": el / steps * 1e3,
+           "step_mode": "two-lane stream" if streaming else "one launch at a time",
+           "ms_per_launch": avg_s * 1e3, "launches_timed": int(n), "exit_classes": [int(x) for x in cls[:7]],
+           "roofline_bound": r["bound"], "roofline_frac": r["frac"], "roofline_achieved_GBps": r["achieved"], "roofline_peak_GBps": r["peak"],
+           "lds_algorithmic_frac": r.get("lds_algorithmic_frac"),
+           "utilisation_busiest": r["utilisation"].get("busiest"), "utilisation_max": r["utilisation"].get("max"),
+           "scratch_bytes_per_lane": r.get("scratch_bytes_per_lane"),
+           "profile": (r.get("profile") or {}).get("counters"),
+           "profile_stale": r.get("profile_stale"), "setup_s": t_setup}
+    if note:
+        rec["roofline_frac_note"] = note
+    rec.update(extra)
+    return rec
 
 
 def time_steps(engine, args, dist, world, total_shots):
     """W untimed steps, then exactly K timed steps + the gather of the decisions, bracketed by barriers and
-    device synchronisation; returns (elapsed seconds = max over ranks, gathered decisions)."""
+    device synchronisation; returns (elapsed seconds = max over ranks, gathered decisions, per-rank record).
+    The per-rank record splits every rank's timed region into its K steps (launch .. device idle) and the gather that follows, so
+    that a multi-GPU line shows imbalance by itself: ms_per_step min / max over ranks and the gather time."""
     from slidingwindowdecoder_amd.distributed import gather_decisions
     import torch
     for i in range(args.warmup):
@@ -621,16 +697,31 @@ def time_steps(engine, args, dist, world, total_shots):
     for i in range(args.steps):
         engine.step(args.warmup + i)
     engine.finish()  # (streaming: the current stream waits for both lanes before the decisions are gathered)
+    engine.sync()
+    t_steps = time.perf_counter() - t0
     gathered = gather_decisions(engine.shot, total_shots)  # per-shot decisions of the last step, over RCCL
     engine.sync()
+    t_gather = time.perf_counter() - t0 - t_steps
     if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    mine = [t_steps, t_gather, elapsed]
+    per_rank = [mine]
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=engine.shot.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, gathered
+        t = torch.tensor(mine, dtype=torch.float64, device=engine.shot.device)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [[float(x) for x in a.cpu()] for a in allt]
+        elapsed = max(r[2] for r in per_rank)
+    k = max(args.steps, 1)
+    rec = {"ms_per_step_per_rank": [r[0] / k * 1e3 for r in per_rank],
+           "ms_per_step_min_over_ranks": min(r[0] for r in per_rank) / k * 1e3,
+           "ms_per_step_max_over_ranks": max(r[0] for r in per_rank) / k * 1e3,
+           "gather_ms_per_rank": [r[1] * 1e3 for r in per_rank],
+           "gather_ms_max_over_ranks": max(r[1] for r in per_rank) * 1e3,
+           "note": "each rank's K timed steps (first launch .. device idle) and its all_gather of the decisions, host clock; "
+                   "`ms_per_step` of the line = (max over ranks of steps + gather + closing barrier) / K"}
+    return elapsed, gathered, rec
 
 
 def main():
@@ -689,7 +780,7 @@ def main():
     else:
         engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload, streaming=streaming)
     W = engine.W
-    elapsed, gathered = time_steps(engine, args, dist, world, total_shots)
+    elapsed, gathered, rank_times = time_steps(engine, args, dist, world, total_shots)
     assert gathered.shape[0] == total_shots, (gathered.shape, total_shots)
     backend = dist.get_backend() if dist.is_initialized() else None
     dist_ranks = dist.get_world_size() if dist.is_initialized() else 0
@@ -713,7 +804,7 @@ def main():
         ok = np.array_equal(gathered.numpy(), StubEngine.expected(0, total_shots))
         line["config"] = {"workload": "launcher test", "world_size": world, "shots_total": total_shots,
                           "shots_this_rank": hi - lo, "shots_per_rank": per_rank, "gather_ok": bool(ok),
-                          "collective_backend": backend, "collective_ranks": dist_ranks}
+                          "collective_backend": backend, "collective_ranks": dist_ranks, "rank_times": rank_times}
         if rank == 0:
             print(json.dumps(line))
         if dist.is_initialized():
@@ -741,18 +832,19 @@ def main():
         "world_size": world, "shots_total": total_shots, "shots_rank0": hi - lo, "shots_per_rank": per_rank, "windows_per_shot": W,
         "parallelism": f"shots sharded over {world} GPU(s), no data-path collective; one all_gather of 8 B per shot",
         # what closed the timed region: the RCCL (backend nccl) all_gather over this many ranks, or nothing (plain one-process run)
-        "collective_backend": backend, "collective_ranks": dist_ranks,
+        "collective_backend": backend, "collective_ranks": dist_ranks, "rank_times": rank_times,
         "kernel_launches_timed": int(launches),
         "step_mode": ("two-lane stream (swd_pipeline_stream_push_dev): consecutive steps overlap" if streaming else "one launch at a time"),
         "single_stream_windows_per_s": (hi - lo) * W * launches / single_wall if launches else None,
         "single_stream_note": "this rank's shots, one launch at a time with HIP events and a host synchronisation per launch (the loop that times the kernel)",
     }
-    alg_bytes = lds_alg = irr = None
+    alg_bytes = lds_alg = irr = lds_note = None
     if args.workload == "bp4":
         cls = np.bincount((st[:, 0] & 0xFF).ravel(), minlength=7)
         cfg["exit_classes_bp_osd_rank0"] = [int(cls[0]), int(cls[2])]
         cfg["converged_fraction_rank0"] = float(((st[:, 0] & 0x100) != 0).mean())
         kernel = "swd::bp4_kernel"
+        lds_alg = bp4_lds_algorithmic_bytes(engine.edges, st)
     else:
         last = (args.warmup + args.steps - 1) % engine.nb
         logical = (sr[:, 0].astype(np.int64) != engine.obs_true[last]) | (sr[:, 1] != 0)
@@ -767,6 +859,10 @@ def main():
                                                           int((st[..., 6].astype(np.int64) * st[..., 3]).sum())]
             alg_bytes = algorithmic_bytes(plan, st, DECODER_KW["pre_max_iter"])
             lds_alg = lds_algorithmic_bytes(plan, st) if args.workload != "global144" else None  # (its messages are not in LDS)
+        else:
+            lds_alg, lds_up = gdg_lds_algorithmic_bytes(plan, st)
+            lds_note = "LOWER bound: the pre-processing iterations only (the live edges of the decimation steps are not in the statistics)"
+            cfg["lds_bytes_algorithmic_upper_bound"] = lds_up
 
     if rank == 0 and world == 1 and headline and not args.no_side_order:
         # the same batches at the other OSD order (a second, untimed-by-the-driver loop): order 0 next to the notebooks' default 10
@@ -786,13 +882,19 @@ def main():
         # (each has its own `bench.py --workload <w>` line and committed counter profile; here: value, ms per launch, staleness)
         del engine
         torch.cuda.empty_cache()
-        cfg["other_workloads"] = [measure_other_workload(w, args, rank, local_rank) for w in ("bb288", "gdg", "gdg64", "global144", "bp4")]
+        cfg["other_workloads"] = []
+        for w in ("bb288", "gdg", "gdg64", "global144", "bp4"):
+            try:  # a failing side workload must not lose the headline record
+                cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank))
+            except Exception as e:  # noqa: BLE001
+                cfg["other_workloads"].append({"workload": w, "error": f"{type(e).__name__}: {e}"[:500]})
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line["config"] = cfg
         # (per-GPU step time: under weak scaling every rank runs the same number of shots per step)
         line["roofline"] = roofline(args.workload, kernel, alg_bytes, lds_alg, avg_kernel_s, irr, step_s=elapsed / args.steps,
-                                    step_mode=cfg["step_mode"])
+                                    step_mode=cfg["step_mode"], lds_alg_note=lds_note)
         line["cpu_baseline"] = cpu
         print(json.dumps(line))
     if dist.is_initialized():

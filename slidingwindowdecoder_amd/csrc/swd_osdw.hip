@@ -625,7 +625,7 @@ static HostStream *stream_new(Plan *d, int max_shots, int flags) {
     if (max_shots <= 0) { set_error("max_shots must be positive"); return nullptr; }
     if (hipSetDevice(d->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", d->device); return nullptr; }
     HostStream *hs = new HostStream();
-    hs->plan = d; hs->max_shots = max_shots; hs->flags = flags;
+    hs->plan = d; hs->max_shots = max_shots; hs->flags = flags; hs->device = d->device;
     for (auto &l : hs->lane)
         if (stream_lane_init(l)) { delete hs; return nullptr; }
     return hs;
@@ -660,13 +660,17 @@ static int stream_push(HostStream *hs, int B, const uint8_t *det) {
                                          (int32_t *)(dv + l.o_shot), l.st);
         if (rc) return rc;
         fault = d->cur->sched.as<uint32_t>() + B + 1;
+        // the fault word of THIS launch (batches in flight on the other lane have their own).  The copy reads the launch slot, so it
+        // belongs to the slot's use: still under the plan's lock -- nobody else can have taken the slot yet -- the slot's `done` event
+        // is recorded again behind it.  A later launch that re-uses the slot from any stream or stream object waits for that event
+        // before its hipMemsetAsync clears the word.
+        SWD_HIP(hipMemcpyAsync(dv + l.o_status, fault, 4, hipMemcpyDeviceToDevice, l.st));
+        SWD_HIP(hipEventRecord(d->cur->done, l.st));
     }
     const long long nb = (long long)B * (long long)row_bytes;
     hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, l.st, (const uint8_t *)(dv + l.o_total),
                        (int64_t)d->num_col, d->num_col, B, (uint8_t *)(dv + l.o_bits), (int)row_bytes);
     SWD_HIP(hipGetLastError());
-    // the fault word of THIS launch (batches in flight on the other lane have their own)
-    SWD_HIP(hipMemcpyAsync(dv + l.o_status, fault, 4, hipMemcpyDeviceToDevice, l.st));
     // what travels back: only the used prefix of every array (four copies into the page-locked block)
     char *ho = (char *)l.hout.p;
     SWD_HIP(hipMemcpyAsync(ho, dv + l.o_bits, (size_t)nb, hipMemcpyDeviceToHost, l.st));
@@ -781,8 +785,8 @@ extern "C" swd_stream *swd_pipeline_stream_create(swd_pipeline *h, int32_t max_s
 extern "C" void swd_pipeline_stream_destroy(swd_stream *s) {
     HostStream *hs = (HostStream *)s;
     if (!hs) return;
+    (void)hipSetDevice(hs->device); // also for a detached stream: its lanes live on the device of the pipeline it was made for
     if (Plan *d = hs->plan) { // (a stream whose pipeline went first was detached by ~Plan and only frees its own lanes)
-        (void)hipSetDevice(d->device);
         std::lock_guard<std::recursive_mutex> lk(d->mu);
         d->streams.erase(std::remove(d->streams.begin(), d->streams.end(), hs), d->streams.end());
     }

@@ -45,11 +45,13 @@ struct StreamLane {
 struct HostStream {
     Plan *plan = nullptr;    // nulled by ~Plan when the pipeline is destroyed first: every later call on the stream fails cleanly
     int max_shots = 0, flags = 0;
+    int device = 0;          // the plan's device, kept here so that a stream detached from its pipeline still frees its lanes on it
     StreamLane lane[2];
     long long npush = 0, npop = 0;
     bool owned_by_plan = false;
     std::mutex mu;
     ~HostStream() {
+        (void)hipSetDevice(device); // (streams, events and the lanes' buffers belong to this device whatever is current in a multi-GPU process)
         for (auto &l : lane) {
             if (l.st) { (void)hipStreamSynchronize(l.st); (void)hipStreamDestroy(l.st); }
             if (l.done) (void)hipEventDestroy(l.done);
@@ -123,9 +125,17 @@ struct Plan {
     std::vector<HostStream *> streams;   // live stream objects of the caller (swd_pipeline_stream_create), under mu
 
     ~Plan() {
+        (void)hipSetDevice(device);
         hstream.reset();
-        // stream objects that outlive their pipeline: drain their lanes (they read this plan's buffers) and detach them
-        for (HostStream *hs : streams) {
+        // stream objects that outlive their pipeline: drain their lanes (they read this plan's buffers) and detach them.  The list is
+        // taken out under the plan's lock, so a swd_pipeline_stream_destroy running on another thread either removed its object
+        // before (it is not in `live`) or finds the list empty afterwards.
+        std::vector<HostStream *> live;
+        {
+            std::lock_guard<std::recursive_mutex> lkp(mu);
+            live.swap(streams);
+        }
+        for (HostStream *hs : live) {
             std::lock_guard<std::mutex> lk(hs->mu);
             for (auto &l : hs->lane) { if (l.st) (void)hipStreamSynchronize(l.st); l.busy = false; }
             hs->npop = hs->npush;
@@ -168,6 +178,18 @@ struct Plan {
         return 0;
     }
 
+    // bytes of snapshot records per workgroup of a guessing-decoder launch, for the form that will run (gdg_parallel decided)
+    void size_snapshots() {
+        snap_stride = 0;
+        for (auto &w : wins) {
+            const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
+            // (the threaded-ensemble form keeps: the state after reset, one tree thread's saved masks, one record per side thread)
+            const int ens_slots = (kind == 1 && gp.multi_thread == 1) ? 2 + std::max(gp.max_side_depth - gp.max_tree_depth, 0) : 0;
+            snap_stride = std::max(snap_stride, rec * (gdg_parallel ? SWD_GDG_SLOTS : std::max(std::max(max_guess, 1), ens_slots)));
+        }
+        snap_stride = (snap_stride + 15) & ~(int64_t)15;
+    }
+
     int finalize(const swd_graph_desc *chk) {
         if (kind == 0 && p.osd_method == 1 && p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); return -1; }
         if (kind != 0) {
@@ -182,15 +204,8 @@ struct Plan {
             // (... and a tree of at most SWD_GDG_SLOTS snapshots: deeper trees take the serial walk)
             gdg_parallel = kind == 1 && gp.multi_thread != 1 && max_guess <= SWD_GDG_SLOTS && gp.max_side_branch_step <= SWD_GDG_MAXSTEP && gp.max_step < 200 && gp.max_side_depth < 200 &&
                            wins.size() <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_GDG_SERIAL");
-            snap_stride = 0;
-            for (auto &w : wins) {
-                const int64_t rec = ((w.new_n + 2 * w.g->m + 7) & ~7) + 8 * (int64_t)w.g->m;
-                // (the threaded-ensemble form keeps: the state after reset, one tree thread's saved masks, one record per side thread)
-                const int ens_slots = (kind == 1 && gp.multi_thread == 1) ? 2 + std::max(gp.max_side_depth - gp.max_tree_depth, 0) : 0;
-                snap_stride = std::max(snap_stride, rec * (gdg_parallel ? SWD_GDG_SLOTS : std::max(std::max(max_guess, 1), ens_slots)));
-                new_n_max = std::max(new_n_max, w.new_n);
-            }
-            snap_stride = (snap_stride + 15) & ~(int64_t)15;
+            for (auto &w : wins) new_n_max = std::max(new_n_max, w.new_n);
+            size_snapshots();
         }
         nmax = 0;
         int lmax = 0, mmax = 0;
@@ -220,6 +235,7 @@ struct Plan {
                 for (auto &w : wins) d2 = d2 && w.new_n <= 2 * variant->nt;
                 if (!d2) { set_error("guessing decoders on large graphs keep at most %d columns (new_n <= 2 x threads)", 2 * variant->nt); variant = nullptr; continue; }
                 gdg_parallel = false; // (no work items: the serial tree walk)
+                size_snapshots();     // ... whose snapshot area holds max_guess records per workgroup, not the parallel form's slots
             }
             nt = variant->nt; vf = variant->vf;
             mmax = 0; lmax = 0; big_stride = 0;

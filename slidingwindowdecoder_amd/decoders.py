@@ -480,17 +480,36 @@ class _HostPool:
 
     def __init__(self, per_shape=3, shapes=6):
         self._bufs, self._per_shape, self._shapes = {}, per_shape, shapes
+        # What sys.getrefcount reports for a pooled base nobody else holds depends on the interpreter (borrowed operand-stack
+        # references, free-threaded builds): measure it with the loop shape take() uses instead of assuming CPython 3.10's 3, and
+        # check the probe the other way -- one live view must read exactly one more.  A probe that disagrees switches recycling off.
+        self._idle = self._probe(hold_view=False)
+        if self._idle is None or self._probe(hold_view=True) != self._idle + 1:
+            self._idle = None
+
+    @staticmethod
+    def _probe(hold_view):
+        import sys
+        lst = [np.empty(4, np.uint8)]
+        view = lst[0][...] if hold_view else None
+        n = None
+        for base in lst:
+            n = sys.getrefcount(base)
+        del view
+        return n
 
     def take(self, shape, dtype):
         import sys
         key = (tuple(int(x) for x in shape), np.dtype(dtype).str)
+        if self._idle is None:  # reference counts are not readable the way the probe expects: plain fresh arrays
+            return np.empty(key[0], dtype)
         lst = self._bufs.get(key)
         if lst is None:
             if len(self._bufs) >= self._shapes:
                 self._bufs.pop(next(iter(self._bufs)))
             lst = self._bufs[key] = []
         for base in lst:
-            if sys.getrefcount(base) == 3:  # the list, this loop variable, getrefcount's own argument: no view of it is alive
+            if sys.getrefcount(base) == self._idle:  # the calibrated count of a base with no view alive
                 return base[...]
         base = np.empty(key[0], dtype)
         if len(lst) < self._per_shape:

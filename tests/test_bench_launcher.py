@@ -60,6 +60,11 @@ def test_self_launch_eight_ranks_weak_and_strong():
     assert j["n_gpus"] == 8 and j["scaling"] == "weak" and c["world_size"] == 8 and c["shots_total"] == 128 and c["gather_ok"]
     assert c["collective_backend"] == "gloo" and c["collective_ranks"] == 8
     assert c["shots_per_rank"] == [16] * 8
+    # the line diagnoses imbalance by itself: every rank's step time and gather time
+    rt = c["rank_times"]
+    assert len(rt["ms_per_step_per_rank"]) == 8 and len(rt["gather_ms_per_rank"]) == 8
+    assert 0 < rt["ms_per_step_min_over_ranks"] <= rt["ms_per_step_max_over_ranks"] <= j["ms_per_step"] + 1e-9
+    assert rt["gather_ms_max_over_ranks"] == max(rt["gather_ms_per_rank"]) >= 0
     r, lines = run_bench("--gpus", "8", "--steps", "2", "--warmup", "0", "--scaling", "strong", "--total-shots", "203", timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = lines[0]
@@ -105,25 +110,45 @@ def test_refuses_more_gpus_than_visible():
 
 
 def test_roofline_is_a_bounded_utilisation():
-    """`roofline.frac` is the largest of the CAPACITY-BOUNDED utilisations (LDS array busy, VALU busy at four cycles per
-    instruction, HBM) from the committed counters, never the algorithmic-bytes figure and never a sum of wave time; with
-    the committed counters and the kernel time of the same profile it stays below 1, and a kernel time that has moved away
-    from the profiled one is flagged."""
+    """`roofline.frac` is achieved / peak from ALGORITHMIC bytes -- lds_bytes_algorithmic / t / 79 TB/s for the LDS-resident kernels,
+    SURVEY 8(d)'s bytes / t / 8 TB/s for the one whose messages live in HBM -- never a busy fraction (those grow with bank
+    conflicts and padding and stay under `utilisation`, each below 1) and never the HBM-priced figure of an LDS-resident kernel;
+    a kernel time that has moved away from the profiled one is flagged."""
     sys.path.insert(0, ROOT)
     import bench
     sq, sm, sq_src, sm_src = bench.find_profile("headline")
     assert sq and sm, "no committed counter profile of the headline kernel"
     t = sm["avg_ms"] * 1e-3
     r = bench.roofline("headline", "swd::pipeline_kernel", 1.49e11, 1.1e11, t, 1.2e8)
-    assert r["bound"] in ("valu", "lds", "hbm") and 0.0 < r["frac"] < 1.0
-    assert set(r["fractions"]) <= {"lds", "valu", "hbm"} and all(0.0 < v["frac"] < 1.0 for v in r["fractions"].values())
-    assert abs(r["frac"] - max(v["frac"] for v in r["fractions"].values())) < 1e-12
-    assert "lds_pipe" in r["diagnostics"] and "lds_pipe" not in r["fractions"]  # wave time inside LDS instructions is no capacity
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == bench.LDS_MIX_PEAK_GBS == 79000.0
+    assert r["frac"] == r["lds_bytes_algorithmic"] / t / 1e9 / bench.LDS_MIX_PEAK_GBS == r["lds_algorithmic_frac"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-15 and 0.0 < r["frac"] < 1.0
+    u = r["utilisation"]
+    assert {"lds", "valu", "hbm"} <= set(u) and all(0.0 < u[k]["frac"] < 1.0 for k in ("lds", "valu", "hbm"))
+    assert u["max"] == max(u[k]["frac"] for k in ("lds", "valu", "hbm")) and u["busiest"] in ("lds", "valu", "hbm")
+    assert r["frac"] < u["lds"]["frac"]  # the algorithm's own bytes are a part of what keeps the LDS pipeline busy
+    assert "fractions" not in r
+    assert "lds_pipe" in r["diagnostics"] and "lds_pipe" not in u  # wave time inside LDS instructions is no capacity
     assert r["achieved_algorithmic_over_hbm_peak"] > 1.0  # reported, but not as `frac`
     assert r["traffic"] >= r["irreducible_hbm_bytes"] > 0
     assert r["lds_bytes_moved"] > r["lds_bytes_algorithmic"] > 0 and r["lds_padding_factor"] > 1.0
     assert r["profile_stale"] is False and r["profile"]["counters"] == sq_src
     assert bench.roofline("headline", "k", 1.49e11, 1.1e11, t * 1.2, 1.2e8)["profile_stale"] is True
+    # the streamed step: the same bytes over the step time
+    r2 = bench.roofline("headline", "k", 1.49e11, 1.1e11, t, 1.2e8, step_s=t * 0.9, step_mode="two-lane stream")
+    assert abs(r2["at_step_time"]["frac"] - r2["frac"] / 0.9) < 1e-12
+    # HBM-resident messages (global144): SURVEY 8(d) bytes against the HBM peak
+    g = bench.roofline("global144", "k", 2.0e10, None, 14.6e-3, None)
+    assert g["bound"] == "hbm" and g["peak"] == 8000.0 and abs(g["frac"] - 2.0e10 / 14.6e-3 / 1e9 / 8000.0) < 1e-15
+
+
+def test_cpu_baseline_carries_the_reference_figure():
+    """the reference's own Cython osd_window, timed beside the port by tests/golden/time_reference.py (committed figure)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.reference_cpu_figure()
+    assert 300 < f["reference_cython_per_core"] < 1000 and 0.3 < f["port_vs_reference"] < 3.0
+    assert "profiles/r06_cpu_reference_vs_port.json" in f["reference_figure_source"]
 
 
 def test_one_rank_job_still_runs_the_collective():

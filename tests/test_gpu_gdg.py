@@ -109,7 +109,9 @@ def test_bb288_gdg_windows_and_pipeline(tag):
     """The reference's [[288,12,18]] guessing-decoder run (`Sliding Window GDG.ipynb` cell 8, guessing.py:160-197 with N = 288:
     (W,F) = (4,1) windows of 576 x 4752 / 4896, max_iter 16, max_step 60, D4 / S20, branch steps 40; and the default D3 / S10 on
     the same windows), recorded from the reference's single-thread gdg(): every window decode (vector, converge flag) and the whole
-    window loop, in the parallel form (side branches as work items) and in the serial tree walk."""
+    window loop.  These windows take the large-graph kernels (1024 threads), which always run the SERIAL tree walk (Plan::finalize
+    switches the work-item form off for them): both loop iterations below exercise that walk, once with and once without the
+    environment switch that forces it -- the parallel form is covered on the [[144]] windows (test_bb144_gdg_windows)."""
     import os
     import slidingwindowdecoder_amd as S
     from tests.test_gpu_pipeline import load_plan

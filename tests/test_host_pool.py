@@ -33,3 +33,16 @@ def test_pool_forgets_old_shapes():
         assert x.shape == (k + 1, 3)
         del x
     assert len(p._bufs) <= 2
+
+
+def test_pool_calibrates_its_idle_reference_count():
+    """the pool measures what an idle base reads on this interpreter (3 on CPython 3.10) and falls back to fresh arrays when the
+    probe disagrees with itself -- it never relies on a literal count"""
+    p = _HostPool()
+    assert p._idle is not None and p._probe(hold_view=True) == p._idle + 1
+    p._idle = None                                       # an interpreter whose counts cannot be read: no recycling, no aliasing
+    a = p.take((3, 3), np.uint8)
+    addr = a.ctypes.data
+    keep = a
+    b = p.take((3, 3), np.uint8)
+    assert not np.shares_memory(keep, b) and b.ctypes.data != addr and not p._bufs
