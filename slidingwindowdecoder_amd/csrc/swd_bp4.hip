@@ -44,29 +44,29 @@ struct Bp4 {
     }
 };
 
-template <int WMAX, int NTO, int DM>
+template <int WMAX, int NTO, int DM, bool FAST>
 static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
     static std::mutex fn_mu; // the attributes and occupancy answers belong to the functions, not to a handle
     std::lock_guard<std::mutex> fn_lock(fn_mu);
     static int lds_limit[64] = {0};
     if (d->L.total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<WMAX, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
+        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<WMAX, DM, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
         lds_limit[d->device & 63] = d->L.total;
     }
     // persistent grid: as many workgroups as the device holds at once, each walks its share of the units
     static int slots[64] = {0}, slots_lds[64] = {0}, slots_nt[64] = {0};
     if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total || slots_nt[d->device & 63] != d->nt) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM>, d->nt, (size_t)d->L.total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM, FAST>, d->nt, (size_t)d->L.total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
-        while (per_cu > 1 && (long long)per_cu * ((d->L.total + 1279) / 1280 * 1280) > 160 * 1024) --per_cu; // LDS is granted in granules of 1280 B (swd_plan.h)
+        while (per_cu > 1 && (long long)per_cu * ((d->L.total + 2048 + 1279) / 1280 * 1280) > 160 * 1024) --per_cu; // LDS is granted in granules of 1280 B (swd_plan.h); + the kernel's 2 KB exp table
         slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
         slots_lds[d->device & 63] = d->L.total; slots_nt[d->device & 63] = d->nt;
     }
     const int units = a.camel ? 4 * a.B : a.B;
     const bool with_osd = !a.camel && a.osd_order >= 0;
-    if (with_osd) SWD_HIP(hipMemsetAsync(a.osd_count, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL((bp4_kernel<WMAX, DM>), dim3(std::min(units, slots[d->device & 63])), dim3(d->nt), d->L.total, st, a);
+    if (with_osd || a.ticket) SWD_HIP(hipMemsetAsync(a.osd_count, 0, 4 * sizeof(uint32_t), st)); // (queue counter, ticket counter)
+    hipLaunchKernelGGL((bp4_kernel<WMAX, DM, FAST>), dim3(std::min(units, slots[d->device & 63])), dim3(d->nt), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
     if (with_osd) { // the queue of unconverged decodes (often empty: its workgroups then read the count and leave)
         static int lds_limit2[64] = {0}, slots2[64] = {0}, slots2_lds[64] = {0};
@@ -88,16 +88,23 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
     return 0;
 }
 
-template <int WMAX, int NTO>
+template <int WMAX, int NTO, bool FAST>
 static int bp4_dispatch_dm(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
-    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4>(d, a, st) : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8>(d, a, st) : bp4_launch<WMAX, NTO, SWD_DMAX>(d, a, st));
+    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4, FAST>(d, a, st)
+                      : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8, FAST>(d, a, st) : bp4_launch<WMAX, NTO, SWD_DMAX, FAST>(d, a, st));
+}
+template <int WMAX, int NTO>
+static int bp4_dispatch_fast(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+    // the specialised instantiation: a thread per qubit and per check, no camel run (swd_bp4_kernel.h)
+    const bool fast = !a.camel && d->n <= d->nt && d->gx.m + d->gz.m <= d->nt && !getenv("SWD_BP4_GENERIC");
+    return fast ? bp4_dispatch_dm<WMAX, NTO, true>(d, a, st) : bp4_dispatch_dm<WMAX, NTO, false>(d, a, st);
 }
 static int bp4_dispatch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
     // BP kernel: one thread per qubit while ceil(n / 64) waves fit a workgroup (the decodes of the notebooks' codes take a few
     // iterations -- what a launch costs is the number of waves it occupies); OSD kernel: the workgroups its layouts were made for
-    if (d->nt <= 256) return bp4_dispatch_dm<4, 256>(d, a, st); // (n <= 3072: the OSD layouts are those of 256 threads)
-    if (d->nt <= 512) return bp4_dispatch_dm<8, 256>(d, a, st); // (still six waves per SIMD: three workgroups of up to eight waves per CU)
-    return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256>(d, a, st) : bp4_dispatch_dm<16, 1024>(d, a, st);
+    if (d->nt <= 256) return bp4_dispatch_fast<4, 256>(d, a, st); // (n <= 3072: the OSD layouts are those of 256 threads)
+    if (d->nt <= 512) return bp4_dispatch_fast<8, 256>(d, a, st); // (still six waves per SIMD: three workgroups of up to eight waves per CU)
+    return d->nt_osd == 256 ? bp4_dispatch_fast<16, 256>(d, a, st) : bp4_dispatch_fast<16, 1024>(d, a, st);
 }
 } // namespace swd
 
@@ -204,6 +211,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     std::lock_guard<std::mutex> lk(d->mu);
     Bp4::LaunchSlot *sl = nullptr;
     if (d->take_slot(st, &sl)) return -1;
+    const bool lpr_wanted = lpr != nullptr;
     if (!lpr) {
         // every slot's buffer at the first launch of this size, not one per launch: the allocations (226 MB each for 65 536 decodes of
         // a 144-qubit code) would otherwise fall into the first kSlots launches one by one -- 5-7 ms of host time each, behind a warm-up
@@ -215,8 +223,18 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     a.llr_x = d->d_llr_x; a.llr_y = d->d_llr_y; a.llr_z = d->d_llr_z;
     a.max_iter = d->p.max_iter; a.osd_method = d->p.osd_method; a.osd_order = d->p.osd_order; a.alpha = d->p.ms_scaling_factor;
     a.B = B; a.sx = sx; a.sz = sz; a.out = out; a.osd0 = osd0; a.bp_dec = bp_dec; a.stats = stats; a.lpr = lpr;
-    for (auto &s2 : d->slot) if (s2.osd_q.reserve((size_t)B * 4 + 16)) return -1;
+    a.lpr_wanted = lpr_wanted ? 1 : 0;
+    // [ OSD queue counter | ticket counter | - | - | OSD queue [B] | weights [B] | start order [B] ]
+    for (auto &s2 : d->slot) if (s2.osd_q.reserve((size_t)B * 12 + 16)) return -1;
     a.osd_count = sl->osd_q.as<uint32_t>(); a.osd_list = sl->osd_q.as<int32_t>() + 4;
+    static const bool static_units = getenv("SWD_BP4_STATIC") != nullptr; // (diagnostics: the static shares of rounds 4-5)
+    if (!static_units) {
+        uint32_t *wt = sl->osd_q.as<uint32_t>() + 4 + B, *ord = wt + B;
+        hipLaunchKernelGGL(bp4_weight_kernel, dim3((B + 3) / 4), dim3(256), 0, st, sx, sz, d->gx.m, d->gz.m, B, wt);
+        hipLaunchKernelGGL((shot_order_kernel<1024>), dim3(1), dim3(1024), 0, st, (const uint32_t *)wt, B, ord);
+        SWD_HIP(hipGetLastError());
+        a.ticket = a.osd_count + 1; a.order = ord;
+    }
     if (bp4_dispatch(d, a, st)) return -1;
     SWD_HIP(hipEventRecord(sl->done, st));
     return 0;

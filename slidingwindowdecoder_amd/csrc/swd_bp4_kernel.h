@@ -36,6 +36,13 @@ struct SwdBp4Args {
     int32_t *osd_list;       // [B]
     uint32_t *osd_count;     // zeroed before the launch
     int32_t camel;
+    // round 6: units are drawn by ticket (the first gridDim.x statically) in the order `order` lists them -- heaviest syndrome first.
+    // A decode that does not converge runs max_iter iterations against 1-3 of the others (80x a normal decode at the notebooks'
+    // noise rates): with a static share of the units per workgroup a launch ended on the workgroups that had met one, the device
+    // 60 % empty on average.  Both NULL: static shares (camel runs).
+    uint32_t *ticket;        // zeroed before the launch
+    const uint32_t *order;   // [B] decode numbers by decreasing syndrome weight (bp4_weight_kernel + shot_order_kernel)
+    int32_t lpr_wanted;      // the caller reads lpr: every decode stores its posteriors (else only those the OSD kernel finishes)
     uint8_t *camel_dec;      // [4B][2][n] decisions of every run
     double *camel_pm;        // [4B] cal_pm of the converged runs
     int32_t *camel_st;       // [4B][2] converged, iterations
@@ -51,15 +58,15 @@ namespace swd {
 // (bpgd.cpp:399-416.  Written without branches: the reference's two cases of each routine differ in the ARGUMENT of one and the same
 // evaluation, so a lane selects the argument, evaluates once and selects the result -- the same operations on the same values per
 // lane, and a wave whose lanes disagree about the case no longer walks both inlined copies of exp / log1p, four per logaddexp.)
-SWD_BP4_FN double bp4_log1pexp(double x) {
+SWD_BP4_FN double bp4_log1pexp(double x, const uint64_t *tab = nullptr) {
     const bool big = x > 36.04365338911715; // -log(DBL_EPSILON)
-    const double r = swd_log1p(swd_exp(big ? -x : x));
+    const double r = swd_log1p(swd_exp_from(big ? -x : x, tab));
     return big ? x + r : r;
 }
-SWD_BP4_FN double bp4_logaddexp(double x, double y) {
+SWD_BP4_FN double bp4_logaddexp(double x, double y, const uint64_t *tab = nullptr) {
     const double tmp = x - y;
     const bool gt = tmp > 0, le = tmp <= 0;
-    const double r = (gt ? x : y) + bp4_log1pexp(gt ? -tmp : tmp);
+    const double r = (gt ? x : y) + bp4_log1pexp(gt ? -tmp : tmp, tab);
     if (x == y) return x + 0.693147180559945309417232121458176568;
     return (gt || le) ? r : tmp; // (NaN: neither case)
 }
@@ -147,20 +154,36 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 #ifndef SWD_BP4_ROLLED
 #define SWD_BP4_ROLLED 1 // the variable-node update's per-edge loops as loops (one helper body per basis; SHYPS r = 3 +10 %, the BB codes unchanged, half the compile time)
 #endif
+#ifndef SWD_BP4_PRIO_IT
+#define SWD_BP4_PRIO_IT 3 // iteration from which a decode's waves run at raised priority (-1: never)
+#endif
 #ifndef SWD_BP4_WAVES
-#define SWD_BP4_WAVES 6 // waves per SIMD the register allocation leaves room for (kernels of up to 256 threads): measured 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]] when the switch was introduced; final kernel 4 / 5 / 6 / 8 -> 14.9 / 19.0 / 18.5 / 14.9 M, [[360]] 7.7 / 7.1 / 8.5 / 9.2 M, SHYPS r = 3 10.4 / 10.8 / 12.5 / 11.1 M
+// waves per SIMD the register allocation leaves room for (kernels of up to 256 / up to 512 threads).  Round 4 (static shares of the
+// units): 1 / 2 / 3 / 4 / 6 / 8 -> 6.9 / 10.0 / 13.4 / 15.3 / 15.4 / 15.0 M decodes/s on [[144,12,12]].  Round 6 (ticket-scheduled units,
+// gpurun_out/r06e -> profiles/r06_bp4_codes_rate.log): 4 / 5 / 6 -> [[144]] 35.2 / 36.4 / 35.7 M, [[72]] 44.8 / 43.5 / 41.4, SHYPS r = 3
+// 26.4 / 24.8 / 23.8 (all one- to three-wave workgroups: five); [[288]] 16.9 / 19.8 / 20.2, [[360]] 15.3 / 14.6 / 15.9 (up to eight waves: six)
+#define SWD_BP4_WAVES(wmax) ((wmax) <= 4 ? 5 : 6)
 #endif
 // WMAX: the most waves a workgroup of this instantiation is launched with (4 / 8: up to 256 / 512 threads, SWD_BP4_WAVES waves per SIMD;
 // 16: up to 1024 threads, 128 registers).  The workgroup size itself is a launch parameter: ceil(n / 64) waves while that is at most 16, so that every qubit has
 // a thread of its own and the node's edges / LLRs / bp_init messages stay in registers.
-template <int WMAX, int DM>
-__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp4_kernel(const SwdBp4Args a) {
+// FAST (round 6): the launch of the notebooks' codes -- every qubit has a thread (n <= NT), every check of both graphs has a thread
+// (mx + mz <= NT), no camel run -- as its own instantiation: the generic paths (strided node loops, per-graph check passes, the
+// decided qubit of camel_decode, loads of the graph tables inside the iterations) are compiled out.
+template <int WMAX, int DM, bool FAST>
+__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 1)) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // glibc's exp table (swd_libm.h) in LDS: tail and scale of an entry are one aligned 16-byte read
+    __shared__ __attribute__((aligned(16))) uint64_t s_exptab[256];
     const int NT = (int)blockDim.x;
+    for (int i = threadIdx.x; i < 256; i += NT) s_exptab[i] = swd_exp_tab_dev[i];
+    __syncthreads(); // (the channel-only messages below already evaluate exp)
+    const uint64_t *const xt = s_exptab;
+    const bool camel_run = !FAST && a.camel;
     const SwdGraphDev &gx = a.gx, &gz = a.gz;
     const int tid = threadIdx.x, n = gx.n, mx = gx.m, mz = gz.m;
-    const int fixed = a.camel ? n - 1 : -1; // the decided qubit of a camel run
-    const int nunits = a.camel ? 4 * a.B : a.B;
+    const int fixed = camel_run ? n - 1 : -1; // the decided qubit of a camel run
+    const int nunits = camel_run ? 4 * a.B : a.B;
     double *msgx = (double *)smem, *msgz = (double *)(smem + a.L.off_msgz);
     uint16_t *jpx = (uint16_t *)(smem + a.L.off_jptrx), *jpz = (uint16_t *)(smem + a.L.off_jptrz);
     int8_t *cnx = (int8_t *)(smem + a.L.off_cnx), *cnz = (int8_t *)(smem + a.L.off_cnz);
@@ -176,7 +199,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
     // and no posterior store inside the iterations (the posteriors of the last update are stored once, after the loop)
     for (int j = tid; j <= gx.K; j += NT) jpx[j] = gx.jptr[j];
     for (int j = tid; j <= gz.K; j += NT) jpz[j] = gz.jptr[j];
-    const bool one = n <= NT;
+    const bool one = FAST || n <= NT;
     const bool mine = one && tid < n;
     int c_dx = 0, c_dz = 0;
     uint32_t c_ex[DM], c_ez[DM];
@@ -195,8 +218,8 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
     // (the messages of bp_init depend on the channel only: three of a decode's ~14 exp / log1p evaluations, hoisted out of the unit loop)
     double c_mx = 0.0, c_mz = 0.0;
     if (mine) {
-        c_mx = bp4_log1pexp(-1. * c_lx) - bp4_logaddexp(-1. * c_ly, -1. * c_lz);
-        c_mz = bp4_log1pexp(-1. * c_lz) - bp4_logaddexp(-1. * c_ly, -1. * c_lz); // sic (bp4_osd.pyx:438)
+        c_mx = bp4_log1pexp(-1. * c_lx, xt) - bp4_logaddexp(-1. * c_ly, -1. * c_lz, xt);
+        c_mz = bp4_log1pexp(-1. * c_lz, xt) - bp4_logaddexp(-1. * c_ly, -1. * c_lz, xt); // sic (bp4_osd.pyx:438)
     }
     // Round 5: when every check of both graphs has a thread (mx + mz <= NT: the notebooks' codes), a thread keeps ONE check for the
     // whole launch -- the checks of Hx, then those of Hz, dealt to the waves in equal shares -- with its degree, its syndrome index
@@ -204,7 +227,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
     // of Hx and the start of Hz walked both: 2x the others, which waited for it at the barrier), and neither the pass nor the
     // reset waits for a load of the graph's tables any more.
     const int mtot = mx + mz;
-    const bool own = SWD_BP4_OWN_CHECK && mtot <= NT;
+    const bool own = FAST || (SWD_BP4_OWN_CHECK && mtot <= NT);
     int o_l = -1, o_deg = 0, o_perm = 0;
     bool o_z = false;
     if (own) {
@@ -227,8 +250,16 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
 #else
 #define BP4T(i)
 #endif
-    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-    const int b = a.camel ? unit >> 2 : unit;
+    uint32_t tk_next = 0; // (thread 0) the ticket drawn for the workgroup's next unit
+    auto next_unit = [&](uint32_t tk) -> uint32_t {
+        if (!a.ticket) return tk + gridDim.x;
+        if (tid == 0) s.scal[1] = (int)tk_next;
+        __syncthreads();
+        return (uint32_t)s.scal[1];
+    };
+    for (uint32_t tk = blockIdx.x; tk < (uint32_t)nunits; tk = next_unit(tk)) {
+    const int unit = (a.ticket && a.order) ? (int)a.order[tk] : (int)tk;
+    const int b = camel_run ? unit >> 2 : unit;
     s.fpar = 0;
     const uint8_t *sx_b = a.sx + (int64_t)b * mx, *sz_b = a.sz + (int64_t)b * mz;
     double *lpr_b = a.lpr + (int64_t)unit * 3 * n;
@@ -248,8 +279,8 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         double m_x = c_mx, m_z = c_mz;
         if (!one) {
             const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
-            m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
-            m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz); // sic (bp4_osd.pyx:438)
+            m_x = bp4_log1pexp(-1. * llrx, xt) - bp4_logaddexp(-1. * llry, -1. * llrz, xt);
+            m_z = bp4_log1pexp(-1. * llrz, xt) - bp4_logaddexp(-1. * llry, -1. * llrz, xt); // sic (bp4_osd.pyx:438)
         }
         const int dx = one ? c_dx : (int)gx.col_deg[v], dz = one ? c_dz : (int)gz.col_deg[v];
         if (one) {
@@ -261,7 +292,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         }
     }
     __syncthreads();
-    if (a.camel) { // vn_set_value(n - 1, value) after bp_init (bp4_osd.pyx:234-236, 388-423): the qubit keeps its prior messages
+    if (camel_run) { // vn_set_value(n - 1, value) after bp_init (bp4_osd.pyx:234-236, 388-423): the qubit keeps its prior messages
         const int value = unit & 3, x = value & 1, z = value >> 1;
         if (tid == 0) { decx[fixed] = (uint8_t)x; decz[fixed] = (uint8_t)z; }
         if (z) for (int k = tid; k < gx.col_deg[fixed]; k += NT) cnx[swd_edge_lane(gx.vn_edge[k * n + fixed])] ^= 1;
@@ -274,6 +305,9 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
     int conv = 0, iters = 0;
     const int lane0z = (mx + mz <= NT) ? mx : 0; // Hz checks on the lanes after the Hx ones when both fit
     for (int it = 0; it < a.max_iter; ++it) {
+        // a decode that is still running after a few iterations is one of the few that will run for long: its waves issue ahead of
+        // the others on their SIMDs from here on (what ends a launch is the last of these decodes, not the device's throughput)
+        if (SWD_BP4_PRIO_IT >= 0 && it == SWD_BP4_PRIO_IT) __builtin_amdgcn_s_setprio(2);
         bool unsat = false;
         if (own) {
             if (o_l >= 0) unsat = bp4_cn_one(o_msg, o_jp, o_cn, o_par, o_l, o_deg, it, a.alpha);
@@ -289,8 +323,8 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
             if (v == fixed) { // decided (bp4_osd.pyx:456-458): its bit-to-check messages stay the priors of bp_init; the
                               // CN pass has just overwritten the shared slots with check-to-bit values, so put them back
                 const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
-                const double m_x = bp4_log1pexp(-1. * llrx) - bp4_logaddexp(-1. * llry, -1. * llrz);
-                const double m_z = bp4_log1pexp(-1. * llrz) - bp4_logaddexp(-1. * llry, -1. * llrz);
+                const double m_x = bp4_log1pexp(-1. * llrx, xt) - bp4_logaddexp(-1. * llry, -1. * llrz, xt);
+                const double m_z = bp4_log1pexp(-1. * llrz, xt) - bp4_logaddexp(-1. * llry, -1. * llrz, xt);
                 for (int k = 0; k < gx.col_deg[v]; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
                 for (int k = 0; k < gz.col_deg[v]; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
                 continue;
@@ -324,7 +358,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
             const int bx = idx & 1, bz = idx >> 1;
             decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz;
             BP4T(3) // node: message loads, sums, posteriors, decision
-            const double num_hx = bp4_log1pexp(-1. * llrx_hx);
+            const double num_hx = bp4_log1pexp(-1. * llrx_hx, xt);
             BP4T(4) // log1pexp
 #if SWD_BP4_ROLLED // one body of the helper per basis instead of DM: the edge word is picked by a select chain, the message re-read from LDS
             auto pick = [&](const uint32_t (&ev)[DM], int k) { uint32_t e = ev[0];
@@ -336,18 +370,18 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
                 const uint32_t e = pick(ex, k);
                 const double c = msgx[swd_edge_slot(e)];
                 const double aa = llrz_hz - c, bb = llry_all - c;
-                msgx[swd_edge_slot(e)] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb);
+                msgx[swd_edge_slot(e)] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb, xt);
                 if (bz) atomicXor(&parx[swd_edge_lane(e)], 1u); // Hx * z-string
             }
             BP4T(5) // Hx edges: logaddexp + store + parity flip each
-            const double num_hz = bp4_log1pexp(-1. * llrz_hz);
+            const double num_hz = bp4_log1pexp(-1. * llrz_hz, xt);
             BP4T(4)
 #pragma unroll 1
             for (int k = 0; k < dz; ++k) {
                 const uint32_t e = pick(ez, k);
                 const double c = msgz[swd_edge_slot(e)];
                 const double aa = llrx_hx - c, bb = llry_all - c;
-                msgz[swd_edge_slot(e)] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb);
+                msgz[swd_edge_slot(e)] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb, xt);
                 if (bx) atomicXor(&parz[swd_edge_lane(e)], 1u); // Hz * x-string
             }
             BP4T(6) // Hz edges
@@ -356,15 +390,15 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
             for (int k = 0; k < DM; ++k)
                 if (k < dx) {
                     const double aa = llrz_hz - cx[k], bb = llry_all - cx[k];
-                    msgx[swd_edge_slot(ex[k])] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb);
+                    msgx[swd_edge_slot(ex[k])] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb, xt);
                     if (bz) atomicXor(&parx[swd_edge_lane(ex[k])], 1u); // Hx * z-string
                 }
-            const double num_hz = bp4_log1pexp(-1. * llrz_hz);
+            const double num_hz = bp4_log1pexp(-1. * llrz_hz, xt);
 #pragma unroll
             for (int k = 0; k < DM; ++k)
                 if (k < dz) {
                     const double aa = llrx_hx - cz[k], bb = llry_all - cz[k];
-                    msgz[swd_edge_slot(ez[k])] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb);
+                    msgz[swd_edge_slot(ez[k])] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb, xt);
                     if (bx) atomicXor(&parz[swd_edge_lane(ez[k])], 1u); // Hz * x-string
                 }
 #endif
@@ -375,7 +409,9 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         ++q_iters;
 #endif
     }
-    if (p_set) { lpr_b[tid] = p_x; lpr_b[n + tid] = p_y; lpr_b[2 * n + tid] = p_z; } // (read back below by this thread only)
+    if (SWD_BP4_PRIO_IT >= 0) __builtin_amdgcn_s_setprio(0);
+    // the next unit's ticket: drawn as soon as this decode's iterations are over, so that the atomic's round trip overlaps the stores below
+    if (a.ticket && tid == 0) tk_next = gridDim.x + atomicAdd(a.ticket, 1u);
     if (!conv) {
         bool unsat = false;
         if (a.max_iter > 0) {
@@ -386,7 +422,11 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES : 1)) bp
         iters = a.max_iter;
         conv = any ? 0 : 1;
     }
-    if (a.camel) {
+    // the posteriors of the last update: an output when the caller asked for them, otherwise only the OSD kernel reads them -- a decode
+    // that converged (all but a few per thousand at the notebooks' noise rates) stores nothing (24 n bytes per decode, 226 MB per
+    // 65 536-decode launch of the 144-qubit code before)
+    if (p_set && (a.lpr_wanted || (!conv && !camel_run && a.osd_order >= 0))) { lpr_b[tid] = p_x; lpr_b[n + tid] = p_y; lpr_b[2 * n + tid] = p_z; }
+    if (camel_run) {
         uint8_t *dst = a.camel_dec + (int64_t)unit * 2 * n;
         for (int v = tid; v < n; v += NT) { dst[v] = decx[v]; dst[n + v] = decz[v]; }
         if (tid == 0) {
@@ -487,6 +527,19 @@ __global__ void __launch_bounds__(NT) bp4_osd_kernel(const SwdBp4Args a) {
         }
         if (tid == 0) a.stats[(int64_t)b * SWD_STAT_WORDS + 7] = rowadds;
     }
+}
+
+// syndrome weight of every decode (both bases), for the start order of a launch: one wave per decode
+__global__ void __launch_bounds__(256) bp4_weight_kernel(const uint8_t *sx, const uint8_t *sz, int mx, int mz, int B, uint32_t *wt) {
+    const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const uint8_t *px = sx + (int64_t)b * mx, *pz = sz + (int64_t)b * mz;
+    int c = 0;
+    for (int r = lane; r < mx; r += 64) c += px[r] ? 1 : 0;
+    for (int r = lane; r < mz; r += 64) c += pz[r] ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) wt[b] = (uint32_t)min(c, 1023);
 }
 
 // camel_decode's choice among the four runs of a shot: the converged run of smallest path metric, strict < keeps

@@ -39,7 +39,9 @@ SWD_LIBM_FN uint64_t swd_exp_tab(unsigned i) {
 #endif
 }
 
-SWD_LIBM_FN double swd_exp(double x) {
+// `tab`: where the 256-word table is read from -- NULL: the constant array above; the quaternary decoder's BP kernel passes its
+// copy in LDS (one 16-byte LDS read per evaluation instead of two dependent gathers through the vector memory path)
+SWD_LIBM_FN double swd_exp_from(double x, const uint64_t *tab) {
     const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8,
                  NegLn2loN = -0x1.cf79abc9e3b3ap-47, C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3,
                  C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
@@ -59,8 +61,8 @@ SWD_LIBM_FN double swd_exp(double x) {
     const double r = __builtin_fma(kd, NegLn2loN, __builtin_fma(kd, NegLn2hiN, x));
     const unsigned idx = 2u * (unsigned)(ki & 127u);
     const uint64_t top = ki << 45;
-    const double tail = swd_asd(swd_exp_tab(idx));
-    uint64_t sbits = swd_exp_tab(idx + 1) + top;
+    const double tail = swd_asd(tab ? tab[idx] : swd_exp_tab(idx));
+    uint64_t sbits = (tab ? tab[idx + 1] : swd_exp_tab(idx + 1)) + top;
     const double r2 = r * r;
     const double tmp = __builtin_fma(r2 * r2, __builtin_fma(r, C5, C4), __builtin_fma(r2, __builtin_fma(r, C3, C2), tail + r));
     if (abstop == 0) {                                 // 512 <= |x| < 1024: the scale factor needs care
@@ -85,6 +87,8 @@ SWD_LIBM_FN double swd_exp(double x) {
     const double scale = swd_asd(sbits);
     return __builtin_fma(scale, tmp, scale);
 }
+
+SWD_LIBM_FN double swd_exp(double x) { return swd_exp_from(x, (const uint64_t *)0); }
 
 SWD_LIBM_FN double swd_log1p(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
