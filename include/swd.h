@@ -312,6 +312,11 @@ int swd_pipeline_get_profile(swd_pipeline *pl, int32_t B, int64_t *out);
 int swd_pipeline_set_timing(swd_pipeline *pl, int32_t on);
 int swd_pipeline_get_timing(swd_pipeline *pl, double *total_ms, int64_t *launches);
 
+/* diagnostics: occupies `blocks` workgroups of `threads` threads with `lds_bytes` of LDS each for `microseconds` (bounded: at most
+ * 2 s) on `stream` -- a foreign, long-running kernel for tests of the persistent grids' forward progress under reduced
+ * residency (tests/test_gpu_forward_progress.py: blocks that each take more than half a CU's LDS hold one CU apiece). */
+int swd_diag_occupy(int device, int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t microseconds, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

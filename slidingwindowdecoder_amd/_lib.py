@@ -92,6 +92,7 @@ SYMBOLS = [
     ("swd_sampler_info", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     ("swd_sampler_sample", C.c_int, [_vp, _i32, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     ("swd_sampler_sample_dev", C.c_int, [_vp, _i32, C.c_uint64, C.c_uint64, _vp, _i64, _vp, _vp, _i64, _vp]),
+    ("swd_diag_occupy", C.c_int, [C.c_int, _i32, _i32, _i32, _i32, _vp]),
 ]
 
 STAT_WORDS = 8

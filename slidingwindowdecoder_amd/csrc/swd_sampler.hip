@@ -163,3 +163,26 @@ extern "C" int swd_sampler_info(const swd_sampler *h, int32_t *num_det, int32_t 
     if (num_obs) *num_obs = s->num_obs;
     return 0;
 }
+
+// ---- diagnostics: a foreign kernel that holds workgroup slots for a bounded time (include/swd.h: swd_diag_occupy) ----
+namespace swd {
+__global__ void __launch_bounds__(1024) occupy_kernel(long long ticks, uint32_t *sink) {
+    extern __shared__ __attribute__((aligned(16))) char occ_smem[];
+    const long long t0 = wall_clock64(); // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && threadIdx.x == 0 && occ_smem[0] == 77) sink[0] = 1u; // (keeps the LDS allocation alive)
+}
+} // namespace swd
+
+extern "C" int swd_diag_occupy(int device, int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t microseconds, void *stream) {
+    if (blocks <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 2000000) {
+        swd::set_error("swd_diag_occupy: blocks > 0, 1..1024 threads, 0..163840 bytes of LDS, at most 2 000 000 us");
+        return -1;
+    }
+    SWD_HIP(hipSetDevice(device));
+    SWD_HIP(hipFuncSetAttribute((const void *)swd::occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(swd::occupy_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), (size_t)lds_bytes, (hipStream_t)stream,
+                       (long long)microseconds * 100, (uint32_t *)nullptr);
+    SWD_HIP(hipGetLastError());
+    return 0;
+}
