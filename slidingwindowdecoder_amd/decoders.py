@@ -218,16 +218,33 @@ class osd_window:
         return np.ascontiguousarray(self._hist.T)
 
 
+def hypotheses_shape(hyp):
+    """(max_tree_depth D, max_side_depth S) of the decimation tree with exactly ``hyp`` root-to-leaf hypotheses per shot:
+    leaves = 1 (main) + (S - D) (side branches below the tree) + 2 (2^D - 1) (two per tree node; bpgd.cpp:576-577,
+    bp_guessing_decoder.pyx:181) with the deepest full tree that fits -- 64 -> D = 5, S = 6; 32 -> (4, 5); 16 -> (3, 4); 100 -> (5, 42).
+    The device holds trees of depth <= 6 and at most 160 snapshots (2 (2^D - 1) + S - D)."""
+    hyp = int(hyp)
+    if hyp < 1:
+        raise ValueError("hypotheses must be a positive integer")
+    D = 0
+    while D < 6 and 2 * (2 ** (D + 1) - 1) + 1 <= hyp:
+        D += 1
+    side = hyp - (2 * (2 ** D - 1) + 1)
+    if 2 * (2 ** D - 1) + side > 160:
+        raise ValueError(f"hypotheses={hyp}: the device holds at most 161 hypotheses per shot (tree depth 6 would need "
+                         f"{2 * (2 ** D - 1) + side} snapshots, limit 160)")
+    return D, D + side
+
+
 def _gdg_params(kwargs, mode):
-    """kwargs of bp_guessing_decoder.pyx:7-9, 162-171, 475-478.  ``hypotheses=64`` (not a reference kwarg) picks the tree
-    shape that fills 64 hypotheses per shot -- leaves = 1 + (S - D) + 2 (2^D - 1) with D = 5, S = 6 (bpgd.cpp:576-577) --
-    and the ensemble semantics of ``multi_thread=True``."""
+    """kwargs of bp_guessing_decoder.pyx:7-9, 162-171, 475-478.  ``hypotheses=H`` (not a reference kwarg) picks the tree
+    shape with H hypotheses per shot (``hypotheses_shape``: 64 -> max_tree_depth 5, max_side_depth 6) and scores every leaf
+    of gdg()'s tree (``multi_thread=2``, this package's own ensemble)."""
     kwargs = dict(kwargs)
     hyp = kwargs.pop("hypotheses", None)
     if hyp is not None:
-        if int(hyp) != 64:
-            raise ValueError("hypotheses: only 64 is provided (max_tree_depth=5, max_side_depth=6)")
-        kwargs.update(max_tree_depth=5, max_side_depth=6, multi_thread=2)  # 2: every leaf of gdg()'s tree (not a reference mode)
+        D, S_ = hypotheses_shape(hyp)
+        kwargs.update(max_tree_depth=D, max_side_depth=S_, multi_thread=2)  # 2: every leaf of gdg()'s tree (not a reference mode)
     new_n = kwargs.get("new_n", None)
     return _lib.GdgParams(int(kwargs.get("max_iter", 50)), float(kwargs.get("ms_scaling_factor", 1.0)),
                           int(kwargs.get("max_iter_per_step", 6)), int(kwargs.get("max_step", 25)),
@@ -249,7 +266,7 @@ class bp_history_decoder:
     Every decode of the ensemble has the state of a NEWLY BUILT reference object: when ``BPGD::reset`` fails the zero vector is
     returned (a re-used reference object returns its previous decode's ``min_pm_error``, bpgd.cpp:583, 619-625), and each thread's
     posterior history starts from zeros (a re-used reference thread keeps its own stale slots when ``max_iter_per_step < 4``);
-    ``hypotheses=64`` is this package's own ensemble over every leaf of gdg()'s tree (no reference counterpart)."""
+    ``hypotheses=H`` is this package's own ensemble over every leaf of gdg()'s tree with H leaves (no reference counterpart)."""
     _mode = 2
 
     def __init__(self, parity_check_matrix, **kwargs):

@@ -293,7 +293,16 @@ def test_hypothesis_ensemble_mode():
     tr = fx.Trace(f, "gdg_win5_", *mat.shape)
     single = S.bpgdg_decoder(mat, channel_probs=priors, **kw)
     out1 = single.decode_batch(tr.synd)
-    for extra in (dict(multi_thread=2), dict(hypotheses=64)):
+    from slidingwindowdecoder_amd.decoders import hypotheses_shape
+    assert hypotheses_shape(64) == (5, 6) and hypotheses_shape(32) == (4, 5) and hypotheses_shape(1) == (0, 0) and hypotheses_shape(100) == (5, 42)
+    for h in (1, 2, 3, 7, 16, 64, 100, 161):  # leaves = 1 + (S - D) + 2 (2^D - 1)
+        D, Sd = hypotheses_shape(h)
+        assert 1 + (Sd - D) + 2 * (2 ** D - 1) == h and 0 <= D <= 6
+    with pytest.raises(ValueError):
+        hypotheses_shape(162)
+    with pytest.raises(ValueError):
+        hypotheses_shape(0)
+    for extra in (dict(multi_thread=2), dict(hypotheses=64), dict(hypotheses=16), dict(hypotheses=7), dict(hypotheses=100), dict(hypotheses=2), dict(hypotheses=1)):
         ens = S.bpgdg_decoder(mat, channel_probs=priors, **dict(kw, **extra))
         out = ens.decode_batch(tr.synd)
         assert np.array_equal(out, ens.decode_batch(tr.synd))  # deterministic
@@ -301,6 +310,8 @@ def test_hypothesis_ensemble_mode():
         H = mat.toarray().astype(np.int64)
         assert not ((out[conv].astype(np.int64) @ H.T + tr.synd[conv]) % 2).any()
         c1 = (single.last_status & 0x100) != 0
+        if extra.get("hypotheses") == 16:  # D = 3, S = 4: a deeper ensemble of the same family can only find a smaller (or the same) metric
+            ens16_pm, ens16_conv = ens.last_min_pm.copy(), conv.copy()
         if "multi_thread" in extra:  # same tree shape: a superset of the hypotheses the pruned search scores
             assert (conv | ~c1).all()
             both = conv & c1
