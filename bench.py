@@ -89,7 +89,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9   # same guide: max clock
 NUM_CU, SIMD_PER_CU = 256, 4
-PROFILE_TAGS = ("r05", "r04", "r03")  # newest first; find_profile falls back to the round-2 headline files
+PROFILE_TAGS = ("r06", "r05", "r04", "r03")  # newest first; find_profile falls back to the round-2 headline files
 STUB = os.environ.get("SWD_BENCH_STUB") == "1"  # launcher test on CPU: gloo + a stand-in decoder, never a measurement
 
 

@@ -37,6 +37,9 @@
 #ifndef SWD_POST_DEPTH2
 #define SWD_POST_DEPTH2 0
 #endif
+#ifndef SWD_BP_HARD_DEFER
+#define SWD_BP_HARD_DEFER 1
+#endif
 // Round-5 experiments on the iteration loop's dependent LDS round trips (bp_run):
 //   SWD_BP_XARG_TRACK        1: the sign of a check's first-minimum position comes out of the sign shift registers (one compare-select
 //                               more per position) instead of a re-read of the message before the write phase
@@ -845,6 +848,23 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #pragma unroll
         for (int k = 0; k < DM; ++k) e[k] = g.vn_edge[max(min(k, g.D - 1), 0) * n + v];
     };
+    // Round 6: the hard decisions of a variable-node pass stay in a register (one bit per cache row) and go to LDS once, when the run
+    // ends -- nothing reads s.hard while the iterations run (convergence is tested through the parity words), and the byte store per row
+    // and iteration was one LDS instruction in twenty-five of the loop (SWD_BP_HARD_DEFER=0: the store per row of rounds 1-5)
+    constexpr bool kHardDefer = SWD_BP_HARD_DEFER != 0 && VF <= 32 && !TBL;
+    [[maybe_unused]] uint32_t hdbits = 0;
+    [[maybe_unused]] auto hard_flush = [&]() {
+        if constexpr (kHardDefer) {
+#pragma unroll
+            for (int i = 0; i < VF; ++i)
+                if (i < nch) { // wave-uniform
+                    const int idx = s.vtid + i * NT;
+                    int v;
+                    if constexpr (!kNodeList) v = (idx < vcnt) ? idx : n; else v = vnode[i];
+                    ((bool *)s.hard)[v] = ((hdbits >> i) & 1u) != 0u;
+                }
+        }
+    };
     for (int it = 0; it < max_iter; ++it) {
         bool unsat = force_unsat; // a check without any selected column but syndrome 1 can never be met
         BPT(tc0);
@@ -1028,7 +1048,12 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         acc_cn += tc1 - tc0; acc_any += tc2 - tc1;
         if (it > 0 && !any && !FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
 #endif
-        if (it > 0 && !any) { iters_done = it; return 1; }
+        if (it > 0 && !any) {
+            if constexpr (kHardDefer) { hard_flush(); __syncthreads(); } // (callers read other threads' decisions)
+            iters_done = it;
+            return 1;
+        }
+        if constexpr (kHardDefer) hdbits = 0;
 
         const int slot_h = it & 3;
         const bool record = record_all || it >= max_iter - 4;
@@ -1089,7 +1114,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                     if (record && valid) hist_b[slot_h * n + v] = temp;
                 }
                 const bool hd = valid && (temp <= 0);
-                ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
+                if constexpr (kHardDefer) hdbits |= hd ? (1u << i) : 0u;
+                else ((bool *)s.hard)[v] = hd; // a bool store is not a character-type access: it does not fence the double loads / stores around it
                 double suf = 0.0;
 #pragma unroll
                 for (int k = KD - 1; k >= 0; --k) {
@@ -1168,6 +1194,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
 #ifdef SWD_BPPROF
     if (!FULL && tid == 0) { s.scal[24] += (int)acc_cn; s.scal[25] += (int)acc_any; s.scal[26] += (int)acc_vn; s.scal[27] += (int)acc_bar; }
 #endif
+    hard_flush(); // (visible to the other threads behind block_any's barrier)
     bool unsat = force_unsat;
     for (int l = tid; l < m; l += NT)
         if (s.cn_val[l] >= 0 && (PB ? ((const uint8_t *)s.par)[l] != 0 : s.par[l] != 0u)) unsat = true;
@@ -3016,8 +3043,13 @@ __device__ __forceinline__ double osd_sweep(const SwdGraphDev &g, const SwdLdsLa
 // solution; the return value is its path metric (sum of g.llr over the solution in column order).
 // QUAD: the scratch region is LDS (osd0_quad addresses its ring there)
 // WIDE: large-graph kernel (osd0_colsw when the layout has its LDS block)
+#ifdef SWD_OSD_NOINLINE // experiment (round 6): the OSD of the shots that need one as a function of its own
+#define SWD_OSD_FN __device__ __attribute__((noinline))
+#else
+#define SWD_OSD_FN __device__ __forceinline__
+#endif
 template <int NT, int DM, bool COLFORM = false, bool QUAD = COLFORM, bool WIDE = false> // COLFORM: the caller's kernel can afford osd0_cols (osd_window kernels of 1024 threads)
-__device__ __forceinline__ double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
+SWD_OSD_FN double osd_run(const SwdGraphDev &g, const SwdLdsLayout &L, const SwdDecodeParams &P, Lds &s,
                                           const uint8_t *synd, uint8_t *osd0_b, int &rowadds, long long &t_sorted,
                                           long long &t_elim, bool presorted = false) {
     const int tid = threadIdx.x, m = g.m, n = g.n;
