@@ -124,5 +124,5 @@ if "bp4shyps" in which:  # BASELINE config 5's decoder on config 5's code (code 
     print(json.dumps({"config": "configs[4] decoder: bp4_osd on the SHYPS r=3 stabiliser matrices (21x49 each), depolarizing p=0.02, max_iter=32, osd_cs 10 "
                                 "(host buffers, PCIe included)", "decodes": B, "decodes_per_s": B / dt, "decodes_per_s_decisions_only": B / dt2,
                       "converged_fraction": float(((dec.last_status & 0x100) != 0).mean())}), flush=True)
-if "w2" in which:  # occupancy experiment: (2,1) windows of the [[144,12,12]] circuit need 34 KB of LDS
+if "w2" in which:  # occupancy experiment (docs/history/DESIGN_rounds_1-5.md section 6): (2,1) windows of the [[144,12,12]] circuit need 34 KB of LDS
     run_pipeline("[[144,12,12]] p=0.003 (2,1) osd_window(pre=8, post=200, osd_cs 0)", bench.build_problem(W=2), 4096, 5, **bench.DECODER_KW)

@@ -305,7 +305,14 @@ extern "C" swd_osdw *swd_osdw_create(const swd_graph_desc *g, const swd_osdw_par
     d->device = device;
     d->p = *p;
     std::map<std::string, std::shared_ptr<Graph>> cache;
-    if (check_params(d->p) || d->add_window(g, 0, 0, 0, cache) || d->finalize(nullptr)) { delete d; return nullptr; }
+    if (check_params(d->p)) { delete d; return nullptr; }
+    if (getenv("SWD_FORCE_HUGE") /* tests: the general form on graphs a variant would take */ || d->add_window(g, 0, 0, 0, cache) || d->finalize(nullptr)) {
+        // no kernel variant takes this graph (more than 1024 checks, 9216 columns, 65 535 edges, row weight 64 or column weight 10):
+        // the general form, every array in HBM (swd_huge.hip) -- the reference's mod2sparse has no size limit
+        d->wins.clear();
+        d->huge.reset(huge_create(g, &d->p, device));
+        if (!d->huge) { delete d; return nullptr; }
+    }
     return (swd_osdw *)d;
 }
 
@@ -319,6 +326,13 @@ extern "C" void swd_osdw_destroy(swd_osdw *h) {
 extern "C" int swd_osdw_info(const swd_osdw *h, int32_t *m, int32_t *n, int32_t *new_n, int32_t *rank) {
     const Plan *d = (const Plan *)h;
     if (!d) { set_error("null decoder"); return -1; }
+    if (d->huge) {
+        if (m) *m = d->huge->m;
+        if (n) *n = d->huge->n;
+        if (new_n) *new_n = d->huge->new_n;
+        if (rank) *rank = d->huge->rank;
+        return 0;
+    }
     const WindowHost &w = d->wins[0];
     if (m) *m = w.g->m;
     if (n) *n = w.g->n;
@@ -351,9 +365,10 @@ extern "C" int swd_osdw_decode_batch_dev(swd_osdw *h, int32_t B, const uint8_t *
     if (B <= 0) return 0;
     if (!synd || !out) { set_error("null output/input pointer"); return -1; }
     SWD_HIP(hipSetDevice(d->device));
+    if (!hist && hist_is_state) { set_error("hist_is_state requires a caller-provided history buffer"); return -1; }
+    if (d->huge) return d->huge->decode_dev(B, synd, synd_stride, out, out_stride, stats, min_pm, hist, hist_is_state, osd0, bp_dec, stream);
     const int n = d->wins[0].g->n, m = d->wins[0].g->m;
     const bool hist_out = hist != nullptr;
-    if (!hist && hist_is_state) { set_error("hist_is_state requires a caller-provided history buffer"); return -1; }
     SwdPipeArgs a{};
     a.wins = d->d_wins.as<SwdWindowDev>(); a.W = 1; a.B = B;
     fill_params(d, a.P, hist_is_state != 0, hist_out);
@@ -372,7 +387,7 @@ static int osdw_decode_batch_direct(swd_osdw *h, int32_t B, const uint8_t *synd,
     if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
     std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
-    const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
+    const size_t m = d->m0(), n = d->n0();
     const size_t hbytes = (size_t)B * 4 * n * 8;
     if (d->synd.reserve(B * m) || d->out.reserve(B * n) || d->stats.reserve((size_t)B * SWD_STAT_WORDS * 4) ||
         d->pm.reserve(B * 8) || (hist && d->hist.reserve(hbytes)))
@@ -404,7 +419,7 @@ extern "C" int swd_osdw_decode_batch(swd_osdw *h, int32_t B, const uint8_t *synd
     if (!synd || !out || !stats || !min_pm) { set_error("null output/input pointer"); return -1; }
     std::lock_guard<std::recursive_mutex> lk(d->mu);
     SWD_HIP(hipSetDevice(d->device));
-    const size_t m = d->wins[0].g->m, n = d->wins[0].g->n;
+    const size_t m = d->m0(), n = d->n0();
     // one packed device buffer mirrored by a pinned host buffer: [ syndromes | history ] travel in,
     // [ history | vectors | statistics | path metrics | OSD-0 vectors ] travel out, one copy each way
     const bool hist_in = hist && hist_is_state;

@@ -76,7 +76,20 @@ bool split_map(const Graph &g, int nt, int cap, std::vector<uint32_t> *map);
 
 
 
+// The general form of osd_window for graphs beyond every kernel variant (swd_huge.hip): every array in HBM, several checks / nodes
+// per thread.  A Plan that carries one has no windows; the single-window entry points route to it.
+struct HugeIface {
+    int m = 0, n = 0, new_n = 0, rank = 0;
+    virtual ~HugeIface() {}
+    virtual int decode_dev(int32_t B, const uint8_t *synd, int64_t synd_stride, uint8_t *out, int64_t out_stride, int32_t *stats,
+                           double *min_pm, double *hist, int32_t hist_is_state, uint8_t *osd0, uint8_t *bp_dec, void *stream) = 0;
+};
+HugeIface *huge_create(const swd_graph_desc *g, const swd_osdw_params *p, int device);
+
 struct Plan {
+    std::unique_ptr<HugeIface> huge;
+    int m0() const { return huge ? huge->m : wins[0].g->m; }
+    int n0() const { return huge ? huge->n : wins[0].g->n; }
     std::vector<WindowHost> wins;
     swd_osdw_params p{};
     swd_gdg_params gp{};

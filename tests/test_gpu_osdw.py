@@ -240,7 +240,7 @@ def test_fuzz_large_m_column_form_elimination_vs_oracle():
 def test_v7816_osd_exits_vs_oracle(seed):
     """The matrices of the fuzz campaign that exposed the round-3 miscompile (seeds 7000 / 7001, 121..300 checks: the
     <256, 7, 8, 16> kernel returned a wrong vector on every OSD exit when built with -structurizecfg-skip-uniform-regions and the
-    explicitly scalar loop values) -- the same trials, deterministic, in the suite.  Fails if a compiler or
+    explicitly scalar loop values; docs/history/DESIGN_rounds_1-5.md section 8) -- the same trials, deterministic, in the suite.  Fails if a compiler or
     flag change brings the wrong OSD ordering back."""
     import subprocess
     import sys
