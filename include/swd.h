@@ -159,9 +159,9 @@ int swd_gdg_decode_batch_dev(swd_gdg *d, int32_t B, const uint8_t *synd, int64_t
  * reference links (glibc >= 2.28: table-driven exp in its FMA build, fdlibm log1p -- csrc/swd_libm.h), so
  * posterior LLRs, decisions and OSD orderings are bit-identical to a reference run on an FMA-capable x86-64.
  * Restrictions (swd_bp4_create fails with a message): column weight of Hx / Hz <= 10; osd_order > 0 needs
- * rank(Hx) == rank(Hz) -- the reference accepts unequal ranks there but then sizes the z-basis sweep with
- * kz = n - rank_x (bp4_osd.pyx:103-104, :284), i.e. reads candidates that do not exist; that quirk is not
- * reproduced. */
+ * rank(Hx) >= rank(Hz) -- the reference sizes BOTH sweeps with kx = n - rank_x (bp4_osd.pyx:103-104, :284): with
+ * rank(Hx) > rank(Hz) its z-basis sweep walks fewer candidate columns than exist, which is reproduced (pinned by
+ * tests/golden/bp4_unequal_ranks.npz); with rank(Hx) < rank(Hz) it reads past its column array, which is not. */
 typedef struct swd_bp4_params {
     int32_t max_iter;          /* default 32 */
     double ms_scaling_factor;

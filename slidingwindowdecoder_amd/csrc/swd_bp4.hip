@@ -133,8 +133,10 @@ extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_des
         set_error("For this code, the OSD order should be set in the range 0<=osd_oder<=%d.", kmin);
         delete d; return nullptr;
     }
-    if (d->p.osd_order > 0 && d->gx.rank != d->gz.rank) {
-        set_error("higher-order OSD with rank(Hx) != rank(Hz) is undefined in the reference (kz = n - rank_x) and not supported");
+    if (d->p.osd_order > 0 && d->gx.rank < d->gz.rank) {
+        // the reference sizes BOTH sweeps with kx = n - rank_x (bp4_osd.pyx:103-104, :284); with rank(Hx) < rank(Hz) its z-basis sweep
+        // reads n - rank_x columns behind the rank_z pivots of an n-long array, i.e. past its end
+        set_error("higher-order OSD with rank(Hx) < rank(Hz) is undefined in the reference (kz = n - rank_x: it reads past its column array) and not supported");
         delete d; return nullptr;
     }
     if (d->p.osd_method == 1 && d->p.osd_order > 15) { set_error("osd_e supports osd_order <= 15 on the device"); delete d; return nullptr; }
@@ -146,6 +148,10 @@ extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_des
     if (const char *e = getenv("SWD_BP4_NT")) { const int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) d->nt = v; } // (diagnostics)
     if (d->gx.upload() || d->gz.upload()) { delete d; return nullptr; }
     d->gx.d.new_n = n; d->gz.d.new_n = n;
+    // rank(Hx) > rank(Hz): the z-basis sweep walks the first kx = n - rank_x non-pivot columns like the reference's (not the n - rank_z
+    // that exist).  The sweep takes k = new_n - rank candidate columns among the first new_n sorted ones, and the first k non-pivot
+    // columns always lie among the first k + rank: new_n = kx + rank_z is the same set.
+    if (d->p.osd_order > 0 && d->gx.rank > d->gz.rank) d->gz.d.new_n = n - d->gx.rank + d->gz.rank;
     make_layout_for_osd(d->gx, d->nt_osd, d->Lx);
     make_layout_for_osd(d->gz, d->nt_osd, d->Lz);
     auto al = [](int x, int a) { return (x + a - 1) / a * a; };

@@ -58,8 +58,8 @@ while done < trials:
     try:
         dev = bp4_osd(Hx, Hz, **kw)
     except (ValueError, RuntimeError) as ex:
-        if "rank(Hx) != rank(Hz)" in str(ex):
-            continue  # documented: the reference's own arithmetic is undefined there
+        if "rank(Hx) < rank(Hz)" in str(ex):
+            continue  # documented: the reference reads past its column array there (rank(Hx) > rank(Hz) is decoded, and compared)
         print(f"trial {done}: device rejected n={n} mx={mx} mz={mz}: {ex}")
         bad += 1; done += 1
         continue

@@ -437,6 +437,37 @@ def gen_bp4(ref):
     save("bp4_depolarizing.npz", **arrs)
 
 
+def gen_bp4_unequal_ranks(ref):
+    """bp4_osd with rank(Hx) > rank(Hz) and a higher-order sweep: the reference sizes BOTH sweeps with kx = n - rank_x
+    (bp4_osd.pyx:103-104, :284) -- well defined in this direction (the z-basis sweep simply walks fewer candidate columns); with
+    rank(Hx) < rank(Hz) it reads past its column array.  Random ragged matrices, unequal X / Y / Z priors."""
+    rng = np.random.default_rng(2718)
+    arrs = {}
+    for tag, mx, mz, n, kw in [("cs3", 14, 12, 40, dict(max_iter=6, ms_scaling_factor=0.8, osd_method="osd_cs", osd_order=3)),
+                               ("e4", 16, 13, 48, dict(max_iter=5, ms_scaling_factor=1.0, osd_method="osd_e", osd_order=4))]:
+        def rand_h(m):
+            H = np.zeros((m, n), np.uint8)
+            for c in range(n):
+                H[rng.choice(m, size=3, replace=False), c] = 1
+            return H
+        Hx, Hz = rand_h(mx), rand_h(mz)
+        Hz[mz - 1] = Hz[0] ^ Hz[1]  # a redundant check: rank(Hz) < mz <= rank(Hx)
+        px, py, pz = rng.uniform(0.01, 0.04, n), rng.uniform(0.01, 0.04, n), rng.uniform(0.01, 0.04, n)
+        dec = ref.bp4_osd(Hx.astype(int), Hz.astype(int), channel_probs_x=px, channel_probs_y=py, channel_probs_z=pz, **kw)
+        sxs, szs, outs, conv, its = [], [], [], [], []
+        for _ in range(250):
+            pa = rng.choice(4, size=n, p=[0.85, 0.05, 0.05, 0.05])
+            ex, ez = ((pa == 1) | (pa == 2)).astype(np.uint8), ((pa == 3) | (pa == 2)).astype(np.uint8)
+            sx, sz = (Hx @ ez) % 2, (Hz @ ex) % 2
+            out = dec.decode(sx, sz)
+            sxs.append(sx); szs.append(sz); outs.append(np.asarray(out, np.uint8)); conv.append(int(dec.converge)); its.append(int(dec.bp_iteration))
+        arrs.update({tag + "_hx": Hx, tag + "_hz": Hz, tag + "_px": px, tag + "_py": py, tag + "_pz": pz, tag + "_params": json.dumps(kw),
+                     tag + "_sx": pack(np.array(sxs)), tag + "_sz": pack(np.array(szs)), tag + "_out": pack(np.array(outs)),
+                     tag + "_converge": np.array(conv, np.uint8), tag + "_bp_iteration": np.array(its, np.int32)})
+        print(f"  bp4_unequal/{tag}: converge {sum(conv)}/250")
+    save("bp4_unequal_ranks.npz", **arrs)
+
+
 def gen_bp4_camel(ref):
     """bp4_osd.camel_decode (src/bp4_osd.pyx:223-247, used by Misc.ipynb): one reference object per case, calls in
     sequence (the returned vectors persist in the object when no run converges)."""
@@ -512,7 +543,7 @@ def gen_bp4_shyps(ref):
 def main():
     ensure_reference()
     import src as ref
-    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "bb288_gdg", "kat288", "bp4", "camel", "bp4_shyps", "global144"]
+    which = sys.argv[1:] or ["bb72", "bb144", "bb288", "bb288_gdg", "kat288", "bp4", "camel", "bp4_shyps", "global144", "bp4_unequal"]
     if "bb72" in which:
         gen_bb72(ref)
     if "bb144" in which:
@@ -531,6 +562,8 @@ def main():
         gen_bp4_camel(ref)
     if "bp4_shyps" in which:
         gen_bp4_shyps(ref)
+    if "bp4_unequal" in which:
+        gen_bp4_unequal_ranks(ref)
 
 
 if __name__ == "__main__":

@@ -152,3 +152,25 @@ def test_bp4_concurrent_launches_of_one_handle_on_two_streams():
     for i, (k, (out, st)) in enumerate(res):
         assert np.array_equal(out.cpu().numpy(), wants[k][0]), f"launch {i} (stream {k}): vectors differ from the single launch"
         assert np.array_equal(st.cpu().numpy(), wants[k][1]), f"launch {i} (stream {k}): status words differ"
+
+
+@pytest.mark.parametrize("tag", ["cs3", "e4"])
+def test_bp4_unequal_ranks_matches_reference(tag):
+    """rank(Hx) > rank(Hz) with a higher-order sweep (refused until round 6): the reference sizes both sweeps with kx = n - rank_x
+    (bp4_osd.pyx:103-104, :284); vectors, converge flags and iteration counts of the run recorded from the reference.  The other
+    direction -- the reference reads past its column array -- stays a refusal with a message."""
+    from slidingwindowdecoder_amd import bp4_osd
+    f = fx.load("bp4_unequal_ranks.npz")
+    Hx, Hz = f[tag + "_hx"], f[tag + "_hz"]
+    kw = fx.params(f, tag + "_params")
+    pr = dict(channel_probs_x=f[tag + "_px"], channel_probs_y=f[tag + "_py"], channel_probs_z=f[tag + "_pz"])
+    dec = bp4_osd(Hx, Hz, **pr, **kw)
+    assert dec.rank_x > dec.rank_z
+    sx, sz, want = fx.unpack(f[tag + "_sx"], Hx.shape[0]), fx.unpack(f[tag + "_sz"], Hz.shape[0]), fx.unpack(f[tag + "_out"], Hx.shape[1])
+    out = dec.decode_batch(sx, sz)
+    bad = np.flatnonzero((out != want).any(axis=(1, 2)))
+    assert bad.size == 0, f"{bad.size} decodes differ: {bad[:8]}"
+    assert np.array_equal((dec.last_status & 0x100) != 0, f[tag + "_converge"] != 0)
+    assert np.array_equal(dec.last_iterations, f[tag + "_bp_iteration"])
+    with pytest.raises((ValueError, RuntimeError), match="rank"):
+        bp4_osd(Hz, Hx, **pr, **kw)  # rank(Hx) < rank(Hz)
