@@ -14,7 +14,8 @@ int make_layout_for_osd(const Graph &g, int nt, SwdLdsLayout &L); // swd_osdw.hi
 struct Bp4 {
     Graph gx, gz;
     swd_bp4_params p{};
-    int device = 0, nt = 256, nt_osd = 256, dm = 4, n = 0; // nt: threads of the BP kernel (a launch parameter), nt_osd: of the OSD kernel (its layouts)
+    int device = 0, nt = 256, nt_osd = 256, dm = 4, n = 0;
+    int nt_split = 0; // > 0: threads of the launch with two threads per qubit (the specialised instantiation; swd_bp4_kernel.h) // nt: threads of the BP kernel (a launch parameter), nt_osd: of the OSD kernel (its layouts)
     SwdLdsLayout Lx{}, Lz{};
     SwdBp4Layout L{};
     DevBuf llr, sx, sz, out, osd0, stats, pm, bpd, io, lpr; // (sx .. lpr: staging of the host-buffer entry points)
@@ -45,7 +46,9 @@ struct Bp4 {
 };
 
 template <int WMAX, int NTO, int DM, bool FAST>
-static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
+static int bp4_launch(Bp4 *d, const SwdBp4Args &a0, hipStream_t st, int nt) {
+    SwdBp4Args a = a0;
+    a.split = (FAST && nt == d->nt_split) ? 1 : 0;
     static std::mutex fn_mu; // the attributes and occupancy answers belong to the functions, not to a handle
     std::lock_guard<std::mutex> fn_lock(fn_mu);
     static int lds_limit[64] = {0};
@@ -55,18 +58,18 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
     }
     // persistent grid: as many workgroups as the device holds at once, each walks its share of the units
     static int slots[64] = {0}, slots_lds[64] = {0}, slots_nt[64] = {0};
-    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total || slots_nt[d->device & 63] != d->nt) {
+    if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total || slots_nt[d->device & 63] != nt) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM, FAST>, d->nt, (size_t)d->L.total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM, FAST>, nt, (size_t)d->L.total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         while (per_cu > 1 && (long long)per_cu * ((d->L.total + 2048 + 1279) / 1280 * 1280) > 160 * 1024) --per_cu; // LDS is granted in granules of 1280 B (swd_plan.h); + the kernel's 2 KB exp table
         slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
-        slots_lds[d->device & 63] = d->L.total; slots_nt[d->device & 63] = d->nt;
+        slots_lds[d->device & 63] = d->L.total; slots_nt[d->device & 63] = nt;
     }
     const int units = a.camel ? 4 * a.B : a.B;
     const bool with_osd = !a.camel && a.osd_order >= 0;
     if (with_osd || a.ticket) SWD_HIP(hipMemsetAsync(a.osd_count, 0, 4 * sizeof(uint32_t), st)); // (queue counter, ticket counter)
-    hipLaunchKernelGGL((bp4_kernel<WMAX, DM, FAST>), dim3(std::min(units, slots[d->device & 63])), dim3(d->nt), d->L.total, st, a);
+    hipLaunchKernelGGL((bp4_kernel<WMAX, DM, FAST>), dim3(std::min(units, slots[d->device & 63])), dim3(nt), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
     if (with_osd) { // the queue of unconverged decodes (often empty: its workgroups then read the count and leave)
         static int lds_limit2[64] = {0}, slots2[64] = {0}, slots2_lds[64] = {0};
@@ -89,22 +92,24 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
 }
 
 template <int WMAX, int NTO, bool FAST>
-static int bp4_dispatch_dm(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
-    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4, FAST>(d, a, st)
-                      : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8, FAST>(d, a, st) : bp4_launch<WMAX, NTO, SWD_DMAX, FAST>(d, a, st));
+static int bp4_dispatch_dm(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) {
+    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4, FAST>(d, a, st, nt)
+                      : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8, FAST>(d, a, st, nt) : bp4_launch<WMAX, NTO, SWD_DMAX, FAST>(d, a, st, nt));
 }
-template <int WMAX, int NTO>
-static int bp4_dispatch_fast(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
-    // the specialised instantiation: a thread per qubit and per check, no camel run (swd_bp4_kernel.h)
-    const bool fast = !a.camel && d->n <= d->nt && d->gx.m + d->gz.m <= d->nt && !getenv("SWD_BP4_GENERIC");
-    return fast ? bp4_dispatch_dm<WMAX, NTO, true>(d, a, st) : bp4_dispatch_dm<WMAX, NTO, false>(d, a, st);
+template <bool FAST>
+static int bp4_dispatch_nt(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) {
+    // BP kernel: one thread per qubit (two in the specialised launch) while the waves fit a workgroup; OSD kernel: the workgroups its
+    // layouts were made for
+    if (nt <= 256) return bp4_dispatch_dm<4, 256, FAST>(d, a, st, nt); // (n <= 3072: the OSD layouts are those of 256 threads)
+    if (nt <= 512) return bp4_dispatch_dm<8, 256, FAST>(d, a, st, nt); // (still six waves per SIMD: three workgroups of up to eight waves per CU)
+    return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256, FAST>(d, a, st, nt) : bp4_dispatch_dm<16, 1024, FAST>(d, a, st, nt);
 }
 static int bp4_dispatch(Bp4 *d, const SwdBp4Args &a, hipStream_t st) {
-    // BP kernel: one thread per qubit while ceil(n / 64) waves fit a workgroup (the decodes of the notebooks' codes take a few
-    // iterations -- what a launch costs is the number of waves it occupies); OSD kernel: the workgroups its layouts were made for
-    if (d->nt <= 256) return bp4_dispatch_fast<4, 256>(d, a, st); // (n <= 3072: the OSD layouts are those of 256 threads)
-    if (d->nt <= 512) return bp4_dispatch_fast<8, 256>(d, a, st); // (still six waves per SIMD: three workgroups of up to eight waves per CU)
-    return d->nt_osd == 256 ? bp4_dispatch_fast<16, 256>(d, a, st) : bp4_dispatch_fast<16, 1024>(d, a, st);
+    // the specialised instantiation: a thread per qubit and per check, no camel run (swd_bp4_kernel.h); two threads per qubit for
+    // small codes (swd_bp4_create; SWD_BP4_NOSPLIT: the one-thread form)
+    const bool fast = !a.camel && d->n <= d->nt && d->gx.m + d->gz.m <= d->nt && !getenv("SWD_BP4_GENERIC");
+    if (fast) return bp4_dispatch_nt<true>(d, a, st, d->nt_split ? d->nt_split : d->nt);
+    return bp4_dispatch_nt<false>(d, a, st, d->nt);
 }
 } // namespace swd
 
@@ -146,6 +151,11 @@ extern "C" swd_bp4 *swd_bp4_create(const swd_graph_desc *hx, const swd_graph_des
     d->nt_osd = n <= 3072 ? 256 : 1024;
     d->nt = n <= 1024 ? std::max(64, (n + 63) / 64 * 64) : 1024;
     if (const char *e = getenv("SWD_BP4_NT")) { const int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) d->nt = v; } // (diagnostics)
+    // two threads per qubit while the workgroup stays within four waves (measured, profiles/r06_bp4_split.log: [[72]] 43.8 -> 46.9 M
+    // decodes/s, SHYPS r = 3 23.9 -> 24.9 M; [[144]] on five waves 35.9 -> 28.0 M, so larger codes keep one thread per qubit;
+    // SWD_BP4_SPLIT_MAX overrides the bound on 2 n for experiments)
+    const int split_max = getenv("SWD_BP4_SPLIT_MAX") ? atoi(getenv("SWD_BP4_SPLIT_MAX")) : 256;
+    d->nt_split = (2 * n <= std::min(split_max, 512) && !getenv("SWD_BP4_NOSPLIT")) ? std::max(64, (2 * n + 63) / 64 * 64) : 0;
     if (d->gx.upload() || d->gz.upload()) { delete d; return nullptr; }
     d->gx.d.new_n = n; d->gz.d.new_n = n;
     // rank(Hx) > rank(Hz): the z-basis sweep walks the first kx = n - rank_x non-pivot columns like the reference's (not the n - rank_z
@@ -235,11 +245,19 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     a.osd_count = sl->osd_q.as<uint32_t>(); a.osd_list = sl->osd_q.as<int32_t>() + 4;
     static const bool static_units = getenv("SWD_BP4_STATIC") != nullptr; // (diagnostics: the static shares of rounds 4-5)
     if (!static_units) {
-        uint32_t *wt = sl->osd_q.as<uint32_t>() + 4 + B, *ord = wt + B;
-        hipLaunchKernelGGL(bp4_weight_kernel, dim3((B + 3) / 4), dim3(256), 0, st, sx, sz, d->gx.m, d->gz.m, B, wt);
-        hipLaunchKernelGGL((shot_order_kernel<1024>), dim3(1), dim3(1024), 0, st, (const uint32_t *)wt, B, ord);
-        SWD_HIP(hipGetLastError());
-        a.ticket = a.osd_count + 1; a.order = ord;
+        a.ticket = a.osd_count + 1;
+        // start order: heaviest syndrome first.  The decodes that run all max_iter iterations are NOT the heaviest ones ([[144]]: weights 5-25
+        // around a median of 10, spread over ranks 0.07-0.89 of the order: profiles/r06_bp4_heavy.log), so the order does not move the tail of
+        // a launch; it still pays where the iteration count follows the weight -- SHYPS r = 3 18.8 -> 24.9 M decodes/s, [[72]] 40.0 -> 45.9,
+        // [[144]] 35.1 -> 36.2; [[288]] .. [[756]] lose 2-3 % to the two small kernels (profiles/r06_bp4_order.log).  SWD_BP4_NO_ORDER: off
+        static const bool by_weight = getenv("SWD_BP4_NO_ORDER") == nullptr;
+        if (by_weight) {
+            uint32_t *wt = sl->osd_q.as<uint32_t>() + 4 + B, *ord = wt + B;
+            hipLaunchKernelGGL(bp4_weight_kernel, dim3((B + 3) / 4), dim3(256), 0, st, sx, sz, d->gx.m, d->gz.m, B, wt);
+            hipLaunchKernelGGL((shot_order_kernel<1024>), dim3(1), dim3(1024), 0, st, (const uint32_t *)wt, B, ord);
+            SWD_HIP(hipGetLastError());
+            a.order = ord;
+        }
     }
     if (bp4_dispatch(d, a, st)) return -1;
     SWD_HIP(hipEventRecord(sl->done, st));

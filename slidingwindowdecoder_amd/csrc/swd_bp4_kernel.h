@@ -42,6 +42,7 @@ struct SwdBp4Args {
     // 60 % empty on average.  Both NULL: static shares (camel runs).
     uint32_t *ticket;        // zeroed before the launch
     const uint32_t *order;   // [B] decode numbers by decreasing syndrome weight (bp4_weight_kernel + shot_order_kernel)
+    int32_t split;           // FAST instantiation: two threads per qubit -- thread v the Hx edges of qubit v, thread n + v its Hz edges
     int32_t lpr_wanted;      // the caller reads lpr: every decode stores its posteriors (else only those the OSD kernel finishes)
     uint8_t *camel_dec;      // [4B][2][n] decisions of every run
     double *camel_pm;        // [4B] cal_pm of the converged runs
@@ -200,20 +201,27 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
     for (int j = tid; j <= gx.K; j += NT) jpx[j] = gx.jptr[j];
     for (int j = tid; j <= gz.K; j += NT) jpz[j] = gz.jptr[j];
     const bool one = FAST || n <= NT;
-    const bool mine = one && tid < n;
+    // Round 6: two threads per qubit (a.split; FAST launches with 2 n <= 1024).  Both compute the node's three posteriors from all of its
+    // messages (same operations in the same order), thread v then updates the Hx edges, thread n + v the Hz edges: the chain of eight
+    // dependent exp / log1p evaluations per node and iteration -- what a launch waits for once its units are ticket-scheduled: the
+    // decodes that run all max_iter iterations -- becomes two chains of four.
+    const bool split = FAST && a.split != 0;
+    const int vt = (split && tid >= n) ? tid - n : tid;          // the thread's qubit
+    const int hsel = !split ? 3 : (tid < n ? 1 : 2);             // bit 0: the Hx edges are this thread's, bit 1: the Hz edges
+    const bool mine = one && vt < n;
     int c_dx = 0, c_dz = 0;
     uint32_t c_ex[DM], c_ez[DM];
     double c_lx = 0.0, c_ly = 0.0, c_lz = 0.0;
 #pragma unroll
     for (int k = 0; k < DM; ++k) { c_ex[k] = 0u; c_ez[k] = 0u; }
     if (mine) {
-        c_dx = gx.col_deg[tid]; c_dz = gz.col_deg[tid];
+        c_dx = gx.col_deg[vt]; c_dz = gz.col_deg[vt];
 #pragma unroll
         for (int k = 0; k < DM; ++k) {
-            c_ex[k] = (k < c_dx) ? gx.vn_edge[k * n + tid] : 0u;
-            c_ez[k] = (k < c_dz) ? gz.vn_edge[k * n + tid] : 0u;
+            c_ex[k] = (k < c_dx) ? gx.vn_edge[k * n + vt] : 0u;
+            c_ez[k] = (k < c_dz) ? gz.vn_edge[k * n + vt] : 0u;
         }
-        c_lx = a.llr_x[tid]; c_ly = a.llr_y[tid]; c_lz = a.llr_z[tid];
+        c_lx = a.llr_x[vt]; c_ly = a.llr_y[vt]; c_lz = a.llr_z[vt];
     }
     // (the messages of bp_init depend on the channel only: three of a decode's ~14 exp / log1p evaluations, hoisted out of the unit loop)
     double c_mx = 0.0, c_mz = 0.0;
@@ -274,8 +282,8 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
         for (int l = tid; l < mx; l += NT) cnx[l] = (int8_t)(sx_b[gx.perm[l]] ? 1 : 0);
         for (int l = tid; l < mz; l += NT) cnz[l] = (int8_t)(sz_b[gz.perm[l]] ? 1 : 0);
     }
-    for (int v = tid; v < n; v += NT) {
-        decx[v] = 0; decz[v] = 0;
+    for (int v = vt; v < n; v += NT) {
+        if (hsel & 1) { decx[v] = 0; decz[v] = 0; }
         double m_x = c_mx, m_z = c_mz;
         if (!one) {
             const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
@@ -285,7 +293,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
         const int dx = one ? c_dx : (int)gx.col_deg[v], dz = one ? c_dz : (int)gz.col_deg[v];
         if (one) {
 #pragma unroll
-            for (int k = 0; k < DM; ++k) { if (k < dx) msgx[swd_edge_slot(c_ex[k])] = m_x; if (k < dz) msgz[swd_edge_slot(c_ez[k])] = m_z; }
+            for (int k = 0; k < DM; ++k) { if (k < dx && (hsel & 1)) msgx[swd_edge_slot(c_ex[k])] = m_x; if (k < dz && (hsel & 2)) msgz[swd_edge_slot(c_ez[k])] = m_z; }
         } else {
             for (int k = 0; k < dx; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
             for (int k = 0; k < dz; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
@@ -319,7 +327,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
         const bool any = bp4_block_any(unsat, s, NT >> 6);
         BP4T(2) // flags + barrier
         if (it > 0 && !any) { conv = 1; iters = it; break; }
-        for (int v = tid; v < n; v += NT) { // vn_update (bp4_osd.pyx:533-589)
+        for (int v = vt; v < n; v += NT) { // vn_update (bp4_osd.pyx:533-589)
             if (v == fixed) { // decided (bp4_osd.pyx:456-458): its bit-to-check messages stay the priors of bp_init; the
                               // CN pass has just overwritten the shared slots with check-to-bit values, so put them back
                 const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
             const double llry_all = llrx_hx + llrz_hz + v_ly;
             llrx_hx = llrx_hx + v_lx;
             llrz_hz = llrz_hz + v_lz;
-            if (one) { p_x = llrx_hx; p_y = llry_all; p_z = llrz_hz; p_set = true; }
+            if (one) { p_x = llrx_hx; p_y = llry_all; p_z = llrz_hz; p_set = (hsel & 1) != 0; }
             else { lpr_b[v] = llrx_hx; lpr_b[n + v] = llry_all; lpr_b[2 * n + v] = llrz_hz; }
             int idx;
             if (0 < llrx_hx && 0 < llry_all && 0 < llrz_hz) idx = 0;
@@ -356,9 +364,9 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
             else if (llry_all > llrz_hz) idx = 2;
             else idx = 3;
             const int bx = idx & 1, bz = idx >> 1;
-            decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz;
+            if (hsel & 1) { decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz; }
             BP4T(3) // node: message loads, sums, posteriors, decision
-            const double num_hx = bp4_log1pexp(-1. * llrx_hx, xt);
+            const double num_hx = (hsel & 1) ? bp4_log1pexp(-1. * llrx_hx, xt) : 0.0;
             BP4T(4) // log1pexp
 #if SWD_BP4_ROLLED // one body of the helper per basis instead of DM: the edge word is picked by a select chain, the message re-read from LDS
             auto pick = [&](const uint32_t (&ev)[DM], int k) { uint32_t e = ev[0];
@@ -366,7 +374,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
                 for (int j = 1; j < DM; ++j) e = (k == j) ? ev[j] : e;
                 return e; };
 #pragma unroll 1
-            for (int k = 0; k < dx; ++k) {
+            for (int k = 0; k < ((hsel & 1) ? dx : 0); ++k) {
                 const uint32_t e = pick(ex, k);
                 const double c = msgx[swd_edge_slot(e)];
                 const double aa = llrz_hz - c, bb = llry_all - c;
@@ -374,10 +382,10 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
                 if (bz) atomicXor(&parx[swd_edge_lane(e)], 1u); // Hx * z-string
             }
             BP4T(5) // Hx edges: logaddexp + store + parity flip each
-            const double num_hz = bp4_log1pexp(-1. * llrz_hz, xt);
+            const double num_hz = (hsel & 2) ? bp4_log1pexp(-1. * llrz_hz, xt) : 0.0;
             BP4T(4)
 #pragma unroll 1
-            for (int k = 0; k < dz; ++k) {
+            for (int k = 0; k < ((hsel & 2) ? dz : 0); ++k) {
                 const uint32_t e = pick(ez, k);
                 const double c = msgz[swd_edge_slot(e)];
                 const double aa = llrx_hx - c, bb = llry_all - c;
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
 #else
 #pragma unroll
             for (int k = 0; k < DM; ++k)
-                if (k < dx) {
+                if (k < dx && (hsel & 1)) {
                     const double aa = llrz_hz - cx[k], bb = llry_all - cx[k];
                     msgx[swd_edge_slot(ex[k])] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb, xt);
                     if (bz) atomicXor(&parx[swd_edge_lane(ex[k])], 1u); // Hx * z-string
@@ -396,7 +404,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
             const double num_hz = bp4_log1pexp(-1. * llrz_hz, xt);
 #pragma unroll
             for (int k = 0; k < DM; ++k)
-                if (k < dz) {
+                if (k < dz && (hsel & 2)) {
                     const double aa = llrx_hx - cz[k], bb = llry_all - cz[k];
                     msgz[swd_edge_slot(ez[k])] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb, xt);
                     if (bx) atomicXor(&parz[swd_edge_lane(ez[k])], 1u); // Hz * x-string
@@ -425,7 +433,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
     // the posteriors of the last update: an output when the caller asked for them, otherwise only the OSD kernel reads them -- a decode
     // that converged (all but a few per thousand at the notebooks' noise rates) stores nothing (24 n bytes per decode, 226 MB per
     // 65 536-decode launch of the 144-qubit code before)
-    if (p_set && (a.lpr_wanted || (!conv && !camel_run && a.osd_order >= 0))) { lpr_b[tid] = p_x; lpr_b[n + tid] = p_y; lpr_b[2 * n + tid] = p_z; }
+    if (p_set && (a.lpr_wanted || (!conv && !camel_run && a.osd_order >= 0))) { lpr_b[vt] = p_x; lpr_b[n + vt] = p_y; lpr_b[2 * n + vt] = p_z; }
     if (camel_run) {
         uint8_t *dst = a.camel_dec + (int64_t)unit * 2 * n;
         for (int v = tid; v < n; v += NT) { dst[v] = decx[v]; dst[n + v] = decz[v]; }
