@@ -622,13 +622,13 @@ def roofline(workload, kernel, alg_bytes, lds_alg_bytes, avg_kernel_s, irreducib
     return out
 
 
-def measure_other_workload(workload, args, rank, local_rank, steps=5):
+def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None):
     """One of the other workloads on this GPU after the headline's timed region: `steps` steps in the step mode `bench.py --workload
     <w>` uses (after one warm-up step), then three single launches under HIP events -> a compact record for config.other_workloads."""
     import copy
     wl = WORKLOADS[workload]
     a = copy.copy(args)
-    a.workload, a.shots, a.steps, a.warmup = workload, default_shots(workload), steps, 1
+    a.workload, a.shots, a.steps, a.warmup = workload, (shots or default_shots(workload)), steps, 1
     osdw = workload in ("bb288", "global144")
     streaming = osdw and not args.no_stream
     t_setup = time.perf_counter()
@@ -885,9 +885,11 @@ def main():
         del engine
         torch.cuda.empty_cache()
         cfg["other_workloads"] = []
-        for w in ("bb288", "gdg", "gdg64", "global144", "bp4"):
+        # (the guessing decoders a second time at 16384 shots per launch: at 4096 their launches are bound by the longest shots' chains of
+        #  eleven windows, not by the device -- BASELINE configs[2] names no batch size)
+        for w, sh in (("bb288", None), ("gdg", None), ("gdg", 16384), ("gdg64", None), ("gdg64", 16384), ("global144", None), ("bp4", None)):
             try:  # a failing side workload must not lose the headline record
-                cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank))
+                cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank, steps=5 if sh is None else 2, shots=sh))
             except Exception as e:  # noqa: BLE001
                 cfg["other_workloads"].append({"workload": w, "error": f"{type(e).__name__}: {e}"[:500]})
             torch.cuda.empty_cache()

@@ -570,10 +570,22 @@ class SlidingWindowDecoder:
         self._pool = _HostPool()
         create = L.swd_pipeline_create if decoder == "osd_window" else L.swd_pipeline_create_gdg
         self._h = create(self.W, C.cast(descs, C.c_void_p), C.byref(chk.desc), C.byref(p), self.device)
+        self._loop = None
         if not self._h:
             msg = _lib.last_error()
             if "OSD order" in msg or "invalid" in msg:
                 raise ValueError(msg)
+            if decoder == "osd_window" and ("no kernel variant" in msg or "exceeds" in msg or "needs" in msg):
+                # windows beyond every kernel variant (e.g. the un-windowed [[288,12,18]] model, 2736 x 26 208): the window loop of
+                # /root/reference/osd.py:130-179 as the reference runs it -- one osd_window per window (device: the general form,
+                # csrc/swd_huge.hip), the residual syndrome det ^ chk @ total_e_hat between windows (osd.py:165, 178) on the host
+                self._loop = [osd_window(w.mat, channel_probs=w.prior, device=self.device,
+                                         **{k: v for k, v in kwargs.items() if k != "device"}) for w in plan.windows]
+                self._chk_t = sp.csr_matrix(plan.chk.T.astype(np.int32))
+                self.lds_bytes, self.threads = 0, 1024
+                self.num_obs = int(plan.obs.shape[0]) if plan.obs is not None else 0
+                self._obs_t = sp.csr_matrix(plan.obs.T.astype(np.int32)) if self.num_obs else None
+                return
             raise RuntimeError(f"swd_pipeline_create failed: {msg}")
         i = [C.c_int32() for _ in range(5)]
         L.swd_pipeline_info(self._h, *[C.byref(x) for x in i])
@@ -611,6 +623,8 @@ class SlidingWindowDecoder:
         faults always travel device -> host in that form (1098 B per shot instead of 8784 for the [[144,12,12]] experiment)."""
         d = self._check_det(det_data)
         B = d.shape[0]
+        if self._loop is not None:
+            return self._decode_window_loop(d, packed)
         pool = self._pool
         total = pool.take((B, (self.num_col + 7) // 8 if packed else self.num_col), np.uint8)
         st = pool.take((B, self.W, _lib.STAT_WORDS), np.int32)
@@ -624,9 +638,37 @@ class SlidingWindowDecoder:
         self.last_obs_flips, self.last_flagged = shot[:, 0].astype(np.uint32), shot[:, 1].astype(bool)
         return total
 
+    def _decode_window_loop(self, d, packed):
+        """the window loop for plans no pipeline kernel takes: per window one batched osd_window decode on the device, commit, residual"""
+        B = d.shape[0]
+        total = np.zeros((B, self.num_col), np.uint8)
+        st = np.zeros((B, self.W, _lib.STAT_WORDS), np.int32)
+        pm = np.zeros((B, self.W), np.float64)
+        cur = d
+        for wi, (w, dec) in enumerate(zip(self.plan.windows, self._loop)):
+            out = dec.decode_batch(np.ascontiguousarray(cur[:, w.row0:w.row1])) if B else np.zeros((0, w.mat.shape[1]), np.uint8)
+            total[:, w.col0:w.col0 + w.commit] = out[:, :w.commit]
+            if B:
+                st[:, wi, 0], st[:, wi, 1], pm[:, wi] = dec.last_status, dec.last_iterations, dec.last_min_pm
+            cur = ((d.astype(np.int32) + (sp.csr_matrix(total) @ self._chk_t).toarray()) % 2).astype(np.uint8)  # osd.py:178
+        self.last_stats, self.last_min_pm = st, pm
+        self.last_flagged = cur.any(axis=1)
+        flips = np.zeros(B, np.uint32)
+        if self._obs_t is not None and self.num_obs <= 32 and B:
+            bits = ((sp.csr_matrix(total) @ self._obs_t).toarray() % 2).astype(np.uint32)
+            flips = (bits << np.arange(self.num_obs, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+        self.last_obs_flips = flips
+        return np.packbits(total, axis=1, bitorder="little") if packed else total
+
+    def _no_loop(self, what):
+        if self._loop is not None:
+            raise RuntimeError(f"{what} needs the one-launch pipeline; this plan's windows are beyond every kernel variant and run as a "
+                               "window loop of osd_window decodes (use decode())")
+
     def stream(self, max_shots, packed=False, want_stats=True):
         """Streaming form for consecutive batches (``SlidingWindowStream``): two batches in flight on two lanes of this
         pipeline, copies and unpacking of batch k overlapped with the launch of batch k + 1."""
+        self._no_loop("stream()")
         return SlidingWindowStream(self, max_shots, packed=packed, want_stats=want_stats)
 
     def decode_stream(self, batches, packed=False, want_stats=True):
@@ -658,6 +700,7 @@ class SlidingWindowDecoder:
         asynchronous on the current torch stream.  ``shot_result`` (int32 [B, 2] CUDA tensor, optional)
         receives the predicted observable-flip mask and the flagged bit of every shot."""
         import torch
+        self._no_loop("decode_device()")
         if det.dtype != torch.uint8 or det.dim() != 2 or det.shape[1] != self.num_det or det.stride(1) != 1:
             raise ValueError(f"det must be a uint8 tensor [B, {self.num_det}] with unit column stride")
         if not det.is_cuda or det.device.index != self.device:
@@ -683,6 +726,8 @@ class SlidingWindowDecoder:
         """Synchronises the device and raises if any launch of this pipeline since the last check recorded a
         scheduling fault (a window whose predecessor never finished: exit class 6 in ``stats``).  The host-buffer
         ``decode`` checks by itself; callers of the asynchronous ``decode_device`` call this after their launches."""
+        if self._loop is not None:
+            return
         flags = C.c_uint32(0)
         if _lib.lib().swd_pipeline_status(self._h, C.byref(flags)):
             raise RuntimeError(f"swd_pipeline_status failed: {_lib.last_error()}")

@@ -124,3 +124,32 @@ def test_graphs_beyond_the_general_form_are_refused():
     H = _rand_h(rng, 4100, 5000, 3, ragged=False)
     with pytest.raises((ValueError, RuntimeError)):
         osd_window(H, channel_probs=np.full(5000, 0.01), osd_method="osd_0")
+
+
+def test_window_loop_for_plans_beyond_every_pipeline_kernel():
+    """SlidingWindowDecoder on (W,F) = (10,1) windows of the 18-round [[288,12,18]] experiment (1440 x ~13 k each: no pipeline kernel
+    takes them): the window loop of osd.py:130-179 with one device osd_window per window; total_e_hat, per-window iterations and the
+    flagged bits equal the same loop over the oracle"""
+    import bench
+    from oracle import oracle as O
+    from slidingwindowdecoder_amd import SlidingWindowDecoder
+    from slidingwindowdecoder_amd.windows import sample_dem
+    plan = bench.build_problem(N=288, p=0.002, rounds=18, W=10, F=1)
+    assert len(plan.windows) > 1 and max(w.mat.shape[0] for w in plan.windows) > 1024
+    kw = dict(pre_max_iter=8, post_max_iter=24, ms_scaling_factor=1.0, osd_method="osd_cs", osd_order=4)
+    dec = SlidingWindowDecoder(plan, **kw)
+    det, _, _ = sample_dem(plan.chk, plan.obs, plan.priors, 3, seed=5)
+    total = dec.decode(det)
+    chk_t = sp.csr_matrix(plan.chk.T.astype(np.int32))
+    want = np.zeros_like(total)
+    cur = det.copy()
+    for wi, w in enumerate(plan.windows):
+        o = O.osd_window(w.mat, channel_probs=w.prior, **kw)
+        out, res = o.decode_batch(cur[:, w.row0:w.row1])
+        want[:, w.col0:w.col0 + w.commit] = out[:, :w.commit]
+        assert np.array_equal(dec.last_stats[:, wi, 1], res["bp_iteration"]), f"window {wi}"
+        cur = ((det + (sp.csr_matrix(want) @ chk_t).toarray()) % 2).astype(np.uint8)
+    assert np.array_equal(total, want)
+    assert np.array_equal(dec.last_flagged, cur.any(axis=1))
+    with pytest.raises(RuntimeError, match="window loop"):
+        dec.stream(8)
