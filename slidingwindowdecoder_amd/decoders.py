@@ -325,8 +325,50 @@ class bp_history_decoder:
 
 
 class bpgdg_decoder(bp_history_decoder):
-    """BP + guided decimation guessing (reference: src/bp_guessing_decoder.pyx:160-442)."""
+    """BP + guided decimation guessing (reference: src/bp_guessing_decoder.pyx:160-442).
+
+    ``multi_thread=True`` and ``decode()`` one syndrome at a time: the reference keeps ONE ``BPGD_main_thread`` for the object's
+    lifetime (bp_guessing_decoder.pyx:238-251) whose ``min_pm_error`` -- a vector over the POSITIONS of the sorted order, not over
+    columns -- is never cleared (bpgd.cpp:597-599); when ``BPGD::reset`` fails, ``do_work`` returns before anything is written to it
+    (:619-625) and the decoder copies the PREVIOUS decode's position vector over this decode's first new_n sorted columns.  The
+    object reproduces that (``reuse_object=True``, the default; round 6): the device decodes with the state of a new object, the
+    sorted order of the decode is recomputed from the pre-processing history it returns (stable argsort of the slot-order sum,
+    bp_guessing_decoder.pyx:240-244), and the position vector is kept between calls.  ``decode_batch`` gives every shot a new
+    object's state (zero vector on a failed reset)."""
     _mode = 0
+
+    def __init__(self, parity_check_matrix, **kwargs):
+        super().__init__(parity_check_matrix, **kwargs)
+        nn = kwargs.get("new_n", None)
+        self._new_n = min(int(nn), self.n) if nn else min(self.n, 2 * self.m)  # bp_guessing_decoder.pyx:186-189
+        self._ens = kwargs.get("multi_thread", False) is True or kwargs.get("multi_thread", False) == 1
+        self._ens = bool(self._ens) and "hypotheses" not in kwargs
+        self._reuse = bool(kwargs.get("reuse_object", True))
+        self._prev_pos = np.zeros(self._new_n, np.uint8)  # min_pm_error of a new object: zeros
+
+    def decode(self, input_vector):
+        if not (self._ens and self._reuse):
+            return super().decode(input_vector)
+        s = _as_synd(input_vector, self.m)
+        out = np.zeros(self.n, dtype=np.uint8)
+        st = np.zeros(_lib.STAT_WORDS, np.int32)
+        pm = np.zeros(1, np.float64)
+        hist = np.zeros((4, self.n), np.float64)
+        rc = _lib.lib().swd_gdg_decode_batch(self._h, 1, s.ctypes.data, out.ctypes.data, st.ctypes.data, pm.ctypes.data, hist.ctypes.data, 0)
+        if rc:
+            raise RuntimeError(f"swd_gdg_decode_batch failed: {_lib.last_error()}")
+        self._last = dict(status=int(st[0]), iters=int(st[1]), min_pm=float(pm[0]))
+        exit_class = int(st[0]) & 0xFF
+        if exit_class == EXIT_PRE:  # the pre-processing BP converged: the ensemble object is not touched
+            return out.astype(np.int64)
+        llr_sum = ((hist[0] + hist[1]) + hist[2]) + hist[3]
+        cols = np.argsort(llr_sum, kind="stable")[:self._new_n]
+        if exit_class == EXIT_FAIL_PEEL:  # BPGD::reset failed: the previous decode's position vector over THIS decode's sorted columns
+            out[:] = 0
+            out[cols] = self._prev_pos
+        else:
+            self._prev_pos = out[cols].copy()
+        return out.astype(np.int64)
 
 
 class bpgd_decoder(bp_history_decoder):

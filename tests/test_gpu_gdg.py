@@ -608,3 +608,77 @@ def test_pipeline_with_more_than_256_windows_takes_the_serial_form():
         def decode(self, s): return O.bpgdg_decoder(self.w.mat, channel_probs=self.w.prior, **kw).decode(s)
     want, _ = sliding_window_decode_host(plan, det, Fresh)
     assert np.array_equal(total, want)
+
+
+def test_reused_ensemble_object_semantics_vs_the_reference_object():
+    """bpgdg_decoder(multi_thread=True).decode() one syndrome at a time against ONE re-used BPGD_main_thread of the reference
+    (oracle/_ref, the reference's own bpgd.cpp compiled where it lies; the library travels to the GPU box): when BPGD::reset fails
+    the reference hands back its PREVIOUS decode's position vector over this decode's sorted columns (bpgd.cpp:597-599, 619-625,
+    bp_guessing_decoder.pyx:247-251) -- round 5 returned zeros there.  Every decode's vector must equal the reference object's,
+    stale ones included (decodes whose winning path metric is tied between different vectors are left out: thread timing)."""
+    import ctypes as C
+    import os
+    import scipy.sparse as sp
+    import slidingwindowdecoder_amd as S
+    from oracle import oracle as O
+    REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libswd_ref.so")
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/libswd_ref.so did not travel to this box (built from /root/reference by make -C oracle ref)")
+    from tests.test_oracle_vs_ref import Pcm
+    R = C.CDLL(REF)
+    vp, i32 = C.c_void_p, C.c_int32
+    R.ref_pcm_new.restype = vp
+    R.ref_pcm_new.argtypes = [i32, i32, vp, vp]
+    R.ref_pcm_free.argtypes = [vp]
+    R.ref_gdg_multi_new.restype = vp
+    R.ref_gdg_multi_new.argtypes = [i32] * 9 + [C.c_double]
+    R.ref_gdg_multi_free.argtypes = [vp]
+    R.ref_gdg_multi_decode.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    f = fx.load("bb72_capacity.npz")
+    mat, _ = fx.graph(f, "gdg_")
+    m, n = mat.shape
+    rng = np.random.default_rng(5)
+    priors = rng.uniform(0.03, 0.08, size=n)
+    new_n = 24
+    kw = dict(max_iter=8, ms_scaling_factor=1.0, max_iter_per_step=6, max_step=25, max_tree_depth=3, max_side_depth=10,
+              max_tree_branch_step=10, max_side_branch_step=10, gdg_factor=1.0, new_n=new_n)
+    H = sp.csr_matrix(mat).astype(np.int64)
+    synds = [(H @ (rng.random(n) < priors * 1.3).astype(np.int64) % 2).astype(np.uint8) for _ in range(120)]
+    synds += [(rng.random(m) < 0.3).astype(np.uint8) for _ in range(120)]
+    order = rng.permutation(len(synds))
+    dev = S.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
+    fresh = S.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, reuse_object=False, **kw)
+    ora = O.bpgdg_decoder(mat, channel_probs=priors, multi_thread=True, **kw)
+    p = Pcm(R, mat)
+    llr = np.ascontiguousarray(np.log((1 - priors) / priors))
+    obj = R.ref_gdg_multi_new(m, new_n, kw["max_iter_per_step"], kw["max_step"], kw["max_tree_depth"], kw["max_side_depth"],
+                              kw["max_tree_branch_step"], kw["max_side_branch_step"], 0, 1.0)
+    ran = fails = stale = 0
+    for k in order:
+        s = synds[k]
+        ora.clear_history()
+        o_out = ora.decode(s)
+        got = dev.decode(s)
+        if ora._res.exit_class == 0:  # the pre-processing BP converged: the ensemble object is not touched
+            assert np.array_equal(got, o_out)
+            continue
+        cols = np.ascontiguousarray(ora.cols)
+        err, rpm, rpms = np.zeros(new_n, np.uint8), C.c_double(), np.zeros(256)
+        su = np.ascontiguousarray(s, np.uint8)
+        R.ref_gdg_multi_decode(obj, p.h, m, new_n, cols.ctypes.data, llr.ctypes.data, su.ctypes.data, err.ctypes.data, C.byref(rpm), rpms.ctypes.data)
+        ref_out = np.zeros(n, np.int64)
+        ref_out[cols[:new_n]] = err
+        ran += 1
+        if ora.ensemble_blocks()[0] == 0:  # BPGD::reset failed
+            fails += 1
+            stale += int(err.any())
+            assert np.array_equal(got, ref_out), "a failed reset must hand back the previous decode's position vector"
+            assert not fresh.decode(s).any() and not dev.converge
+            continue
+        if ora.ensemble_info()[2] == 0:
+            assert np.array_equal(got, ref_out)
+            assert bool(dev.converge) == (rpm.value < 9999.0)
+        else:  # tied winners: the device and the reference may pick different vectors; keep the two objects' states aligned
+            dev._prev_pos = err.copy()
+    R.ref_gdg_multi_free(obj)
+    assert ran >= 80 and fails >= 5 and stale >= 3, (ran, fails, stale)
