@@ -9,4 +9,4 @@ for f in swd_osdw swd_kernels_k0 swd_kernels_k1 swd_kernels_k2 swd_kernels_k3 sw
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o build/${f}_dev.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../${SWD_DEV_OUT:-libswd_hip_dev.so} build/swd_graph.o build/swd_osdw_dev.o build/swd_kernels_k0_dev.o build/swd_kernels_k1_dev.o build/swd_kernels_k2_dev.o build/swd_kernels_k3_dev.o build/swd_kernels_k5.o build/swd_kernels_k7_dev.o build/swd_kernels_k8.o build/swd_bp4.o build/swd_sampler.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../${SWD_DEV_OUT:-libswd_hip_dev.so} build/swd_graph.o build/swd_osdw_dev.o build/swd_kernels_k0_dev.o build/swd_kernels_k1_dev.o build/swd_kernels_k2_dev.o build/swd_kernels_k3_dev.o build/swd_kernels_k5.o build/swd_kernels_k7_dev.o build/swd_kernels_k8.o build/swd_bp4.o build/swd_sampler.o build/swd_huge.o

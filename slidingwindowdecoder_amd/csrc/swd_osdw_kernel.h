@@ -40,6 +40,9 @@
 #ifndef SWD_BP_HARD_DEFER
 #define SWD_BP_HARD_DEFER 1
 #endif
+#ifndef SWD_BP_PAR_INC
+#define SWD_BP_PAR_INC 1
+#endif
 // Round-5 experiments on the iteration loop's dependent LDS round trips (bp_run):
 //   SWD_BP_XARG_TRACK        1: the sign of a check's first-minimum position comes out of the sign shift registers (one compare-select
 //                               more per position) instead of a re-read of the message before the write phase
@@ -852,7 +855,8 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
     // ends -- nothing reads s.hard while the iterations run (convergence is tested through the parity words), and the byte store per row
     // and iteration was one LDS instruction in twenty-five of the loop (SWD_BP_HARD_DEFER=0: the store per row of rounds 1-5)
     constexpr bool kHardDefer = SWD_BP_HARD_DEFER != 0 && VF <= 32 && !TBL;
-    [[maybe_unused]] uint32_t hdbits = 0;
+    constexpr bool kParInc = kHardDefer && SWD_BP_PAR_INC != 0;
+    [[maybe_unused]] uint32_t hdbits = 0, hdprev = 0;
     [[maybe_unused]] auto hard_flush = [&]() {
         if constexpr (kHardDefer) {
 #pragma unroll
@@ -870,12 +874,16 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
         BPT(tc0);
         {
             if (cv >= 0 && cn.sub == 0) {
+                // kParInc (round 6): the parity word of a check is set once per run and then kept up to date by the nodes whose decision
+                // CHANGED in a pass (the previous pass's decisions are the bits of hdbits) -- instead of being reset here and flipped by
+                // every node that decides 1 in every pass: after a few iterations few decisions move, and a wave without one skips
+                // the atomics of the row altogether.  Same value in front of every test (residual check value ^ parity of the decisions).
                 if constexpr (PB) { // tuned kernels: one parity byte per check, flipped by word atomics (bit 8 (l & 3) of word l >> 2)
                     if (it > 0 && ((const uint8_t *)s.par)[l] != 0) unsat = true;
-                    ((uint8_t *)s.par)[l] = (uint8_t)cv;
+                    if (!kParInc || it == 0) ((uint8_t *)s.par)[l] = (uint8_t)cv;
                 } else {
                     if (it > 0 && s.par[l] != 0u) unsat = true;
-                    s.par[l] = (uint32_t)cv;
+                    if (!kParInc || it == 0) s.par[l] = (uint32_t)cv;
                 }
             }
             // CN pass (osd_window.pyx:393-439).  Slots come from registers, so the message reads of a
@@ -1053,7 +1061,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
             iters_done = it;
             return 1;
         }
-        if constexpr (kHardDefer) hdbits = 0;
+        if constexpr (kHardDefer) { hdprev = hdbits; hdbits = 0; }
 
         const int slot_h = it & 3;
         const bool record = record_all || it >= max_iter - 4;
@@ -1148,7 +1156,7 @@ __device__ __forceinline__ int bp_run(const SwdGraphDev &g, const SwdDecodeParam
                         }
                     }
                 } else
-                if (hd) {
+                if (kParInc ? (hd != (((hdprev >> i) & 1u) != 0u)) : hd) {
 #pragma unroll
                     for (int k2 = 0; k2 < (KD + 1) / 2; ++k2) {
                         uint32_t pw = c.par[i][k2];
