@@ -630,7 +630,7 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
     a = copy.copy(args)
     a.workload, a.shots, a.steps, a.warmup = workload, (shots or default_shots(workload)), steps, 1
     osdw = workload in ("bb288", "global144")
-    streaming = osdw and not args.no_stream
+    streaming = (osdw or workload == "gdg") and not args.no_stream
     t_setup = time.perf_counter()
     if workload == "bp4":
         eng = Bp4Engine(a, rank, local_rank, 0, a.shots)
@@ -742,10 +742,10 @@ def main():
     wl = WORKLOADS[args.workload]
     headline = args.workload == "headline"
     osdw = args.workload in ("headline", "bb288", "global144")
-    # the two-lane stream is the step mode where overlapping consecutive launches pays (the osd_window workloads: the next launch's grid
-    # fills the tail of the previous one); the guessing decoders' launches keep the device busy to their end and lose 3-5 % when two
-    # of them share it (gdg 1.17 against 1.20 M windows/s, 64 hypotheses 0.57 against 0.60 M), so their steps run one launch at a time
-    streaming = not args.no_stream and osdw and not STUB
+    # the two-lane stream is the step mode where overlapping consecutive launches pays: the osd_window workloads and gdg() -- the next
+    # launch's grid fills the tail of the previous one, and a stream's gdg() batches take the serial tree walk (1.19 -> 1.56 M windows/s,
+    # round 6).  The threaded ensemble's launches keep the device busy to their end (0.59 M either way): one launch at a time.
+    streaming = not args.no_stream and (osdw or args.workload == "gdg" or os.environ.get("SWD_BENCH_STREAM_ALL") == "1") and not STUB
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)

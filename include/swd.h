@@ -111,7 +111,9 @@ int swd_osdw_get_timing(swd_osdw *d, double *total_ms, int64_t *launches);
  * bp_guessing_decoder.pyx:7-9, 162-171, 475-478.  stats words for these decoders:
  *   [0] exit class | SWD_STATUS_CONVERGE (property `converge`), [1] BP iterations in total,
  *   [2] pre-processing iterations, [3] iterations inside decimation steps, [4] snapshots pushed,
- *   [5] BP blocks run, [6] min_converge_depth, [7] 0.                                           */
+ *   [5] BP blocks run, [6] min_converge_depth, [7] scheduling diagnostic, not part of the result:
+ *   snapshots of the main branch that ran as work items (0 whenever the launch took the serial
+ *   tree walk: large batches, batches of a stream object, posterior history requested).          */
 typedef struct swd_gdg_params {
     int32_t max_iter;            /* pre-processing BP iterations (default 50; 8 in the notebooks) */
     double ms_scaling_factor;

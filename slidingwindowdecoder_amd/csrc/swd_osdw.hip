@@ -233,7 +233,14 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // guessing decoders: the parallel form (side branches as work items) shortens the critical path of a batch that
     // cannot fill the device with whole shots; large batches keep the serial walk (no speculation, no queue traffic)
     static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 4608; // measured, [[144]] GDG windows (parallel vs serial): 4096 shots 37.5 vs 47 ms, 4608 shots 47.3 vs 47.2, 5120 shots 51.3 vs 47.9, 8192 shots 76.6 vs 54.9 (round 2, before the serial form got faster: 6144)
-    const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots && a.B < SWD_GDG_ITEM_MAX_SHOTS;
+    const int stream_serial_min = getenv("SWD_GDG_STREAM_SERIAL_MIN") ? atoi(getenv("SWD_GDG_STREAM_SERIAL_MIN")) : 3072; // (read per launch: the tests switch it)
+    // ... and so do the batches of a stream object from 3072 shots (round 6): the work-item form shortens ONE launch's critical path at the price of
+    // queue traffic and idle polling; with two batches in flight the next launch's grid fills the tail the serial walk leaves --
+    // [[144]] GDG windows, 4096 shots per batch: 1.19 M windows/s one launch at a time (work items), 1.21 M streamed with work items,
+    // 1.56 M streamed with the serial walk; streamed, serial against work items: 1024 shots 14.6 / 12.4 ms per batch, 2048 26.1 / 21.9,
+    // 3072 25.3 / 29.6, 4096 28.9 / 37.3 (profiles/r06_gdg_stream.log)
+    const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots && a.B < SWD_GDG_ITEM_MAX_SHOTS &&
+                     !(d->stream_push && a.B >= stream_serial_min);
     // osd_window: when the posterior history is only consumed as its slot-order sum (no history in or out, both
     // iteration caps multiples of four) the kernel that accumulates the sum in registers runs: no 4 x n ring in HBM
     const bool acc = d->kind == 0 && d->variant->launch_acc && !a.hist && !a.P.record_all && !a.P.hist_is_state && !a.P.zero_hist &&
@@ -670,9 +677,11 @@ static int stream_push(HostStream *hs, int B, const uint8_t *det) {
     const uint32_t *fault = nullptr; // this launch's own fault word (launch(): sched[B + 1] of its launch slot)
     {
         std::lock_guard<std::recursive_mutex> lkp(d->mu);
+        d->stream_push = true;
         int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, (const uint8_t *)dv, 0, (uint8_t *)(dv + l.o_total), 0,
                                          stats ? (int32_t *)(dv + l.o_stats) : nullptr, stats ? (double *)(dv + l.o_pm) : nullptr,
                                          (int32_t *)(dv + l.o_shot), l.st);
+        d->stream_push = false;
         if (rc) return rc;
         fault = d->cur->sched.as<uint32_t>() + B + 1;
         // the fault word of THIS launch (batches in flight on the other lane have their own).  The copy reads the launch slot, so it
@@ -844,7 +853,13 @@ extern "C" int swd_pipeline_stream_push_dev(swd_stream *s, int32_t B, const uint
         SWD_HIP(hipEventRecord(l.ready, (hipStream_t)after));
         SWD_HIP(hipStreamWaitEvent(l.st, l.ready, 0));
     }
-    int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, det, det_stride, total, total_stride, stats, min_pm, shot_result, l.st);
+    int rc;
+    {
+        std::lock_guard<std::recursive_mutex> lkp(d->mu);
+        d->stream_push = true;
+        rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, det, det_stride, total, total_stride, stats, min_pm, shot_result, l.st);
+        d->stream_push = false;
+    }
     if (rc) return rc;
     SWD_HIP(hipEventRecord(l.done, l.st));
     hs->npush++; hs->npop++; // (nothing to pop: the results are the caller's device buffers)

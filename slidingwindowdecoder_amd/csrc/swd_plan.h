@@ -95,6 +95,7 @@ struct Plan {
     swd_gdg_params gp{};
     int kind = 0;           // 0 osd_window, 1 bpgdg, 2 bpgd, 3 bp_history
     bool gdg_parallel = false; // bpgdg: side branches of the decimation tree run as work items on the persistent grid
+    bool stream_push = false;  // (under mu) the launch being prepared comes from a stream object: another batch follows or is in flight
     int new_n_max = 0;
     int max_guess = 0;
     int64_t snap_stride = 0;

@@ -104,6 +104,50 @@ def test_gdg_pipeline_more_shots_than_workgroups():
         assert bad.size == 0, f"serial={serial}: {bad.size} shots differ: {bad[:8]}"
 
 
+@pytest.mark.parametrize("serial_min", [1, None])
+def test_gdg_stream_batches_take_the_serial_walk_and_equal_the_recorded_run(serial_min, monkeypatch):
+    """Batches of 3072 shots or more pushed through a stream object run the serial tree walk (the next batch's grid fills the tail;
+    swd_osdw.hip launch()) -- here with the threshold at 1 shot and at its default: host-buffer stream with ragged batches,
+    device-buffer stream with alternating lanes, and a decode() call large enough to be cut in two halves on the lanes -- every shot
+    gets the reference's recorded result, and the per-window statistics equal the one-launch (work-item) form's."""
+    if serial_min is not None:
+        monkeypatch.setenv("SWD_GDG_STREAM_SERIAL_MIN", str(serial_min))
+    import torch
+    import slidingwindowdecoder_amd as S
+    from tests.test_gpu_pipeline import load_plan
+    f = fx.load("bb144_circuit_p003_w3f1.npz")
+    plan = load_plan(f, 11)
+    kw = fx.params(f, "gdg_params")
+    kw.pop("multi_thread")
+    det = fx.unpack(f["det"], plan.chk.shape[0])
+    want = fx.unpack(f["gdg_total"], plan.chk.shape[1])
+    dec = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", **kw)
+    assert np.array_equal(dec.decode(det), want)
+    st0, pm0, fl0, fg0 = dec.last_stats[..., :7].copy(), dec.last_min_pm.copy(), dec.last_obs_flips.copy(), dec.last_flagged.copy()
+    cuts = [0, 50, 51, 120, 192]  # (statistics word 7 is a scheduling diagnostic of the work-item form: include/swd.h)
+    got = list(dec.decode_stream([det[a:b] for a, b in zip(cuts[:-1], cuts[1:])]))
+    for (a, b), (tot, st, pm, flips, flagged) in zip(zip(cuts[:-1], cuts[1:]), got):
+        assert np.array_equal(tot, want[a:b]) and np.array_equal(st[..., :7], st0[a:b]) and np.array_equal(pm, pm0[a:b])
+        assert np.array_equal(flips, fl0[a:b]) and np.array_equal(flagged, fg0[a:b])  # (a guessing decoder may leave a window unsolved)
+    reps = 11  # 2112 shots: decode() cuts the call in two halves on the lanes
+    assert np.array_equal(dec.decode(np.tile(det, (reps, 1))), np.tile(want, (reps, 1)))
+    assert np.array_equal(dec.last_stats[..., :7], np.tile(st0, (reps, 1, 1)))
+    dev = torch.device("cuda", 0)
+    nrep = 3 if serial_min else 17  # (default threshold: 3264 shots per batch, the serial walk by the product's own rule)
+    d_t = torch.from_numpy(np.tile(det, (nrep, 1))).to(dev)
+    ncol = plan.chk.shape[1]
+    outs = [dict(total=torch.empty((len(d_t), ncol), dtype=torch.uint8, device=dev), stats=torch.empty((len(d_t), 11, 8), dtype=torch.int32, device=dev))
+            for _ in range(2)]
+    s = dec.stream(len(d_t))
+    for i in range(4):
+        s.push_device(d_t, **outs[i % 2])
+    s.wait()
+    for o in outs:
+        assert np.array_equal(o["total"].cpu().numpy(), np.tile(want, (nrep, 1))) and np.array_equal(o["stats"].cpu().numpy()[..., :7], np.tile(st0, (nrep, 1, 1)))
+    dec.check_status()
+    s.close()
+
+
 @pytest.mark.parametrize("tag", ["d4s20", "d3s10"])
 def test_bb288_gdg_windows_and_pipeline(tag):
     """The reference's [[288,12,18]] guessing-decoder run (`Sliding Window GDG.ipynb` cell 8, guessing.py:160-197 with N = 288:
