@@ -889,7 +889,9 @@ def main():
         #  eleven windows, not by the device -- BASELINE configs[2] names no batch size)
         for w, sh in (("bb288", None), ("gdg", None), ("gdg", 16384), ("gdg64", None), ("gdg64", 16384), ("global144", None), ("bp4", None)):
             try:  # a failing side workload must not lose the headline record
-                cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank, steps=5 if sh is None else 2, shots=sh))
+                # (streamed workloads: the last step's tail is not overlapped by a next step -- enough steps to amortise it)
+                k = (20 if w == "gdg" else 5) if sh is None else (6 if w == "gdg" else 2)
+                cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank, steps=k, shots=sh))
             except Exception as e:  # noqa: BLE001
                 cfg["other_workloads"].append({"workload": w, "error": f"{type(e).__name__}: {e}"[:500]})
             torch.cuda.empty_cache()
