@@ -345,9 +345,12 @@ class GpuEngine:
 
 
 class Bp4Engine:
-    """bp4_osd on device-resident syndromes (one launch per step); decisions = exit word + iteration count per shot."""
+    """bp4_osd on device-resident syndromes (one launch per step); decisions = exit word + iteration count per shot.
+    streaming: consecutive steps alternate between two HIP streams (swd_bp4_decode_batch_dev takes the stream; the handle's launch
+    slots keep the launches' scratch apart) and two sets of output buffers -- a launch ends on the few decodes that run all
+    max_iter iterations (0.9 ms of a 1.8 ms launch with one workgroup busy), the next launch's grid fills that tail."""
 
-    def __init__(self, args, rank, local_rank, lo, hi):
+    def __init__(self, args, rank, local_rank, lo, hi, streaming=False):
         import torch
         from slidingwindowdecoder_amd import bp4_osd
         from slidingwindowdecoder_amd.codes import bb_code
@@ -368,16 +371,35 @@ class Bp4Engine:
             ex, ez = ((pauli == 1) | (pauli == 2)).astype(np.uint8), ((pauli == 3) | (pauli == 2)).astype(np.uint8)
             self.sx.append(torch.from_numpy(np.ascontiguousarray((ez @ code.hx.T % 2).astype(np.uint8))).to(self.dev))
             self.sz.append(torch.from_numpy(np.ascontiguousarray((ex @ code.hz.T % 2).astype(np.uint8))).to(self.dev))
-        self.out = torch.empty((shots, 2, n), dtype=torch.uint8, device=self.dev)
-        self.stats = torch.empty((shots, 8), dtype=torch.int32, device=self.dev)
-        self.shot = self.stats[:, :2]
+        self.streaming = streaming
+        self.outs = [torch.empty((shots, 2, n), dtype=torch.uint8, device=self.dev) for _ in range(2 if streaming else 1)]
+        self.stat = [torch.empty((shots, 8), dtype=torch.int32, device=self.dev) for _ in range(2 if streaming else 1)]
+        self.lanes = [torch.cuda.Stream(self.dev) for _ in range(2)] if streaming else None
+        self.nstep = self.last = 0
         self.timing, self.events = False, []
 
+    @property
+    def stats(self):  # of the most recent step
+        return self.stat[self.last]
+
+    @property
+    def shot(self):
+        return self.stat[self.last][:, :2]
+
     def step(self, i):
+        if self.streaming and not self.timing:
+            self.last = self.nstep & 1
+            self.nstep += 1
+            lane = self.lanes[self.last]
+            if self.nstep <= 2:  # the syndromes were produced on the current stream
+                lane.wait_stream(self.torch.cuda.current_stream(self.dev))
+            self.dec.decode_batch_device(self.sx[i % self.nb], self.sz[i % self.nb], out=self.outs[self.last], stats=self.stat[self.last], stream=lane)
+            return
+        self.last = 0
         if self.timing:  # HIP events on the launch stream (torch's current stream is the stream the kernel is launched on)
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.dec.decode_batch_device(self.sx[i % self.nb], self.sz[i % self.nb], out=self.out, stats=self.stats)
+        self.dec.decode_batch_device(self.sx[i % self.nb], self.sz[i % self.nb], out=self.outs[0], stats=self.stat[0])
         if self.timing:
             e1.record()
             self.events.append((e0, e1))
@@ -396,7 +418,10 @@ class Bp4Engine:
         pass
 
     def finish(self):
-        pass
+        """the current torch stream waits for both lanes (the gather of the decisions follows on it)"""
+        if self.streaming:
+            for lane in self.lanes:
+                self.torch.cuda.current_stream(self.dev).wait_stream(lane)
 
     def kernel_timing(self, i0, k):
         self.sync()
@@ -630,10 +655,10 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
     a = copy.copy(args)
     a.workload, a.shots, a.steps, a.warmup = workload, (shots or default_shots(workload)), steps, 1
     osdw = workload in ("bb288", "global144")
-    streaming = (osdw or workload == "gdg") and not args.no_stream
+    streaming = (osdw or workload in ("gdg", "bp4")) and not args.no_stream
     t_setup = time.perf_counter()
     if workload == "bp4":
-        eng = Bp4Engine(a, rank, local_rank, 0, a.shots)
+        eng = Bp4Engine(a, rank, local_rank, 0, a.shots, streaming=streaming)
     else:
         plan = build_problem(**wl["problem"])
         eng = GpuEngine(a, rank, local_rank, 0, a.shots, plan, args.osd_order, workload, streaming=streaming)
@@ -745,7 +770,8 @@ def main():
     # the two-lane stream is the step mode where overlapping consecutive launches pays: the osd_window workloads and gdg() -- the next
     # launch's grid fills the tail of the previous one, and a stream's gdg() batches take the serial tree walk (1.19 -> 1.56 M windows/s,
     # round 6).  The threaded ensemble's launches keep the device busy to their end (0.59 M either way): one launch at a time.
-    streaming = not args.no_stream and (osdw or args.workload == "gdg" or os.environ.get("SWD_BENCH_STREAM_ALL") == "1") and not STUB
+    # bp4_osd: two HIP streams handed to swd_bp4_decode_batch_dev in turn (a launch ends on the few decodes that run all max_iter iterations)
+    streaming = not args.no_stream and (osdw or args.workload in ("gdg", "bp4") or os.environ.get("SWD_BENCH_STREAM_ALL") == "1") and not STUB
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)
@@ -778,7 +804,7 @@ def main():
     if STUB:
         engine = StubEngine(args, rank, lo, hi)
     elif args.workload == "bp4":
-        engine = Bp4Engine(args, rank, local_rank, lo, hi)
+        engine = Bp4Engine(args, rank, local_rank, lo, hi, streaming=streaming)
     else:
         engine = GpuEngine(args, rank, local_rank, lo, hi, plan, args.osd_order, args.workload, streaming=streaming)
     W = engine.W
@@ -836,7 +862,8 @@ def main():
         # what closed the timed region: the RCCL (backend nccl) all_gather over this many ranks, or nothing (plain one-process run)
         "collective_backend": backend, "collective_ranks": dist_ranks, "rank_times": rank_times,
         "kernel_launches_timed": int(launches),
-        "step_mode": ("two-lane stream (swd_pipeline_stream_push_dev): consecutive steps overlap" if streaming else "one launch at a time"),
+        "step_mode": (("two HIP streams in turn (swd_bp4_decode_batch_dev): consecutive steps overlap" if args.workload == "bp4" else
+                       "two-lane stream (swd_pipeline_stream_push_dev): consecutive steps overlap") if streaming else "one launch at a time"),
         "single_stream_windows_per_s": (hi - lo) * W * launches / single_wall if launches else None,
         "single_stream_note": "this rank's shots, one launch at a time with HIP events and a host synchronisation per launch (the loop that times the kernel)",
     }
