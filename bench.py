@@ -693,7 +693,7 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
     cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
     rec = {"workload": workload, "metric": wl["metric"], "value": a.shots * eng.W * steps / el, "unit": wl.get("unit", "windows/s"),
            "shots_per_step": a.shots, "steps": steps, "ms_per_step": el / steps * 1e3,
-           "step_mode": "two-lane stream" if streaming else "one launch at a time",
+           "step_mode": ("two HIP streams in turn" if workload == "bp4" else "two-lane stream") if streaming else "one launch at a time",
            "ms_per_launch": avg_s * 1e3, "launches_timed": int(n), "exit_classes": [int(x) for x in cls[:7]],
            "roofline_bound": r["bound"], "roofline_frac": r["frac"], "roofline_achieved_GBps": r["achieved"], "roofline_peak_GBps": r["peak"],
            "lds_algorithmic_frac": r.get("lds_algorithmic_frac"),
@@ -917,7 +917,7 @@ def main():
         for w, sh in (("bb288", None), ("gdg", None), ("gdg", 16384), ("gdg64", None), ("gdg64", 16384), ("global144", None), ("bp4", None)):
             try:  # a failing side workload must not lose the headline record
                 # (streamed workloads: the last step's tail is not overlapped by a next step -- enough steps to amortise it)
-                k = (20 if w == "gdg" else 5) if sh is None else (6 if w == "gdg" else 2)
+                k = (20 if w == "gdg" else 30 if w == "bp4" else 5) if sh is None else (6 if w == "gdg" else 2)
                 cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank, steps=k, shots=sh))
             except Exception as e:  # noqa: BLE001
                 cfg["other_workloads"].append({"workload": w, "error": f"{type(e).__name__}: {e}"[:500]})
