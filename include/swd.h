@@ -268,7 +268,9 @@ int swd_pipeline_decode_packed(swd_pipeline *pl, int32_t B, const uint8_t *det, 
  * /root/reference/osd.py:130-191 cut into batches, does): a stream object owns two lanes, each with its own HIP stream, launch
  * slot, device buffers and page-locked staging.  Batch k + 1 is copied in and launched while batch k still runs: its persistent
  * grid takes the workgroup slots that the tail of batch k leaves empty, and the copy-out / unpacking of batch k overlaps the
- * launch of k + 1.  Results are those of swd_pipeline_decode, batch by batch, in push order.
+ * launch of k + 1.  Results are those of swd_pipeline_decode, batch by batch, in push order.  (Guessing decoders: a stream batch of
+ * 3072 shots or more walks each decimation tree serially instead of spreading its side branches over the grid as work items --
+ * the next batch fills the tail the serial walk leaves; same results, statistics word 7 aside.)
  *   flags  SWD_STREAM_PACKED    total_e_hat is returned bit-packed (layout of swd_pipeline_decode_packed)
  *          SWD_STREAM_NO_STATS  per-window stats / min_pm are not copied back (pop takes NULL for them)
  * Host form: push(det [B*num_det]) enqueues copy-in + launch + copy-out on the next lane and returns at once; pop() waits for
