@@ -232,7 +232,7 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     int rc;
     // guessing decoders: the parallel form (side branches as work items) shortens the critical path of a batch that
     // cannot fill the device with whole shots; large batches keep the serial walk (no speculation, no queue traffic)
-    static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 4608; // measured, [[144]] GDG windows (parallel vs serial): 4096 shots 37.5 vs 47 ms, 4608 shots 47.3 vs 47.2, 5120 shots 51.3 vs 47.9, 8192 shots 76.6 vs 54.9 (round 2, before the serial form got faster: 6144)
+    static const int par_max_shots = getenv("SWD_GDG_PAR_MAX_SHOTS") ? atoi(getenv("SWD_GDG_PAR_MAX_SHOTS")) : 5120; // measured, [[144]] GDG windows (work items with 64 contexts vs serial, round 6): 4096 shots 36.9 vs 41.3 ms, 5120 shots 44.2 vs 45.2, 6144 shots 50.3 vs 47.5, 8192 shots 66.6 vs 55.9 (round 5, every context handed out: 4608)
     const int stream_serial_min = getenv("SWD_GDG_STREAM_SERIAL_MIN") ? atoi(getenv("SWD_GDG_STREAM_SERIAL_MIN")) : 3072; // (read per launch: the tests switch it)
     // ... and so do the batches of a stream object from 3072 shots (round 6): the work-item form shortens ONE launch's critical path at the price of
     // queue traffic and idle polling; with two batches in flight the next launch's grid fills the tail the serial walk leaves --

@@ -122,6 +122,7 @@ struct Plan {
         DevBuf sched, state, hist, snap, gq, gfq, gctx, gsnap, big, order;
         DevBuf gfree_tmpl;     // a full free-context ring, copied into the slot's ring per launch (per slot: a launch on another
         int gfree_n = 0;       // stream may still be copying from the template of ITS slot while this one is rebuilt)
+        int gfree_avail = -1;  // contexts the template hands out (KIND 2: depends on the batch size)
         hipEvent_t done = nullptr;
     };
     static constexpr int kSlots = 4;
@@ -445,14 +446,19 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         if (sl.gq.reserve(qbytes) || sl.gfq.reserve(fbytes) || sl.gctx.reserve((size_t)nctx * a.gdgp.ctx_stride) ||
             sl.gsnap.reserve((size_t)nctx * a.gdgp.csnap_stride))
             return -1;
-        if (sl.gfree_n != (int)nctx) { // template of the full free ring: ids 0..nctx-1 in order
-            std::vector<uint64_t> tmpl(2 + nctx);
-            const unsigned navail = getenv("SWD_GDG_NCTX") ? std::min<unsigned>(nctx, (unsigned)atoi(getenv("SWD_GDG_NCTX"))) : nctx; // diagnostics
+        // Contexts handed out at a time: every one of them up to 3072 shots; 64 beyond -- a batch that fills the grid with units for
+        // most of the launch walks most trees serially (no speculative branches, no queue traffic) and spreads only a few at a time
+        // (measured, [[144]] GDG windows, ms per launch with 16 / 64 / 256 / all contexts: 256 shots 10.7 / 9.2 / 8.0 / 8.1, 1024 shots
+        // 16.2 / 15.0 / 14.0 / 13.4, 2048 shots 25.1 / 24.0 / 24.0 / 22.9, 4096 shots 36.5 / 36.5 / 37.3 / 38.7; profiles/r06_gdg_stream.log)
+        const unsigned navail = getenv("SWD_GDG_NCTX") ? std::min<unsigned>(nctx, (unsigned)atoi(getenv("SWD_GDG_NCTX"))) : (a.B > 3072 ? std::min(nctx, 64u) : nctx);
+        if (sl.gfree_n != (int)nctx || sl.gfree_avail != (int)navail) { // template of the free ring: ids 0..navail-1 in order
+            std::vector<uint64_t> tmpl(2 + nctx, 0);
             tmpl[0] = (uint64_t)navail << 32; tmpl[1] = 0; // head 0, tail = contexts available
-            for (unsigned t = 0; t < nctx; ++t) tmpl[2 + t] = ((uint64_t)(t + 1) << 32) | t;
+            for (unsigned t = 0; t < navail; ++t) tmpl[2 + t] = ((uint64_t)(t + 1) << 32) | t;
             if (sl.gfree_tmpl.reserve(fbytes)) return -1;
+            if (sl.done) SWD_HIP(hipEventSynchronize(sl.done)); // (the slot's previous launch may still be copying from the template)
             SWD_HIP(hipMemcpy(sl.gfree_tmpl.p, tmpl.data(), fbytes, hipMemcpyHostToDevice));
-            sl.gfree_n = (int)nctx;
+            sl.gfree_n = (int)nctx; sl.gfree_avail = (int)navail;
         }
         a.gdgp.q = sl.gq.as<uint32_t>(); a.gdgp.qmask = cap - 1;
         a.gdgp.fq = sl.gfq.as<uint32_t>(); a.gdgp.fmask = nctx - 1;
