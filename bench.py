@@ -323,7 +323,8 @@ class GpuEngine:
         kernel duration the roofline and the committed rocprof profile describe -> (total ms, launches, wall seconds)"""
         o = self.out[0]
         self.sync()
-        self.dec.decode_device(self.dets[i0 % self.nb], min_pm=None, **o)
+        for _ in range(4):  # one untimed launch per launch slot of the handle: a form the streamed steps did not use allocates its scratch now
+            self.dec.decode_device(self.dets[i0 % self.nb], min_pm=None, **o)
         self.sync()
         self.dec.set_timing(True)
         t0 = time.perf_counter()
@@ -655,7 +656,7 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
     a = copy.copy(args)
     a.workload, a.shots, a.steps, a.warmup = workload, (shots or default_shots(workload)), steps, 1
     osdw = workload in ("bb288", "global144")
-    streaming = (osdw or workload in ("gdg", "bp4")) and not args.no_stream
+    streaming = not args.no_stream
     t_setup = time.perf_counter()
     if workload == "bp4":
         eng = Bp4Engine(a, rank, local_rank, 0, a.shots, streaming=streaming)
@@ -769,9 +770,9 @@ def main():
     osdw = args.workload in ("headline", "bb288", "global144")
     # the two-lane stream is the step mode where overlapping consecutive launches pays: the osd_window workloads and gdg() -- the next
     # launch's grid fills the tail of the previous one, and a stream's gdg() batches take the serial tree walk (1.19 -> 1.56 M windows/s,
-    # round 6).  The threaded ensemble's launches keep the device busy to their end (0.59 M either way): one launch at a time.
+    # round 6) and so do the threaded ensemble's (tickets instead of the work-item ring: +3-6 % at 4096 shots, +9 % at 16 384).
     # bp4_osd: two HIP streams handed to swd_bp4_decode_batch_dev in turn (a launch ends on the few decodes that run all max_iter iterations)
-    streaming = not args.no_stream and (osdw or args.workload in ("gdg", "bp4") or os.environ.get("SWD_BENCH_STREAM_ALL") == "1") and not STUB
+    streaming = not args.no_stream and not STUB
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
         cpu = cpu_baseline(args.osd_order)  # before the GPU is touched (spawned workers)

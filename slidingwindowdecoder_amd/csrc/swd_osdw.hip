@@ -239,8 +239,9 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // [[144]] GDG windows, 4096 shots per batch: 1.19 M windows/s one launch at a time (work items), 1.21 M streamed with work items,
     // 1.56 M streamed with the serial walk; streamed, serial against work items: 1024 shots 14.6 / 12.4 ms per batch, 2048 26.1 / 21.9,
     // 3072 25.3 / 29.6, 4096 28.9 / 37.3 (profiles/r06_gdg_stream.log)
+    d->stream_serial = d->stream_push && a.B >= stream_serial_min; // (the threaded ensemble's launcher reads it too: swd_plan.h, KIND 7)
     const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots && a.B < SWD_GDG_ITEM_MAX_SHOTS &&
-                     !(d->stream_push && a.B >= stream_serial_min);
+                     !d->stream_serial;
     // osd_window: when the posterior history is only consumed as its slot-order sum (no history in or out, both
     // iteration caps multiples of four) the kernel that accumulates the sum in registers runs: no 4 x n ring in HBM
     const bool acc = d->kind == 0 && d->variant->launch_acc && !a.hist && !a.P.record_all && !a.P.hist_is_state && !a.P.zero_hist &&

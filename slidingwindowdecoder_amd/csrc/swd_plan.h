@@ -96,6 +96,7 @@ struct Plan {
     int kind = 0;           // 0 osd_window, 1 bpgdg, 2 bpgd, 3 bp_history
     bool gdg_parallel = false; // bpgdg: side branches of the decimation tree run as work items on the persistent grid
     bool stream_push = false;  // (under mu) the launch being prepared comes from a stream object: another batch follows or is in flight
+    bool stream_serial = false; // (under mu) ... and is large enough for the guessing decoders' ticket-scheduled forms (launch())
     int new_n_max = 0;
     int max_guess = 0;
     int64_t snap_stride = 0;
@@ -376,7 +377,10 @@ int launch_nt(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
         // vector; its fork records (masks + message cells, 2^(D-1) of them) in the csnap area.
         // (large-graph form: window-major tickets, every thread body on the unit's workgroup)
         const int Dp = d->gp.max_tree_depth, NS = std::max(d->gp.max_side_depth - d->gp.max_tree_depth, 0);
-        if (!BIG && a.W > 1 && a.B < SWD_GDG_ITEM_MAX_SHOTS && a.W <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_ENS_TICKETS")) {
+        // (a stream object's batches of 3072 shots or more: tickets, every thread body on the unit's workgroup -- the ring's workgroups poll
+        // until the launch ends, the ticket-scheduled ones leave their slots to the next batch: 64 hypotheses, 4096 shots per batch 77.9 ->
+        // 75.7 ms per step, 16 384 shots 0.62 -> 0.68 M windows/s; one launch at a time the ring wins, 80 against 119 ms)
+        if (!BIG && a.W > 1 && a.B < SWD_GDG_ITEM_MAX_SHOTS && a.W <= SWD_GDG_ITEM_MAX_WINDOWS && !getenv("SWD_ENS_TICKETS") && !d->stream_serial) {
             a.slot_scratch = 1;
             const bool tasks = Dp >= 1 && !getenv("SWD_ENS_NO_TASKS");
             unsigned nctx = 64;

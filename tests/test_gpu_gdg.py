@@ -547,6 +547,14 @@ def test_threaded_ensemble_pipeline_work_items_vs_oracle(D, S_, monkeypatch):
         assert np.array_equal(other[0], total), name
         assert np.array_equal(other[1], st), name
         assert np.array_equal(other[2], pm), name
+    # batches of a stream object take the ticket schedule from 3072 shots (here: from one shot): the same records again
+    monkeypatch.setenv("SWD_GDG_STREAM_SERIAL_MIN", "1")
+    dec = S.SlidingWindowDecoder(plan, decoder="bpgdg_decoder", multi_thread=True, **kw)
+    cuts = [0, 40, 41, B]
+    for (a0, b0), (tot_s, st_s, pm_s, _, _) in zip(zip(cuts[:-1], cuts[1:]), dec.decode_stream([det[a:b] for a, b in zip(cuts[:-1], cuts[1:])])):
+        assert np.array_equal(tot_s, total[a0:b0]) and np.array_equal(st_s, st[a0:b0]) and np.array_equal(pm_s, pm[a0:b0])
+    dec.check_status()
+    monkeypatch.delenv("SWD_GDG_STREAM_SERIAL_MIN")
     # more shots than workgroups and contexts to spare: the same shots tiled and shuffled, every copy the same record
     reps = 28
     perm = np.random.default_rng(D).permutation(B * reps)
