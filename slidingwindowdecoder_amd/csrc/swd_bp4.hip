@@ -32,6 +32,8 @@ struct Bp4 {
     static constexpr int kSlots = 4;
     LaunchSlot slot[kSlots];
     int next_slot = 0;
+    hipEvent_t last_done = nullptr; // (under mu) end of the most recent decode launch and the stream it ran on
+    hipStream_t last_stream = nullptr;
     std::mutex mu;
     ~Bp4() { for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done); }
     // the next slot, ordered behind its previous launch on `st` (call under mu)
@@ -250,8 +252,13 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
         // around a median of 10, spread over ranks 0.07-0.89 of the order: profiles/r06_bp4_heavy.log), so the order does not move the tail of
         // a launch; it still pays where the iteration count follows the weight -- SHYPS r = 3 18.8 -> 24.9 M decodes/s, [[72]] 40.0 -> 45.9,
         // [[144]] 35.1 -> 36.2; [[288]] .. [[756]] lose 2-3 % to the two small kernels (profiles/r06_bp4_order.log).  SWD_BP4_NO_ORDER: off
+        // ... and not when another launch of this handle is still running on a DIFFERENT stream (a caller that keeps two launches in
+        // flight): whatever tail this launch has, the other launch's grid fills it, and the two small kernels are 6 % of a step
+        // ([[144]], two streams in turn: 55.4 -> 58.7 M decodes/s without them)
         static const bool by_weight = getenv("SWD_BP4_NO_ORDER") == nullptr;
-        if (by_weight) {
+        static const bool always = getenv("SWD_BP4_ORDER_ALWAYS") != nullptr;
+        const bool overlapped = !always && d->last_done && d->last_stream != st && hipEventQuery(d->last_done) == hipErrorNotReady;
+        if (by_weight && !overlapped) {
             uint32_t *wt = sl->osd_q.as<uint32_t>() + 4 + B, *ord = wt + B;
             hipLaunchKernelGGL(bp4_weight_kernel, dim3((B + 3) / 4), dim3(256), 0, st, sx, sz, d->gx.m, d->gz.m, B, wt);
             hipLaunchKernelGGL((shot_order_kernel<1024>), dim3(1), dim3(1024), 0, st, (const uint32_t *)wt, B, ord);
@@ -261,6 +268,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     }
     if (bp4_dispatch(d, a, st)) return -1;
     SWD_HIP(hipEventRecord(sl->done, st));
+    d->last_done = sl->done; d->last_stream = st;
     return 0;
 }
 
