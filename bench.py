@@ -375,7 +375,8 @@ class Bp4Engine:
         self.streaming = streaming
         self.outs = [torch.empty((shots, 2, n), dtype=torch.uint8, device=self.dev) for _ in range(2 if streaming else 1)]
         self.stat = [torch.empty((shots, 8), dtype=torch.int32, device=self.dev) for _ in range(2 if streaming else 1)]
-        self.lanes = [torch.cuda.Stream(self.dev) for _ in range(2)] if streaming else None
+        # (the second stream at high priority: streams of one priority may share a hardware queue, and then nothing overlaps -- swd_osdw.hip)
+        self.lanes = [torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev, priority=-1)] if streaming else None
         self.nstep = self.last = 0
         self.timing, self.events = False, []
 
@@ -918,7 +919,7 @@ def main():
         for w, sh in (("bb288", None), ("gdg", None), ("gdg", 16384), ("gdg64", None), ("gdg64", 16384), ("global144", None), ("bp4", None)):
             try:  # a failing side workload must not lose the headline record
                 # (streamed workloads: the last step's tail is not overlapped by a next step -- enough steps to amortise it)
-                k = (20 if w == "gdg" else 30 if w == "bp4" else 5) if sh is None else (6 if w == "gdg" else 2)
+                k = {"gdg": 20, "bp4": 30, "global144": 10}.get(w, 5) if sh is None else (6 if w == "gdg" else 2)
                 cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank, steps=k, shots=sh))
             except Exception as e:  # noqa: BLE001
                 cfg["other_workloads"].append({"workload": w, "error": f"{type(e).__name__}: {e}"[:500]})

@@ -636,8 +636,18 @@ static int stream_alloc_lane(HostStream *hs, StreamLane &l) {
     return 0;
 }
 
-static int stream_lane_init(StreamLane &l) {
-    if (!l.st) SWD_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+// The second lane is a high-priority stream: the runtime deals streams of ONE priority onto a few hardware queues per device and lets
+// later streams share them (GPU_MAX_HW_QUEUES, default 4; which queue a stream shares is not ours to choose), and two lanes on one
+// queue run their launches back to back -- seen with pairs of plain streams (scripts/hwq_probe.py: 1.83 instead of 1.12 ms per step).
+// Queues are pooled per priority, so lanes of different priority never share one.  The lanes' launches are persistent grids that
+// take the slots the other launch leaves free either way; the priority only decides which of them gets a freed slot first.
+static int stream_lane_init(StreamLane &l, bool high_priority) {
+    if (!l.st) {
+        int least = 0, greatest = 0;
+        if (high_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least && !getenv("SWD_STREAM_SAME_PRIORITY"))
+            SWD_HIP(hipStreamCreateWithPriority(&l.st, hipStreamNonBlocking, greatest));
+        else SWD_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    }
     if (!l.done) SWD_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
     if (!l.ready) SWD_HIP(hipEventCreateWithFlags(&l.ready, hipEventDisableTiming));
     return 0;
@@ -649,8 +659,8 @@ static HostStream *stream_new(Plan *d, int max_shots, int flags) {
     if (hipSetDevice(d->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", d->device); return nullptr; }
     HostStream *hs = new HostStream();
     hs->plan = d; hs->max_shots = max_shots; hs->flags = flags; hs->device = d->device;
-    for (auto &l : hs->lane)
-        if (stream_lane_init(l)) { delete hs; return nullptr; }
+    for (int i = 0; i < 2; ++i)
+        if (stream_lane_init(hs->lane[i], i == 1)) { delete hs; return nullptr; }
     return hs;
 }
 
