@@ -688,7 +688,7 @@ static int stream_push(HostStream *hs, int B, const uint8_t *det) {
     const uint32_t *fault = nullptr; // this launch's own fault word (launch(): sched[B + 1] of its launch slot)
     {
         std::lock_guard<std::recursive_mutex> lkp(d->mu);
-        d->stream_push = true;
+        d->stream_push = hs->overlapping; // (a synchronous host call in one part has nothing in flight beside it)
         int rc = swd_pipeline_decode_dev((swd_pipeline *)d, B, (const uint8_t *)dv, 0, (uint8_t *)(dv + l.o_total), 0,
                                          stats ? (int32_t *)(dv + l.o_stats) : nullptr, stats ? (double *)(dv + l.o_pm) : nullptr,
                                          (int32_t *)(dv + l.o_shot), l.st);
@@ -771,6 +771,7 @@ static int pipeline_decode_host(Plan *d, int32_t B, const uint8_t *det, uint8_t 
         d->hstream->owned_by_plan = true;
     }
     HostStream *hs = d->hstream.get();
+    hs->overlapping = parts > 1;
     while (hs->npop < hs->npush) (void)stream_pop(hs, nullptr, nullptr, nullptr, nullptr, 0); // (a failed earlier call left batches behind)
     const size_t W = d->wins.size(), row_bytes = ((size_t)d->num_col + 7) / 8;
     auto push = [&](int k) { const int lo = k * per, n = std::min(per, B - lo); return n > 0 ? stream_push(hs, n, det + (size_t)lo * d->num_det) : 0; };

@@ -47,6 +47,7 @@ struct HostStream {
     int max_shots = 0, flags = 0;
     int device = 0;          // the plan's device, kept here so that a stream detached from its pipeline still frees its lanes on it
     StreamLane lane[2];
+    bool overlapping = true; // batches of this object overlap (false: the plan's own object while it serves a host call in ONE part)
     long long npush = 0, npop = 0;
     bool owned_by_plan = false;
     std::mutex mu;
