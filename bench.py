@@ -919,7 +919,7 @@ def main():
         for w, sh in (("bb288", None), ("gdg", None), ("gdg", 16384), ("gdg64", None), ("gdg64", 16384), ("global144", None), ("bp4", None)):
             try:  # a failing side workload must not lose the headline record
                 # (streamed workloads: the last step's tail is not overlapped by a next step -- enough steps to amortise it)
-                k = {"gdg": 20, "bp4": 30, "global144": 10}.get(w, 5) if sh is None else (6 if w == "gdg" else 2)
+                k = {"gdg": 20, "gdg64": 12, "bp4": 30, "global144": 10}.get(w, 5) if sh is None else (6 if w == "gdg" else 3 if w == "gdg64" else 2)
                 cfg["other_workloads"].append(measure_other_workload(w, args, rank, local_rank, steps=k, shots=sh))
             except Exception as e:  # noqa: BLE001
                 cfg["other_workloads"].append({"workload": w, "error": f"{type(e).__name__}: {e}"[:500]})
