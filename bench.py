@@ -705,6 +705,9 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
            "profile_stale": r.get("profile_stale"), "setup_s": t_setup}
     if note:
         rec["roofline_frac_note"] = note
+    if shots is not None and shots != default_shots(workload):  # (the committed profile describes launches of the default batch size)
+        rec["profile_stale"] = None
+        rec["profile_note"] = "counters profiled at the workload's default batch size; the launch time of this batch size is not comparable"
     rec.update(extra)
     return rec
 
