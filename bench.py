@@ -347,9 +347,9 @@ class GpuEngine:
 
 class Bp4Engine:
     """bp4_osd on device-resident syndromes (one launch per step); decisions = exit word + iteration count per shot.
-    streaming: consecutive steps alternate between two HIP streams (swd_bp4_decode_batch_dev takes the stream; the handle's launch
-    slots keep the launches' scratch apart) and two sets of output buffers -- a launch ends on the few decodes that run all
-    max_iter iterations (0.9 ms of a 1.8 ms launch with one workgroup busy), the next launch's grid fills that tail."""
+    streaming: consecutive steps go round four HIP streams (swd_bp4_decode_batch_dev takes the stream; the handle's four launch
+    slots keep the launches' scratch apart) and four sets of output buffers -- a launch ends on the few decodes that run all
+    max_iter iterations (0.9 ms of a 1.8 ms launch with one workgroup busy), the other launches' grids fill that tail."""
 
     def __init__(self, args, rank, local_rank, lo, hi, streaming=False):
         import torch
@@ -373,10 +373,13 @@ class Bp4Engine:
             self.sx.append(torch.from_numpy(np.ascontiguousarray((ez @ code.hx.T % 2).astype(np.uint8))).to(self.dev))
             self.sz.append(torch.from_numpy(np.ascontiguousarray((ex @ code.hz.T % 2).astype(np.uint8))).to(self.dev))
         self.streaming = streaming
-        self.outs = [torch.empty((shots, 2, n), dtype=torch.uint8, device=self.dev) for _ in range(2 if streaming else 1)]
-        self.stat = [torch.empty((shots, 8), dtype=torch.int32, device=self.dev) for _ in range(2 if streaming else 1)]
-        # (the second stream at high priority: streams of one priority may share a hardware queue, and then nothing overlaps -- swd_osdw.hip)
-        self.lanes = [torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev, priority=-1)] if streaming else None
+        # four launches in flight: the handle has four launch slots, and a launch of 65 536 decodes ends on decodes that take as long as
+        # its whole body ([[144]]: 1 / 2 / 3 / 4 launches in flight 35 / 66 / 70 / 73 M decodes/s, scripts/bp4_lanes.py)
+        self.nl = 4 if streaming else 1
+        self.outs = [torch.empty((shots, 2, n), dtype=torch.uint8, device=self.dev) for _ in range(self.nl)]
+        self.stat = [torch.empty((shots, 8), dtype=torch.int32, device=self.dev) for _ in range(self.nl)]
+        # (streams of both priorities: streams of one priority may share a hardware queue, and those that do run back to back -- swd_osdw.hip)
+        self.lanes = [torch.cuda.Stream(self.dev, priority=-(i & 1)) for i in range(self.nl)] if streaming else None
         self.nstep = self.last = 0
         self.timing, self.events = False, []
 
@@ -390,10 +393,10 @@ class Bp4Engine:
 
     def step(self, i):
         if self.streaming and not self.timing:
-            self.last = self.nstep & 1
+            self.last = self.nstep % self.nl
             self.nstep += 1
             lane = self.lanes[self.last]
-            if self.nstep <= 2:  # the syndromes were produced on the current stream
+            if self.nstep <= self.nl:  # the syndromes were produced on the current stream
                 lane.wait_stream(self.torch.cuda.current_stream(self.dev))
             self.dec.decode_batch_device(self.sx[i % self.nb], self.sz[i % self.nb], out=self.outs[self.last], stats=self.stat[self.last], stream=lane)
             return
@@ -428,6 +431,10 @@ class Bp4Engine:
     def kernel_timing(self, i0, k):
         self.sync()
         self.set_timing(True)
+        for i in range(4):  # untimed: the single-launch form (start-order kernels, one stream) settles after the streamed steps
+            self.step(i0 + i)
+        self.sync()
+        self.events = []
         t0 = time.perf_counter()
         for i in range(k):
             self.step(i0 + i)
@@ -695,7 +702,7 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
     cls = np.bincount((st[..., 0] & 0xFF).ravel(), minlength=7)
     rec = {"workload": workload, "metric": wl["metric"], "value": a.shots * eng.W * steps / el, "unit": wl.get("unit", "windows/s"),
            "shots_per_step": a.shots, "steps": steps, "ms_per_step": el / steps * 1e3,
-           "step_mode": ("two HIP streams in turn" if workload == "bp4" else "two-lane stream") if streaming else "one launch at a time",
+           "step_mode": ("four HIP streams in turn" if workload == "bp4" else "two-lane stream") if streaming else "one launch at a time",
            "ms_per_launch": avg_s * 1e3, "launches_timed": int(n), "exit_classes": [int(x) for x in cls[:7]],
            "roofline_bound": r["bound"], "roofline_frac": r["frac"], "roofline_achieved_GBps": r["achieved"], "roofline_peak_GBps": r["peak"],
            "lds_algorithmic_frac": r.get("lds_algorithmic_frac"),
@@ -775,7 +782,7 @@ def main():
     # the two-lane stream is the step mode where overlapping consecutive launches pays: the osd_window workloads and gdg() -- the next
     # launch's grid fills the tail of the previous one, and a stream's gdg() batches take the serial tree walk (1.19 -> 1.56 M windows/s,
     # round 6) and so do the threaded ensemble's (tickets instead of the work-item ring: +3-6 % at 4096 shots, +9 % at 16 384).
-    # bp4_osd: two HIP streams handed to swd_bp4_decode_batch_dev in turn (a launch ends on the few decodes that run all max_iter iterations)
+    # bp4_osd: four HIP streams handed to swd_bp4_decode_batch_dev in turn (a launch ends on the few decodes that run all max_iter iterations)
     streaming = not args.no_stream and not STUB
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not STUB and headline:
@@ -867,7 +874,7 @@ def main():
         # what closed the timed region: the RCCL (backend nccl) all_gather over this many ranks, or nothing (plain one-process run)
         "collective_backend": backend, "collective_ranks": dist_ranks, "rank_times": rank_times,
         "kernel_launches_timed": int(launches),
-        "step_mode": (("two HIP streams in turn (swd_bp4_decode_batch_dev): consecutive steps overlap" if args.workload == "bp4" else
+        "step_mode": (("four HIP streams in turn (swd_bp4_decode_batch_dev): consecutive steps overlap" if args.workload == "bp4" else
                        "two-lane stream (swd_pipeline_stream_push_dev): consecutive steps overlap") if streaming else "one launch at a time"),
         "single_stream_windows_per_s": (hi - lo) * W * launches / single_wall if launches else None,
         "single_stream_note": "this rank's shots, one launch at a time with HIP events and a host synchronisation per launch (the loop that times the kernel)",

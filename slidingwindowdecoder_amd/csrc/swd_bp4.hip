@@ -47,7 +47,7 @@ struct Bp4 {
     }
 };
 
-template <int WMAX, int NTO, int DM, bool FAST>
+template <int WMAX, int NTO, int DM, bool FAST, bool LAZY>
 static int bp4_launch(Bp4 *d, const SwdBp4Args &a0, hipStream_t st, int nt) {
     SwdBp4Args a = a0;
     a.split = (FAST && nt == d->nt_split) ? 1 : 0;
@@ -55,14 +55,14 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a0, hipStream_t st, int nt) {
     std::lock_guard<std::mutex> fn_lock(fn_mu);
     static int lds_limit[64] = {0};
     if (d->L.total > lds_limit[d->device & 63]) {
-        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<WMAX, DM, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
+        SWD_HIP(hipFuncSetAttribute((const void *)bp4_kernel<WMAX, DM, FAST, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, d->L.total));
         lds_limit[d->device & 63] = d->L.total;
     }
     // persistent grid: as many workgroups as the device holds at once, each walks its share of the units
     static int slots[64] = {0}, slots_lds[64] = {0}, slots_nt[64] = {0};
     if (!slots[d->device & 63] || slots_lds[d->device & 63] != d->L.total || slots_nt[d->device & 63] != nt) {
         int per_cu = 0, cus = 0;
-        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM, FAST>, nt, (size_t)d->L.total));
+        SWD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bp4_kernel<WMAX, DM, FAST, LAZY>, nt, (size_t)d->L.total));
         SWD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
         while (per_cu > 1 && (long long)per_cu * ((d->L.total + 2048 + 1279) / 1280 * 1280) > 160 * 1024) --per_cu; // LDS is granted in granules of 1280 B (swd_plan.h); + the kernel's 2 KB exp table
         slots[d->device & 63] = std::max(1, per_cu) * std::max(1, cus);
@@ -71,7 +71,7 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a0, hipStream_t st, int nt) {
     const int units = a.camel ? 4 * a.B : a.B;
     const bool with_osd = !a.camel && a.osd_order >= 0;
     if (with_osd || a.ticket) SWD_HIP(hipMemsetAsync(a.osd_count, 0, 4 * sizeof(uint32_t), st)); // (queue counter, ticket counter)
-    hipLaunchKernelGGL((bp4_kernel<WMAX, DM, FAST>), dim3(std::min(units, slots[d->device & 63])), dim3(nt), d->L.total, st, a);
+    hipLaunchKernelGGL((bp4_kernel<WMAX, DM, FAST, LAZY>), dim3(std::min(units, slots[d->device & 63])), dim3(nt), d->L.total, st, a);
     SWD_HIP(hipGetLastError());
     if (with_osd) { // the queue of unconverged decodes (often empty: its workgroups then read the count and leave)
         static int lds_limit2[64] = {0}, slots2[64] = {0}, slots2_lds[64] = {0};
@@ -93,15 +93,21 @@ static int bp4_launch(Bp4 *d, const SwdBp4Args &a0, hipStream_t st, int nt) {
     return 0;
 }
 
-template <int WMAX, int NTO, bool FAST>
+template <int WMAX, int NTO, bool FAST, bool LAZY = false>
 static int bp4_dispatch_dm(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) {
-    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4, FAST>(d, a, st, nt)
-                      : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8, FAST>(d, a, st, nt) : bp4_launch<WMAX, NTO, SWD_DMAX, FAST>(d, a, st, nt));
+    return d->dm == 4 ? bp4_launch<WMAX, NTO, 4, FAST, LAZY>(d, a, st, nt)
+                      : (d->dm == 8 ? bp4_launch<WMAX, NTO, 8, FAST, LAZY>(d, a, st, nt) : bp4_launch<WMAX, NTO, SWD_DMAX, FAST, LAZY>(d, a, st, nt));
 }
 template <bool FAST>
 static int bp4_dispatch_nt(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) {
     // BP kernel: one thread per qubit (two in the specialised launch) while the waves fit a workgroup; OSD kernel: the workgroups its
-    // layouts were made for
+    // layouts were made for.  The two-half node update (LAZY, swd_bp4_kernel.h) where it was measured to pay: one thread per qubit on up
+    // to four or on more than eight waves (profiles/r06_bp4_lazy.log); SWD_BP4_NO_LAZY: never
+    static const bool lazy_ok = getenv("SWD_BP4_NO_LAZY") == nullptr;
+    if constexpr (FAST) {
+        if (lazy_ok && nt <= 256 && nt != d->nt_split) return bp4_dispatch_dm<4, 256, true, true>(d, a, st, nt);
+        if (lazy_ok && nt > 512) return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256, true, true>(d, a, st, nt) : bp4_dispatch_dm<16, 1024, true, true>(d, a, st, nt);
+    }
     if (nt <= 256) return bp4_dispatch_dm<4, 256, FAST>(d, a, st, nt); // (n <= 3072: the OSD layouts are those of 256 threads)
     if (nt <= 512) return bp4_dispatch_dm<8, 256, FAST>(d, a, st, nt); // (still six waves per SIMD: three workgroups of up to eight waves per CU)
     return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256, FAST>(d, a, st, nt) : bp4_dispatch_dm<16, 1024, FAST>(d, a, st, nt);

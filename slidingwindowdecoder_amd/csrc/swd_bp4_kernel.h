@@ -155,6 +155,12 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 #ifndef SWD_BP4_ROLLED
 #define SWD_BP4_ROLLED 1 // the variable-node update's per-edge loops as loops (one helper body per basis; SHYPS r = 3 +10 %, the BB codes unchanged, half the compile time)
 #endif
+#ifndef SWD_BP4_LAZY_MSG
+#define SWD_BP4_LAZY_MSG 1 // the node update's message half runs only when another check pass follows (round 6; needs SWD_BP4_ROLLED)
+#endif
+#ifndef SWD_BP4_LAZY_ITS
+#define SWD_BP4_LAZY_ITS 3 // ... in a decode's first iterations (the iterations of the decodes that stop early)
+#endif
 #ifndef SWD_BP4_PRIO_IT
 #define SWD_BP4_PRIO_IT 3 // iteration from which a decode's waves run at raised priority (-1: never)
 #endif
@@ -171,7 +177,11 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 // FAST (round 6): the launch of the notebooks' codes -- every qubit has a thread (n <= NT), every check of both graphs has a thread
 // (mx + mz <= NT), no camel run -- as its own instantiation: the generic paths (strided node loops, per-graph check passes, the
 // decided qubit of camel_decode, loads of the graph tables inside the iterations) are compiled out.
-template <int WMAX, int DM, bool FAST>
+// LAZY (round 6): the two-half variable-node update in a decode's first iterations (below).  An instantiation of its own: it pays where the
+// register budget has room for both forms of the update -- one thread per qubit on up to four waves (96 registers) or on 9-16 waves (128):
+// [[144]] 58 -> 65 M decodes/s with two launches in flight, [[756]] 7.1 -> 8.8 -- and costs ~10 % where it has not (the eight-wave
+// workgroups' 80 registers, the two-threads-per-qubit launches of the small codes): the launcher picks (swd_bp4.hip, bp4_dispatch_nt).
+template <int WMAX, int DM, bool FAST, bool LAZY = false>
 __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 1)) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // glibc's exp table (swd_libm.h) in LDS: tail and scale of an entry are one aligned 16-byte read
@@ -312,7 +322,132 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
     // bp4_decode_llr (bp4_osd.pyx:444-481)
     int conv = 0, iters = 0;
     const int lane0z = (mx + mz <= NT) ? mx : 0; // Hz checks on the lanes after the Hx ones when both fit
+    // Round 6: in a decode's first SWD_BP4_LAZY_ITS iterations the variable-node update runs in two halves with the convergence test between them.  Half A is what the test and the outputs
+    // need -- sums of the check messages, the three posteriors, the hard decision, its parity flips; half B, the new bit-to-check
+    // messages (a log1pexp and a logaddexp per edge: most of a decode's arithmetic), only feeds the NEXT check pass and is skipped when the
+    // decode stops here -- for the notebooks' noise rates after the first update in three decodes out of four.  Outputs are those of
+    // the reference's "update everything, then test" (bp4_osd.pyx:444-481): nothing reads the messages of a decode that has ended.
+    // A decode that is still running after those iterations is one of the few that run for long: it goes on with the fused update of
+    // rounds 4-5 (two barriers per iteration instead of four; the test of an update is made by the next check pass).
     for (int it = 0; it < a.max_iter; ++it) {
+#if SWD_BP4_LAZY_MSG && SWD_BP4_ROLLED
+        if constexpr (LAZY) if (it < SWD_BP4_LAZY_ITS) {
+        if (SWD_BP4_PRIO_IT >= 0 && it == SWD_BP4_PRIO_IT) __builtin_amdgcn_s_setprio(2);
+        if (own) {
+            if (o_l >= 0) (void)bp4_cn_one(o_msg, o_jp, o_cn, o_par, o_l, o_deg, 0, a.alpha);
+        } else {
+            (void)bp4_cn_pass(NT, gx, msgx, jpx, cnx, parx, 0, 0, a.alpha);
+            (void)bp4_cn_pass(NT, gz, msgz, jpz, cnz, parz, lane0z, 0, a.alpha);
+        }
+        BP4T(1) // check passes
+        __syncthreads();
+        BP4T(2)
+        // the node's edge words, check messages and sums (bp4_osd.pyx:533-558); the same operations in the same order in both halves
+        auto node_sums = [&](int v, uint32_t (&ex)[DM], uint32_t (&ez)[DM], int &dx, int &dz, double &lx, double &ly, double &lz) {
+            dx = one ? c_dx : (int)gx.col_deg[v]; dz = one ? c_dz : (int)gz.col_deg[v];
+            double cx[DM], cz[DM];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                ex[k] = one ? c_ex[k] : ((k < dx) ? gx.vn_edge[k * n + v] : 0u);
+                ez[k] = one ? c_ez[k] : ((k < dz) ? gz.vn_edge[k * n + v] : 0u);
+            }
+            const double v_lx = one ? c_lx : a.llr_x[v], v_ly = one ? c_ly : a.llr_y[v], v_lz = one ? c_lz : a.llr_z[v];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) { cx[k] = msgx[swd_edge_slot(ex[k])]; cz[k] = msgz[swd_edge_slot(ez[k])]; }
+            double llrx_hx = 0.0, llrz_hz = 0.0;
+#pragma unroll
+            for (int k = 0; k < DM; ++k) if (k < dz) llrx_hx += cz[k];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) if (k < dx) llrz_hz += cx[k];
+            ly = llrx_hx + llrz_hz + v_ly;
+            lx = llrx_hx + v_lx;
+            lz = llrz_hz + v_lz;
+        };
+        auto pick = [&](const uint32_t (&ev)[DM], int k) { uint32_t e = ev[0];
+#pragma unroll
+            for (int j = 1; j < DM; ++j) e = (k == j) ? ev[j] : e;
+            return e; };
+        double k_lx = 0.0, k_ly = 0.0, k_lz = 0.0; // (one node per thread) the sums of half A, kept for half B
+        for (int v = vt; v < n; v += NT) { // half A
+            if (v == fixed) continue; // (decided, bp4_osd.pyx:456-458: its parity flips went into the checks' syndrome bits)
+            uint32_t ex[DM], ez[DM];
+            int dx, dz;
+            double llrx_hx, llry_all, llrz_hz;
+            node_sums(v, ex, ez, dx, dz, llrx_hx, llry_all, llrz_hz);
+            if (one) { p_x = llrx_hx; p_y = llry_all; p_z = llrz_hz; p_set = (hsel & 1) != 0; k_lx = llrx_hx; k_ly = llry_all; k_lz = llrz_hz; }
+            else { lpr_b[v] = llrx_hx; lpr_b[n + v] = llry_all; lpr_b[2 * n + v] = llrz_hz; }
+            int idx;
+            if (0 < llrx_hx && 0 < llry_all && 0 < llrz_hz) idx = 0;
+            else if (llrx_hx < llry_all && llrx_hx < llrz_hz) idx = 1;
+            else if (llry_all > llrz_hz) idx = 2;
+            else idx = 3;
+            const int bx = idx & 1, bz = idx >> 1;
+            if (hsel & 1) { decx[v] = (uint8_t)bx; decz[v] = (uint8_t)bz; }
+            if (bz && (hsel & 1)) // Hx * z-string
+#pragma unroll 1
+                for (int k = 0; k < dx; ++k) atomicXor(&parx[swd_edge_lane(pick(ex, k))], 1u);
+            if (bx && (hsel & 2)) // Hz * x-string
+#pragma unroll 1
+                for (int k = 0; k < dz; ++k) atomicXor(&parz[swd_edge_lane(pick(ez, k))], 1u);
+        }
+        BP4T(3) // node: message loads, sums, posteriors, decision, parity flips
+        __syncthreads();
+        bool unsat = false;
+        if (own) { if (o_l >= 0) unsat = o_par[o_l] != 0u; }
+        else {
+            for (int l = tid; l < mx; l += NT) if (parx[l] != 0u) unsat = true;
+            for (int l = tid; l < mz; l += NT) if (parz[l] != 0u) unsat = true;
+        }
+        const bool any = bp4_block_any(unsat, s, NT >> 6);
+        BP4T(7)
+#ifdef SWD_BP4PROF
+        ++q_iters;
+#endif
+        if (!any) { conv = 1; iters = it + 1; break; }
+        if (it + 1 >= a.max_iter) break; // (the messages of the last update feed no check pass)
+        for (int v = vt; v < n; v += NT) { // half B: the new bit-to-check messages (bp4_osd.pyx:571-589)
+            if (v == fixed) { // decided: its bit-to-check messages stay the priors of bp_init; the CN pass has overwritten the shared
+                              // slots with check-to-bit values, so put them back
+                const double llrx = a.llr_x[v], llry = a.llr_y[v], llrz = a.llr_z[v];
+                const double m_x = bp4_log1pexp(-1. * llrx, xt) - bp4_logaddexp(-1. * llry, -1. * llrz, xt);
+                const double m_z = bp4_log1pexp(-1. * llrz, xt) - bp4_logaddexp(-1. * llry, -1. * llrz, xt);
+                for (int k = 0; k < gx.col_deg[v]; ++k) msgx[swd_edge_slot(gx.vn_edge[k * n + v])] = m_x;
+                for (int k = 0; k < gz.col_deg[v]; ++k) msgz[swd_edge_slot(gz.vn_edge[k * n + v])] = m_z;
+                continue;
+            }
+            uint32_t ex[DM], ez[DM];
+            int dx, dz;
+            double llrx_hx, llry_all, llrz_hz;
+            if (one) {
+                dx = c_dx; dz = c_dz; llrx_hx = k_lx; llry_all = k_ly; llrz_hz = k_lz;
+#pragma unroll
+                for (int k = 0; k < DM; ++k) { ex[k] = c_ex[k]; ez[k] = c_ez[k]; }
+            } else node_sums(v, ex, ez, dx, dz, llrx_hx, llry_all, llrz_hz);
+            const double num_hx = (hsel & 1) ? bp4_log1pexp(-1. * llrx_hx, xt) : 0.0;
+            BP4T(4) // log1pexp
+#pragma unroll 1
+            for (int k = 0; k < ((hsel & 1) ? dx : 0); ++k) {
+                const uint32_t e = pick(ex, k);
+                const double c = msgx[swd_edge_slot(e)];
+                const double aa = llrz_hz - c, bb = llry_all - c;
+                msgx[swd_edge_slot(e)] = num_hx - bp4_logaddexp(-1. * aa, -1. * bb, xt);
+            }
+            BP4T(5) // Hx edges: logaddexp + store each
+            const double num_hz = (hsel & 2) ? bp4_log1pexp(-1. * llrz_hz, xt) : 0.0;
+            BP4T(4)
+#pragma unroll 1
+            for (int k = 0; k < ((hsel & 2) ? dz : 0); ++k) {
+                const uint32_t e = pick(ez, k);
+                const double c = msgz[swd_edge_slot(e)];
+                const double aa = llrx_hx - c, bb = llry_all - c;
+                msgz[swd_edge_slot(e)] = num_hz - bp4_logaddexp(-1. * aa, -1. * bb, xt);
+            }
+            BP4T(6) // Hz edges
+        }
+        __syncthreads();
+            continue;
+        }
+#endif
         // a decode that is still running after a few iterations is one of the few that will run for long: its waves issue ahead of
         // the others on their SIMDs from here on (what ends a launch is the last of these decodes, not the device's throughput)
         if (SWD_BP4_PRIO_IT >= 0 && it == SWD_BP4_PRIO_IT) __builtin_amdgcn_s_setprio(2);
@@ -416,7 +551,7 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
 #ifdef SWD_BP4PROF
         ++q_iters;
 #endif
-    }
+        }
     if (SWD_BP4_PRIO_IT >= 0) __builtin_amdgcn_s_setprio(0);
     // the next unit's ticket: drawn as soon as this decode's iterations are over, so that the atomic's round trip overlaps the stores below
     if (a.ticket && tid == 0) tk_next = gridDim.x + atomicAdd(a.ticket, 1u);
