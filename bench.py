@@ -296,6 +296,10 @@ class GpuEngine:
         self.stream = self.dec.stream(shots) if streaming else None
         self.nstep = 0
         self.last = 0
+        if streaming:  # one launch per lane before anything is timed (the first launch on a lane creates its hardware queue and its buffers)
+            for k in range(2):
+                self.stream.push_device(self.dets[0], min_pm=None, **self.out[k])
+            self.stream.wait()
 
     @property
     def shot(self):  # decisions of the most recent step
@@ -380,6 +384,10 @@ class Bp4Engine:
         self.stat = [torch.empty((shots, 8), dtype=torch.int32, device=self.dev) for _ in range(self.nl)]
         # (streams of both priorities: streams of one priority may share a hardware queue, and those that do run back to back -- swd_osdw.hip)
         self.lanes = [torch.cuda.Stream(self.dev, priority=-(i & 1)) for i in range(self.nl)] if streaming else None
+        for k, lane in enumerate(self.lanes or []):  # the first launch on a stream creates its hardware queue: not inside a timed step
+            lane.wait_stream(torch.cuda.current_stream(self.dev))
+            self.dec.decode_batch_device(self.sx[0], self.sz[0], out=self.outs[k], stats=self.stat[k], stream=lane)
+        torch.cuda.synchronize()
         self.nstep = self.last = 0
         self.timing, self.events = False, []
 
