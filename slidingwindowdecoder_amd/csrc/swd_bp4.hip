@@ -263,7 +263,11 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
         // ([[144]], two streams in turn: 55.4 -> 58.7 M decodes/s without them)
         static const bool by_weight = getenv("SWD_BP4_NO_ORDER") == nullptr;
         static const bool always = getenv("SWD_BP4_ORDER_ALWAYS") != nullptr;
-        const bool overlapped = !always && d->last_done && d->last_stream != st && hipEventQuery(d->last_done) == hipErrorNotReady;
+        bool overlapped = false;
+        if (!always && d->last_done && d->last_stream != st) {
+            overlapped = hipEventQuery(d->last_done) == hipErrorNotReady;
+            (void)hipGetLastError(); // ("not ready" is an answer, not an error: it must not be what the launch checks below pick up)
+        }
         if (by_weight && !overlapped) {
             uint32_t *wt = sl->osd_q.as<uint32_t>() + 4 + B, *ord = wt + B;
             hipLaunchKernelGGL(bp4_weight_kernel, dim3((B + 3) / 4), dim3(256), 0, st, sx, sz, d->gx.m, d->gz.m, B, wt);
