@@ -181,8 +181,14 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 // register budget has room for both forms of the update -- one thread per qubit on up to four waves (96 registers) or on 9-16 waves (128):
 // [[144]] 58 -> 65 M decodes/s with two launches in flight, [[756]] 7.1 -> 8.8 -- and costs ~10 % where it has not (the eight-wave
 // workgroups' 80 registers, the two-threads-per-qubit launches of the small codes): the launcher picks (swd_bp4.hip, bp4_dispatch_nt).
+// The LAZY instantiation of up to four waves is compiled for three waves per SIMD (139 registers, 48 B of scratch) instead of five (96 and
+// 224 B): its short decodes are chains of dependent steps that want their values in registers more than they want neighbours --
+// [[144]], 1 / 2 / 3 / 4 launches in flight: 36.7 / 67.4 / 73.5 / 78.9 -> 37.4 / 73.5 / 78.2 / 84.3 M decodes/s (four waves: 38.0 / 69.7 / 76.8 / 81.8).
+#ifndef SWD_BP4_WAVES_LAZY
+#define SWD_BP4_WAVES_LAZY 3
+#endif
 template <int WMAX, int DM, bool FAST, bool LAZY = false>
-__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 1)) bp4_kernel(const SwdBp4Args a) {
+__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? ((LAZY && WMAX <= 4) ? SWD_BP4_WAVES_LAZY : SWD_BP4_WAVES(WMAX)) : 1)) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // glibc's exp table (swd_libm.h) in LDS: tail and scale of an entry are one aligned 16-byte read
     __shared__ __attribute__((aligned(16))) uint64_t s_exptab[256];
@@ -367,14 +373,13 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
 #pragma unroll
             for (int j = 1; j < DM; ++j) e = (k == j) ? ev[j] : e;
             return e; };
-        double k_lx = 0.0, k_ly = 0.0, k_lz = 0.0; // (one node per thread) the sums of half A, kept for half B
         for (int v = vt; v < n; v += NT) { // half A
             if (v == fixed) continue; // (decided, bp4_osd.pyx:456-458: its parity flips went into the checks' syndrome bits)
             uint32_t ex[DM], ez[DM];
             int dx, dz;
             double llrx_hx, llry_all, llrz_hz;
             node_sums(v, ex, ez, dx, dz, llrx_hx, llry_all, llrz_hz);
-            if (one) { p_x = llrx_hx; p_y = llry_all; p_z = llrz_hz; p_set = (hsel & 1) != 0; k_lx = llrx_hx; k_ly = llry_all; k_lz = llrz_hz; }
+            if (one) { p_x = llrx_hx; p_y = llry_all; p_z = llrz_hz; p_set = (hsel & 1) != 0; }
             else { lpr_b[v] = llrx_hx; lpr_b[n + v] = llry_all; lpr_b[2 * n + v] = llrz_hz; }
             int idx;
             if (0 < llrx_hx && 0 < llry_all && 0 < llrz_hz) idx = 0;
@@ -418,11 +423,9 @@ __global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? SWD_BP4_WAVES(WMAX) : 
             uint32_t ex[DM], ez[DM];
             int dx, dz;
             double llrx_hx, llry_all, llrz_hz;
-            if (one) {
-                dx = c_dx; dz = c_dz; llrx_hx = k_lx; llry_all = k_ly; llrz_hz = k_lz;
-#pragma unroll
-                for (int k = 0; k < DM; ++k) { ex[k] = c_ex[k]; ez[k] = c_ez[k]; }
-            } else node_sums(v, ex, ez, dx, dz, llrx_hx, llry_all, llrz_hz);
+            // (the sums of half A again, from the check messages it left untouched: holding them across the test costs registers this
+            // kernel does not have -- [[144]], 4 launches in flight: 73 -> 79 M decodes/s without them)
+            node_sums(v, ex, ez, dx, dz, llrx_hx, llry_all, llrz_hz);
             const double num_hx = (hsel & 1) ? bp4_log1pexp(-1. * llrx_hx, xt) : 0.0;
             BP4T(4) // log1pexp
 #pragma unroll 1
