@@ -101,11 +101,12 @@ static int bp4_dispatch_dm(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) 
 template <bool FAST>
 static int bp4_dispatch_nt(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) {
     // BP kernel: one thread per qubit (two in the specialised launch) while the waves fit a workgroup; OSD kernel: the workgroups its
-    // layouts were made for.  The two-half node update (LAZY, swd_bp4_kernel.h) where it was measured to pay: one thread per qubit on up
-    // to four or on more than eight waves (profiles/r06_bp4_lazy.log); SWD_BP4_NO_LAZY: never
+    // layouts were made for.  The two-half node update (LAZY, swd_bp4_kernel.h) where it was measured to pay: every launch with one thread
+    // per qubit (profiles/r06_bp4_lazy.log; the two-threads-per-qubit launches of the small codes keep the fused update); SWD_BP4_NO_LAZY: never
     static const bool lazy_ok = getenv("SWD_BP4_NO_LAZY") == nullptr;
     if constexpr (FAST) {
         if (lazy_ok && nt <= 256 && nt != d->nt_split) return bp4_dispatch_dm<4, 256, true, true>(d, a, st, nt);
+        if (lazy_ok && nt > 256 && nt <= 512) return bp4_dispatch_dm<8, 256, true, true>(d, a, st, nt);
         if (lazy_ok && nt > 512) return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256, true, true>(d, a, st, nt) : bp4_dispatch_dm<16, 1024, true, true>(d, a, st, nt);
     }
     if (nt <= 256) return bp4_dispatch_dm<4, 256, FAST>(d, a, st, nt); // (n <= 3072: the OSD layouts are those of 256 threads)

@@ -177,10 +177,10 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 // FAST (round 6): the launch of the notebooks' codes -- every qubit has a thread (n <= NT), every check of both graphs has a thread
 // (mx + mz <= NT), no camel run -- as its own instantiation: the generic paths (strided node loops, per-graph check passes, the
 // decided qubit of camel_decode, loads of the graph tables inside the iterations) are compiled out.
-// LAZY (round 6): the two-half variable-node update in a decode's first iterations (below).  An instantiation of its own: it pays where the
-// register budget has room for both forms of the update -- one thread per qubit on up to four waves (96 registers) or on 9-16 waves (128):
-// [[144]] 58 -> 65 M decodes/s with two launches in flight, [[756]] 7.1 -> 8.8 -- and costs ~10 % where it has not (the eight-wave
-// workgroups' 80 registers, the two-threads-per-qubit launches of the small codes): the launcher picks (swd_bp4.hip, bp4_dispatch_nt).
+// LAZY (round 6): the two-half variable-node update in a decode's first iterations (below).  An instantiation of its own, compiled for fewer
+// waves per SIMD than the fused form: it pays when the register budget has room for both forms of the update (at the fused form's budgets it
+// cost ~10 % on the eight-wave workgroups) -- [[144]] 58 -> 72 M decodes/s with two launches in flight, [[756]] 7.1 -> 9.3.  The launcher takes
+// it for every launch with one thread per qubit (swd_bp4.hip, bp4_dispatch_nt); the two-threads-per-qubit launches keep the fused update.
 // The LAZY instantiation of up to four waves is compiled for three waves per SIMD (139 registers, 48 B of scratch) instead of five (96 and
 // 224 B): its short decodes are chains of dependent steps that want their values in registers more than they want neighbours --
 // [[144]], 1 / 2 / 3 / 4 launches in flight: 36.7 / 67.4 / 73.5 / 78.9 -> 37.4 / 73.5 / 78.2 / 84.3 M decodes/s (four waves: 38.0 / 69.7 / 76.8 / 81.8).
@@ -188,7 +188,10 @@ __device__ __forceinline__ bool bp4_cn_pass(int nthreads, const SwdGraphDev &g, 
 #define SWD_BP4_WAVES_LAZY 3
 #endif
 template <int WMAX, int DM, bool FAST, bool LAZY = false>
-__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? ((LAZY && WMAX <= 4) ? SWD_BP4_WAVES_LAZY : SWD_BP4_WAVES(WMAX)) : 1)) bp4_kernel(const SwdBp4Args a) {
+#ifndef SWD_BP4_WAVES_LAZY8
+#define SWD_BP4_WAVES_LAZY8 4 // ... and the five- to eight-wave ones for four (128 registers, 96 B; six: 80 registers, the fused form's choice): [[288]] 19.6 -> 22.8 M decodes/s one launch at a time, 26.8 -> 32.0 M with two in flight; [[360]] 15.7 -> 20.7, 20.5 -> 27.7 (three waves: 15.4 / 19.9, 14.1 / 18.3)
+#endif
+__global__ void __launch_bounds__(WMAX * 64, (WMAX <= 8 ? (LAZY ? (WMAX <= 4 ? SWD_BP4_WAVES_LAZY : SWD_BP4_WAVES_LAZY8) : SWD_BP4_WAVES(WMAX)) : 1)) bp4_kernel(const SwdBp4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // glibc's exp table (swd_libm.h) in LDS: tail and scale of an entry are one aligned 16-byte read
     __shared__ __attribute__((aligned(16))) uint64_t s_exptab[256];
