@@ -34,6 +34,7 @@ struct Bp4 {
     int next_slot = 0;
     hipEvent_t last_done = nullptr; // (under mu) end of the most recent decode launch and the stream it ran on
     hipStream_t last_stream = nullptr;
+    bool overlapped = false;        // (under mu) the launch being prepared found the previous one still running on another stream
     std::mutex mu;
     ~Bp4() { for (auto &sl : slot) if (sl.done) (void)hipEventDestroy(sl.done); }
     // the next slot, ordered behind its previous launch on `st` (call under mu)
@@ -105,7 +106,9 @@ static int bp4_dispatch_nt(Bp4 *d, const SwdBp4Args &a, hipStream_t st, int nt) 
     // per qubit (profiles/r06_bp4_lazy.log; the two-threads-per-qubit launches of the small codes keep the fused update); SWD_BP4_NO_LAZY: never
     static const bool lazy_ok = getenv("SWD_BP4_NO_LAZY") == nullptr;
     if constexpr (FAST) {
-        if (lazy_ok && nt <= 256 && nt != d->nt_split) return bp4_dispatch_dm<4, 256, true, true>(d, a, st, nt);
+        // (two threads per qubit: the fused form one launch at a time, the two-half form when another launch is in flight beside this one --
+        // SHYPS r = 3, two streams: 33.2 -> 40.8 M decodes/s, [[72]] 70.7 / 70.0; one at a time it loses 5-7 %)
+        if (lazy_ok && nt <= 256 && (nt != d->nt_split || d->overlapped)) return bp4_dispatch_dm<4, 256, true, true>(d, a, st, nt);
         if (lazy_ok && nt > 256 && nt <= 512) return bp4_dispatch_dm<8, 256, true, true>(d, a, st, nt);
         if (lazy_ok && nt > 512) return d->nt_osd == 256 ? bp4_dispatch_dm<16, 256, true, true>(d, a, st, nt) : bp4_dispatch_dm<16, 1024, true, true>(d, a, st, nt);
     }
@@ -253,6 +256,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
     for (auto &s2 : d->slot) if (s2.osd_q.reserve((size_t)B * 12 + 16)) return -1;
     a.osd_count = sl->osd_q.as<uint32_t>(); a.osd_list = sl->osd_q.as<int32_t>() + 4;
     static const bool static_units = getenv("SWD_BP4_STATIC") != nullptr; // (diagnostics: the static shares of rounds 4-5)
+    d->overlapped = false;
     if (!static_units) {
         a.ticket = a.osd_count + 1;
         // start order: heaviest syndrome first.  The decodes that run all max_iter iterations are NOT the heaviest ones ([[144]]: weights 5-25
@@ -269,6 +273,7 @@ extern "C" int swd_bp4_decode_batch_dev(swd_bp4 *h, int32_t B, const uint8_t *sx
             overlapped = hipEventQuery(d->last_done) == hipErrorNotReady;
             (void)hipGetLastError(); // ("not ready" is an answer, not an error: it must not be what the launch checks below pick up)
         }
+        d->overlapped = overlapped;
         if (by_weight && !overlapped) {
             uint32_t *wt = sl->osd_q.as<uint32_t>() + 4 + B, *ord = wt + B;
             hipLaunchKernelGGL(bp4_weight_kernel, dim3((B + 3) / 4), dim3(256), 0, st, sx, sz, d->gx.m, d->gz.m, B, wt);
