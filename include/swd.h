@@ -270,7 +270,9 @@ int swd_pipeline_decode_packed(swd_pipeline *pl, int32_t B, const uint8_t *det, 
  * grid takes the workgroup slots that the tail of batch k leaves empty, and the copy-out / unpacking of batch k overlaps the
  * launch of k + 1.  Results are those of swd_pipeline_decode, batch by batch, in push order.  (Guessing decoders: a stream batch of
  * 3072 shots or more walks each decimation tree serially instead of spreading its side branches over the grid as work items --
- * the next batch fills the tail the serial walk leaves; same results, statistics word 7 aside.)
+ * the next batch fills the tail the serial walk leaves; same results, statistics word 7 aside.  A caller that alternates streams of
+ * its own with swd_pipeline_decode_dev gets the same choice: a launch that finds the handle's previous launch still running on
+ * another stream is treated as a stream batch.)
  *   flags  SWD_STREAM_PACKED    total_e_hat is returned bit-packed (layout of swd_pipeline_decode_packed)
  *          SWD_STREAM_NO_STATS  per-window stats / min_pm are not copied back (pop takes NULL for them)
  * Host form: push(det [B*num_det]) enqueues copy-in + launch + copy-out on the next lane and returns at once; pop() waits for

@@ -239,7 +239,13 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
     // [[144]] GDG windows, 4096 shots per batch: 1.19 M windows/s one launch at a time (work items), 1.21 M streamed with work items,
     // 1.56 M streamed with the serial walk; streamed, serial against work items: 1024 shots 14.6 / 12.4 ms per batch, 2048 26.1 / 21.9,
     // 3072 25.3 / 29.6, 4096 28.9 / 37.3 (profiles/r06_gdg_stream.log)
-    d->stream_serial = d->stream_push && a.B >= stream_serial_min; // (the threaded ensemble's launcher reads it too: swd_plan.h, KIND 7)
+    // (a caller that alternates streams of its own is in the same position: the previous launch of this handle still runs on another stream)
+    bool overlapped = false;
+    if (d->kind == 1 && !d->stream_push && d->last_done && d->last_stream != st) {
+        overlapped = hipEventQuery(d->last_done) == hipErrorNotReady;
+        (void)hipGetLastError(); // ("not ready" is an answer, not an error)
+    }
+    d->stream_serial = (d->stream_push || overlapped) && a.B >= stream_serial_min; // (the threaded ensemble's launcher reads it too: swd_plan.h, KIND 7)
     const bool par = d->kind == 1 && d->gdg_parallel && !a.hist && d->variant->launch_par && a.B <= par_max_shots && a.B < SWD_GDG_ITEM_MAX_SHOTS &&
                      !d->stream_serial;
     // osd_window: when the posterior history is only consumed as its slot-order sum (no history in or out, both
@@ -251,6 +257,7 @@ static int launch(Plan *d, const SwdPipeArgs &a0, hipStream_t st) {
                         : (ens ? d->variant->launch_ens(d, a, st) : (par ? d->variant->launch_par(d, a, st) : d->variant->launch_gdg(d, a, st)));
     if (rc) return rc;
     SWD_HIP(hipEventRecord(sl.done, st));
+    d->last_done = sl.done; d->last_stream = st;
     if (d->timing) {
         SWD_HIP(hipEventRecord(d->ev1, st));
         SWD_HIP(hipEventSynchronize(d->ev1));

@@ -98,6 +98,8 @@ struct Plan {
     bool gdg_parallel = false; // bpgdg: side branches of the decimation tree run as work items on the persistent grid
     bool stream_push = false;  // (under mu) the launch being prepared comes from a stream object: another batch follows or is in flight
     bool stream_serial = false; // (under mu) ... and is large enough for the guessing decoders' ticket-scheduled forms (launch())
+    hipEvent_t last_done = nullptr; // (under mu) end of the most recent launch and its stream: a launch that finds it still running on
+    hipStream_t last_stream = nullptr; // another stream is a stream batch in all but name
     int new_n_max = 0;
     int max_guess = 0;
     int64_t snap_stride = 0;

@@ -146,6 +146,17 @@ def test_gdg_stream_batches_take_the_serial_walk_and_equal_the_recorded_run(seri
         assert np.array_equal(o["total"].cpu().numpy(), np.tile(want, (nrep, 1))) and np.array_equal(o["stats"].cpu().numpy()[..., :7], np.tile(st0, (nrep, 1, 1)))
     dec.check_status()
     s.close()
+    # a caller's own two streams in turn (no stream object): a launch that finds the previous one still running on the other stream is
+    # scheduled like a stream batch -- same records
+    lanes = [torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1)]
+    for ln in lanes:
+        ln.wait_stream(torch.cuda.current_stream(dev))
+    for i in range(6):
+        dec.decode_device(d_t, stream=lanes[i % 2], **outs[i % 2])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o["total"].cpu().numpy(), np.tile(want, (nrep, 1))) and np.array_equal(o["stats"].cpu().numpy()[..., :7], np.tile(st0, (nrep, 1, 1)))
+    dec.check_status()
 
 
 @pytest.mark.parametrize("tag", ["d4s20", "d3s10"])
