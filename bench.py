@@ -671,7 +671,6 @@ def measure_other_workload(workload, args, rank, local_rank, steps=5, shots=None
     wl = WORKLOADS[workload]
     a = copy.copy(args)
     a.workload, a.shots, a.steps, a.warmup = workload, (shots or default_shots(workload)), steps, 1
-    osdw = workload in ("bb288", "global144")
     streaming = not args.no_stream
     t_setup = time.perf_counter()
     if workload == "bp4":
