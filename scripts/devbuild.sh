@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../slidingwindowdecoder_amd/csrc"
 mkdir -p build
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None -I../../include -I. ${SWD_DEV_VARIANTS:--DSWD_HEADLINE_ONLY}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=${SWD_SCHED:-iterative-ilp} -mllvm -amdgpu-atomic-optimizer-strategy=None -I../../include -I. ${SWD_DEV_VARIANTS:--DSWD_HEADLINE_ONLY}"
 for f in swd_osdw swd_kernels_k0 swd_kernels_k1 swd_kernels_k2 swd_kernels_k3 swd_kernels_k7; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o build/${f}_dev.o &
 done
